@@ -1,0 +1,159 @@
+/* CPU ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C restatement of the batched particle world (simple_spread /
+ * simple_tag) in two precisions:
+ *   *_f64  NumPy-float64 semantics of the canonical upstream `multiagent`
+ *          package the reference imports (experiments/scenarios.py:2-3) --
+ *          libm exp/log1p, i.e. np.logaddexp's stable form.
+ *   *_f32  the SAME operation order in IEEE float32 with a deterministic,
+ *          libm-free softplus/exp (only + - * / sqrt, no FMA contraction), so
+ *          the HIP kernels can be compared BIT FOR BIT, integer collision
+ *          masks included.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  Nothing under multiagent_rl_amd/ links or calls it.
+ *
+ * PARITY UNPINNED: the reference holds no golden vectors for this path and the
+ * arithmetic lives in an un-vendored, un-pinned third-party package
+ * (SURVEY.md section 0, 8(c)).  This file is validated against
+ * oracle/particle_oracle.py (the upstream-structured scalar NumPy
+ * restatement) and hand-derived known-answer tests (tests/test_oracle_kat.py).
+ *
+ * Build (see oracle/Makefile): gcc -O2 -ffp-contract=off -fno-fast-math
+ *                              -fPIC -shared -o libpworld_oracle.so pworld_oracle.c -lm
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+#define PO_EXPORT __attribute__((visibility("default")))
+#define PO_MAX_AGENTS 64
+#define PO_MAX_ENTITIES 192
+enum { PO_SIMPLE_SPREAD = 0, PO_SIMPLE_TAG = 1 };
+enum { PO_OBS_LOCAL = 0, PO_OBS_FULL = 1 };
+
+typedef struct po_config {
+    int32_t scenario;
+    int32_t num_agents;
+    int32_t num_landmarks;
+    int32_t num_adversaries;       /* simple_tag: agents [0, A) are adversaries */
+    int32_t obs_mode;
+    int32_t max_episode_len;       /* rls/arglist.py:5 -> 25; 0 = never terminal */
+    int32_t auto_reset;
+    int32_t force_discrete_action; /* experiments/scenarios.py:191 */
+    int32_t landmark_collide;
+    int32_t action_force_uses_accel; /* fork knob, canonical 0 */
+    uint64_t seed;
+    uint64_t env_id_base;
+    double dt, damping, contact_force, contact_margin, default_sensitivity, mass, landmark_size;
+    double agent_size[PO_MAX_AGENTS];
+    double agent_accel[PO_MAX_AGENTS];     /* < 0 : None */
+    double agent_max_speed[PO_MAX_AGENTS]; /* < 0 : None */
+} po_config;
+
+PO_EXPORT int po_config_size(void) { return (int)sizeof(po_config); }
+
+PO_EXPORT int po_obs_dim(const po_config *c)
+{
+    const int N = c->num_agents, L = c->num_landmarks;
+    if (c->scenario == PO_SIMPLE_SPREAD)
+        return c->obs_mode == PO_OBS_FULL ? 4 + 2 * L + 4 * (N - 1) : 4 + 2 * L;
+    /* simple_tag: adversary rows are the widest (see all G good velocities) */
+    const int G = N - c->num_adversaries;
+    return 4 + 2 * L + 2 * (N - 1) + 2 * (c->num_adversaries > 0 ? G : G - 1);
+}
+
+/* ---- deterministic float32 math (restated, not shared, from include/pworld_math.h) ---- */
+static inline float po_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* exp(x), x in (-87, 88); x <= -87 -> 0 exactly; x >= 88 -> 2^127 */
+PO_EXPORT float po_exp_det_f32(float x)
+{
+    if (!(x > -87.0f)) return x != x ? x : 0.0f;
+    if (x >= 88.0f) return po_u2f(0x7f000000u);
+    float t = x * 1.44269504088896341f;
+    float n = floorf(t + 0.5f);
+    float r = x - n * 0.693359375f;         /* ln2 hi (exact in 9 bits) */
+    r = r - n * -2.12194440054690583e-4f;   /* ln2 lo */
+    float p = 1.98412698412698413e-4f;      /* 1/5040 */
+    p = p * r + 1.38888888888888894e-3f;    /* 1/720 */
+    p = p * r + 8.33333333333333322e-3f;    /* 1/120 */
+    p = p * r + 4.16666666666666644e-2f;    /* 1/24 */
+    p = p * r + 1.66666666666666657e-1f;    /* 1/6 */
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    int32_t e = (int32_t)n + 127;
+    return p * po_u2f((uint32_t)e << 23);
+}
+
+/* log1p(t), t in [0, 1]: 2 atanh(t / (2 + t)) */
+PO_EXPORT float po_log1p_det_f32(float t)
+{
+    float s = t / (2.0f + t);
+    float z = s * s;
+    float q = 6.66666666666666657e-2f;      /* 1/15 */
+    q = q * z + 7.69230769230769273e-2f;    /* 1/13 */
+    q = q * z + 9.09090909090909116e-2f;    /* 1/11 */
+    q = q * z + 1.11111111111111105e-1f;    /* 1/9 */
+    q = q * z + 1.42857142857142849e-1f;    /* 1/7 */
+    q = q * z + 0.2f;
+    q = q * z + 3.33333333333333315e-1f;    /* 1/3 */
+    q = q * z + 1.0f;
+    return 2.0f * s * q;
+}
+
+/* logaddexp(0, x) = max(x, 0) + log1p(exp(-|x|)) */
+PO_EXPORT float po_softplus_det_f32(float x)
+{
+    float ax = x < 0.0f ? -x : x;
+    float m = x > 0.0f ? x : 0.0f;
+    return m + po_log1p_det_f32(po_exp_det_f32(-ax));
+}
+
+/* ---- Philox4x32-10 (Salmon et al. 2011), reset RNG of the batched env ---- */
+PO_EXPORT void po_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+PO_EXPORT void po_philox_xy(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t entity,
+                            float lo, float hi, float *x, float *y)
+{
+    uint32_t ctr[4] = {entity, episode, (uint32_t)env_id, (uint32_t)(env_id >> 32)};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
+    po_philox4x32_10(ctr, key, r);
+    float span = hi - lo;
+    float u0 = (float)(r[0] >> 8) * 5.9604644775390625e-8f; /* 2^-24 */
+    float u1 = (float)(r[1] >> 8) * 5.9604644775390625e-8f;
+    *x = span * u0 + lo;
+    *y = span * u1 + lo;
+}
+
+#define PO_CAT_(a, b) a##b
+#define PO_CAT(a, b) PO_CAT_(a, b)
+
+#define REAL float
+#define PO_IS_F32 1
+#define SUFFIX(x) PO_CAT(x, _f32)
+#include "pworld_oracle_impl.h"
+#undef REAL
+#undef PO_IS_F32
+#undef SUFFIX
+
+#define REAL double
+#define PO_IS_F32 0
+#define SUFFIX(x) PO_CAT(x, _f64)
+#include "pworld_oracle_impl.h"
+#undef REAL
+#undef PO_IS_F32
+#undef SUFFIX
