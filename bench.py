@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched particle world on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched by
+``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).  Rank 0
+prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): simple_spread, N = 6 agents, L = 6 landmarks, B = 4096 envs per
+GPU, local observation (D = 16), episode length 25 with in-kernel auto-reset, synthetic uniform
+action indices pre-generated on the device, seed 12345678.  A "step" is one batched
+MultiAgentEnv.step of all B envs (state update + obs + reward + done/terminal + auto-reset);
+steps are issued as pw_rollout launches of ``--chunk`` (25) steps each, every step's outputs
+written to their own HBM buffers.  value = n_gpus * B * K / max-over-ranks wall time.
+
+N > 1 (weak scaling, B per GPU fixed): envs are sharded by env_id_base; the only exchange is the
+RCCL gather of the replay minibatch rows sampled from each rank's local shard to rank 0 once per
+chunk (DESIGN.md "Multi-GPU").
+
+Extra objects: ``roofline`` (HIP-event timed pw_rollout launches vs the 8 TB/s HBM peak, algorithmic
+bytes = 678 B per env-step) and ``cpu_baseline`` (the upstream-structured scalar NumPy oracle on one
+host core, bounded sample; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s copy ceiling)
+
+
+def cpu_baseline(seconds, n_agents):
+    """Reference-style CPU step: the scalar NumPy float64 oracle (upstream loop structure) driven
+    through the MultiAgentEnv list API exactly as experiments/run.py drives it, 1 core."""
+    import numpy as np
+    from oracle import particle_oracle as po  # cpu_baseline leg: the oracle as the measured CPU port
+    np.random.seed(12345678)
+    env = po.make_oracle_env('simple_spread', n=n_agents)
+    env.reset()
+    rng = np.random.RandomState(12345678)
+    eye = np.eye(5)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(25):  # rls/arglist.py:5 episode
+            env.step([eye[a].copy() for a in rng.randint(0, 5, n_agents)])
+        env.reset()
+        steps += 25
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return dict(value=steps / el, unit='env-steps/s', cores=1, kind='port',
+                sample='%d env-steps (%d episodes of 25) of simple_spread N=%d, B=1, scalar NumPy float64 oracle '
+                       'via the MultiAgentEnv list API, %.1f s' % (steps, steps // 25, n_agents, el))
+
+
+def c_oracle_rate(B, n_agents, steps=50):
+    import numpy as np
+    from oracle import c_oracle as co
+    cfg = co.make_config('simple_spread', n_agents, max_episode_len=25, auto_reset=True)
+    o = co.COracle(cfg, B, np.float32)
+    o.reset()
+    act = np.random.RandomState(0).randint(0, 5, (B, n_agents)).astype(np.int32)
+    o.step(act_idx=act)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o.step(act_idx=act)
+    return B * steps / (time.perf_counter() - t0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=1000)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--envs', type=int, default=4096, help='B per GPU')
+    ap.add_argument('--agents', type=int, default=6)
+    ap.add_argument('--chunk', type=int, default=25, help='steps per pw_rollout launch')
+    ap.add_argument('--scenario', default='simple_spread')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--batch-size', type=int, default=1024, help='replay minibatch gathered per chunk (N > 1)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from multiagent_rl_amd.env import BatchedParticleEnv
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)' %
+                         (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    B, N, K, W, T = args.envs, args.agents, args.steps, args.warmup, max(1, args.chunk)
+    kw = dict(num_agents=N) if args.scenario == 'simple_spread' else dict(num_adversaries=4, num_good=2)
+    env = BatchedParticleEnv(args.scenario, B, max_episode_len=25, auto_reset=True, seed=12345678,
+                             env_id_base=rank * B, **kw)
+    N, D = env.n, env.obs_dim
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(12345678 + rank)
+
+    def make_chunks(total):
+        return [min(T, total - s) for s in range(0, total, T)]
+
+    def alloc(total):
+        acts = torch.randint(0, 5, (total, B, N), generator=gen, device=dev, dtype=torch.int32)
+        outs = env.alloc_outputs(total, coll=False)
+        return acts, outs
+
+    def run(acts, outs, chunks, events=None, shard=None):
+        s = 0
+        for i, n in enumerate(chunks):
+            view = {k: v[s:s + n] for k, v in outs.items()}
+            if events is not None:
+                events[i][0].record()
+            env.rollout(acts[s:s + n], out=view)
+            if events is not None:
+                events[i][1].record()
+            if shard is not None:
+                shard(view, acts[s:s + n])
+            s += n
+
+    shard = None
+    if world > 1:
+        from multiagent_rl_amd.dist import SampledTransitionGather
+        shard = SampledTransitionGather(env, args.batch_size, rank, world, dev)
+
+    env.reset()
+    if W > 0:
+        wa, wo = alloc(W)
+        run(wa, wo, make_chunks(W), shard=shard)
+        del wa, wo
+    acts, outs = alloc(K)
+    chunks = make_chunks(K)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in chunks]
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(acts, outs, chunks, events, shard)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: pw_rollout_kernel<spread, local>; HIP events on the launch stream
+    full = [(e0.elapsed_time(e1), n) for (e0, e1), n in zip(events, chunks) if n == T] or \
+           [(e0.elapsed_time(e1), n) for (e0, e1), n in zip(events, chunks)]
+    launch_ms = sum(ms for ms, _ in full) / len(full)
+    steps_per_launch = full[0][1]
+    bytes_per_launch = env.bytes_per_env_step * B * steps_per_launch
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+
+    finite = bool(torch.isfinite(outs['obs'][-1]).all().item()) and (K < 25 or bool(outs['terminal'][24].all().item()))
+
+    if rank == 0:
+        value = world * B * K / elapsed
+        line = {
+            'metric': 'env-steps/sec, simple_spread N=6 x B envs, 1/2/4/8 MI355X',
+            'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': elapsed * 1e3 / K, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s N=%d L=%d, B=%d envs per GPU (global %d), local obs D=%d, episode 25 with '
+                                   'auto-reset, uniform int32 action indices, %d steps per pw_rollout launch'
+                                   % (args.scenario, N, env.num_landmarks, B, world * B, D, T),
+                       'global_batch': world * B, 'parallelism': 'env-shard x%d' % world,
+                       'outputs_finite': finite},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'kernel': 'pw_rollout_kernel', 'launch_ms': launch_ms,
+                         'bytes_per_env_step': env.bytes_per_env_step, 'env_steps_per_launch': B * steps_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.scenario == 'simple_spread':
+            line['cpu_baseline'] = cpu_baseline(args.cpu_seconds, N)
+            line['cpu_baseline']['c_oracle_f32_1core_env_steps_per_s'] = c_oracle_rate(B, N)
+        elif world == 1:
+            line['cpu_baseline'] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

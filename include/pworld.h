@@ -1,0 +1,183 @@
+/* pworld.h -- C ABI of libpworld.so: the MI355X (gfx950) batched particle-world.
+ *
+ * Drop-in boundary for the environment surface the reference drives:
+ *   MultiAgentEnv.reset()/step()  call sites  experiments/run.py:28,44,60
+ *   make_env() configuration                  experiments/scenarios.py:124-192
+ *   local observation layout                  experiments/scenarios.py:6-20
+ *   episode length / terminal rule            experiments/run.py:49-50, rls/arglist.py:5
+ *   transition sink (replay)                  rls/replay_buffer.py:30-52
+ * The arithmetic itself (World.step & friends) lives in the third-party
+ * `multiagent` package the reference imports (experiments/scenarios.py:2-3);
+ * each entry point names the upstream function it replaces.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked "device" is caller-owned HBM
+ *     (PyTorch allocates it); the library never allocates or frees device memory
+ *   - every launch is asynchronous on the caller's hipStream_t (passed as void*,
+ *     e.g. torch.cuda.current_stream().cuda_stream); no hidden synchronisation,
+ *     so calls are hipGraph-capturable
+ *   - return 0 on success, a negative PW_E* code otherwise; pw_last_error() gives
+ *     the thread-local message of the last failure
+ *   - one handle per (device, env shard); a handle is not thread-safe
+ *
+ * Layouts (B envs, N agents, L landmarks, D = pw_obs_dim):
+ *   state block (device, pw_state_bytes, 256-B aligned planes, SoA over [B x N]):
+ *     pos_x[B*N] pos_y[B*N] vel_x[B*N] vel_y[B*N] lm_x[B*L] lm_y[B*L]
+ *     ep_step[B] (int32) ep_count[B] (uint32)      -- offsets: pw_state_layout
+ *   obs [B,N,D] f32 row-major (rows of ragged simple_tag agents zero-padded)
+ *   rew [B,N] f32; done [B,N] u8 (always 0: upstream done_callback is None);
+ *   terminal [B] u8 (episode_step >= max_episode_len, run.py:50);
+ *   coll [B,N] u64, bit j = is_collision(agent j, agent i) (bit i is always set,
+ *   exactly as upstream's reward loop counts it)
+ *
+ * Reset RNG (device path): Philox4x32-10, counter = (entity, episode, env_id lo,
+ *   env_id hi), key = (seed lo, seed hi); entity = agent index, or N + landmark
+ *   index; x = out[0], y = out[1]; u = (r >> 8) * 2^-24; value = (hi-lo)*u + lo in
+ *   float32 without FMA.  env_id = env_id_base + local env index, so a batch
+ *   split over GPUs draws the same states as the unsplit batch.
+ *   (The B = 1 compatibility env instead draws from NumPy's global legacy stream on
+ *   the host, as upstream reset_world does -- main.py:47 -- and uploads via pw_set_state.)
+ *
+ * Numerics: IEEE float32, no FMA contraction, correctly rounded / and sqrt, and
+ *   a libm-free deterministic softplus/exp (definitions: pworld_math.h).  A CPU
+ *   implementation following pworld_math.h reproduces every output bit for bit.
+ */
+#ifndef PWORLD_H
+#define PWORLD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PW_VERSION 100 /* 0.1.0 */
+#define PW_MAX_AGENTS 64
+#define PW_MAX_LANDMARKS 64
+
+enum pw_scenario { PW_SIMPLE_SPREAD = 0, PW_SIMPLE_TAG = 1 };
+enum pw_obs_mode { PW_OBS_LOCAL = 0, PW_OBS_FULL = 1 };
+enum pw_error {
+    PW_OK = 0,
+    PW_EINVAL = -1,   /* bad argument / unsupported configuration */
+    PW_ESTATE = -2,   /* state block not bound */
+    PW_EHIP = -3,     /* a HIP runtime call failed (message has hipGetErrorString) */
+    PW_ENOMEM = -4
+};
+
+typedef struct pw_handle pw_handle;
+
+/* Mirrors what make_env()/make_world() fix for one env (experiments/scenarios.py:124-192)
+ * plus the World constants (upstream core.py World.__init__). */
+typedef struct pw_config {
+    uint32_t struct_size;            /* = sizeof(pw_config); checked */
+    int32_t scenario;                /* pw_scenario */
+    int32_t num_envs;                /* B of THIS handle (the local shard) */
+    int32_t num_agents;              /* N <= PW_MAX_AGENTS */
+    int32_t num_landmarks;           /* L <= PW_MAX_LANDMARKS */
+    int32_t num_adversaries;         /* simple_tag: agents [0, A) are adversaries */
+    int32_t obs_mode;                /* pw_obs_mode (simple_spread only) */
+    int32_t max_episode_len;         /* rls/arglist.py:5 (25); 0 = never terminal */
+    int32_t auto_reset;              /* reset an env inside the step that made it terminal (run.py:59-60) */
+    int32_t force_discrete_action;   /* experiments/scenarios.py:191; applies to act_vec input */
+    int32_t landmark_collide;        /* simple_spread 0, simple_tag 1 */
+    int32_t action_force_uses_accel; /* fork knob: p_force = mass*accel*u; canonical 0 */
+    uint64_t seed;                   /* Philox key */
+    uint64_t env_id_base;            /* global index of local env 0 (multi-GPU sharding) */
+    float dt, damping, contact_force, contact_margin, default_sensitivity, mass, landmark_size;
+    float agent_size[PW_MAX_AGENTS];
+    float agent_accel[PW_MAX_AGENTS];     /* < 0: None (sensitivity = default_sensitivity) */
+    float agent_max_speed[PW_MAX_AGENTS]; /* < 0: None */
+} pw_config;
+
+typedef struct pw_state_layout {
+    size_t pos_x, pos_y, vel_x, vel_y, lm_x, lm_y, ep_step, ep_count; /* byte offsets */
+    size_t total_bytes;
+} pw_state_layout;
+
+/* Buffers of one step (T = 1) or of a T-step rollout (leading dimension T).
+ * Any output pointer may be NULL (that output is skipped). Exactly one of
+ * act_idx / act_vec is non-NULL. All pointers are device pointers. */
+typedef struct pw_step_io {
+    const int32_t *act_idx; /* [T,B,N] action index 0..4 (0 noop,1 +x,2 -x,3 +y,4 -y) */
+    const float *act_vec;   /* [T,B,N,5] one-hot / soft action, as run.py:38 passes it */
+    float *obs;             /* [T,B,N,D] what the policy sees next (post-reset where auto-reset fired) */
+    float *final_obs;       /* [T,B,N,D] pre-reset observation; written only for envs that reset */
+    float *rew;             /* [T,B,N] per-agent reward (world.collaborative = False) */
+    float *rew_shared;      /* [T,B]   sum over agents in agent order (run.py:46) */
+    uint8_t *done;          /* [T,B,N] always 0 */
+    uint8_t *terminal;      /* [T,B] */
+    uint64_t *coll;         /* [T,B,N] */
+} pw_step_io;
+
+int pw_version(void);
+const char *pw_last_error(void);
+
+/* Canonical upstream constants for a scenario: simple_spread (N agents, L = N
+ * landmarks) or simple_tag (num_adversaries + good, L = 2). Replaces
+ * Scenario.make_world() + World.__init__(). */
+int pw_config_default(pw_config *cfg, int scenario, int num_envs, int num_agents,
+                      int num_landmarks /* <0: scenario default */, int num_adversaries);
+
+int pw_create(const pw_config *cfg, pw_handle **out); /* MultiAgentEnv.__init__ */
+void pw_destroy(pw_handle *h);
+int pw_obs_dim(const pw_handle *h);                   /* observation_space[i].shape[0] */
+int pw_get_config(const pw_handle *h, pw_config *out);
+/* env.force_discrete_action = ... after construction (experiments/scenarios.py:191) */
+int pw_set_force_discrete_action(pw_handle *h, int on);
+int pw_get_state_layout(const pw_handle *h, pw_state_layout *out);
+size_t pw_state_bytes(const pw_handle *h);
+int pw_bind_state(pw_handle *h, void *device_state_block);
+
+/* AoS <-> SoA: pos/vel [B,N,2], lm [B,L,2] f32 device (upstream p_pos / p_vel arrays);
+ * ep_step/ep_count [B] may be NULL (set: zeroed / get: skipped). */
+int pw_set_state(pw_handle *h, const float *pos, const float *vel, const float *lm,
+                 const int32_t *ep_step, const uint32_t *ep_count, void *stream);
+int pw_get_state(pw_handle *h, float *pos, float *vel, float *lm,
+                 int32_t *ep_step, uint32_t *ep_count, void *stream);
+
+/* MultiAgentEnv.reset(): env_mask [B] u8 device or NULL (= all). Masked-in envs get
+ * ep_count += 1, ep_step = 0, Philox initial state; obs (may be NULL) is written for ALL envs. */
+int pw_reset(pw_handle *h, const uint8_t *env_mask, float *obs, void *stream);
+/* scenario.observation for every agent from the current state. */
+int pw_observe(pw_handle *h, float *obs, void *stream);
+/* scenario.reward / is_collision from the current state (no step). */
+int pw_reward(pw_handle *h, float *rew, uint64_t *coll, void *stream);
+
+/* MultiAgentEnv.step(): _set_action, World.step (apply_action_force,
+ * apply_environment_force/get_collision_force, integrate_state), then per agent
+ * observation, reward, done -- one fused launch for all B envs. */
+int pw_step(pw_handle *h, const pw_step_io *io, void *stream);
+/* T consecutive steps in ONE launch (state stays in registers/LDS between steps). */
+int pw_rollout(pw_handle *h, const pw_step_io *io, int num_steps, void *stream);
+
+/* Algorithmic HBM bytes of one env-step: 57N + 8L + 8NL for local obs. */
+size_t pw_algorithmic_bytes_per_env_step(const pw_handle *h);
+
+/* ---- device replay ring (rls/replay_buffer.py:9-91 ReplayBuffer) -----------------
+ * Storage is caller-owned SoA: obs/next_obs [cap,N,D] f32, act [cap,N] u8 index,
+ * rew [cap] f32 (shared reward), done [cap] f32. */
+typedef struct pw_replay_store {
+    float *obs, *next_obs, *rew, *done;
+    uint8_t *act;
+    int64_t capacity;
+    int32_t num_agents, obs_dim;
+} pw_replay_store;
+
+/* add(): append B transitions at ring positions (start + i) % capacity.
+ * next_obs row i comes from final_obs where terminal[i] != 0 (and final_obs != NULL). */
+int pw_replay_add(const pw_replay_store *st, int64_t start, int32_t B,
+                  const float *obs, const int32_t *act_idx, const float *rew_shared,
+                  const float *next_obs, const float *final_obs, const uint8_t *terminal,
+                  const float *done /* [B] or NULL = 0 */, void *stream);
+/* sample_index() / _encode_sample(): gather rows idx[0..b) into dense batch tensors;
+ * out_act is one-hot f32 [b,N,5] exactly as the reference's trainer consumes it. */
+int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b,
+                     float *out_obs, float *out_act, float *out_rew, float *out_next_obs,
+                     float *out_done, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWORLD_H */

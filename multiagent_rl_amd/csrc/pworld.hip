@@ -1,0 +1,867 @@
+// libpworld.so -- batched particle world for MI355X (gfx950, wave64).
+//
+// One fused kernel advances all B envs: _set_action -> apply_action_force ->
+// apply_environment_force (pairwise get_collision_force) -> integrate_state ->
+// per-agent observation / reward / done, optionally for T consecutive steps with
+// the state held in registers + LDS (pw_rollout).  Entry points and the upstream
+// functions they replace are declared in include/pworld.h.
+//
+// Mapping: one lane per (env, agent); a 64-lane wave holds EPW = floor(64 / N)
+// whole envs, so every per-env exchange is a wave-local LDS broadcast or a
+// ds_bpermute shuffle and no env ever straddles a wave.  A workgroup is ONE wave
+// (64 threads): at B = 4096, N = 6 that is 410 independent workgroups over the
+// 256 CUs, and __syncthreads() degenerates to an LDS fence (no s_barrier wait).
+// State planes are SoA over the flattened [B x N] index g = env * N + agent, so a
+// wave's loads/stores are one contiguous run of EPW*N floats per plane.
+//
+// Arithmetic is IEEE float32 in the upstream operation order, no FMA contraction,
+// with the deterministic softplus/exp of include/pworld_math.h, so a CPU
+// restatement reproduces every output bit (tests/ compare against oracle/).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <type_traits>
+
+#include "pworld.h"
+#include "pworld_math.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define PW_HIP_CHECK(expr)                                                             \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return fail(PW_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+    } while (0)
+
+constexpr int kWave = 64;
+
+// Everything a kernel needs, passed by value in the kernarg segment.
+struct KParams {
+    int B, N, L, A, D;
+    int epw;          // envs per wave
+    int max_episode_len, auto_reset, force_discrete, landmark_collide;
+    uint64_t seed, env_id_base;
+    float dt, damp, contact_force, contact_margin, mass, landmark_size;
+    float *pos_x, *pos_y, *vel_x, *vel_y, *lm_x, *lm_y;
+    int32_t *ep_step;
+    uint32_t *ep_count;
+    float agent_size[PW_MAX_AGENTS];
+    float agent_sens[PW_MAX_AGENTS];      // accel if set else default_sensitivity (_set_action)
+    float agent_fscale[PW_MAX_AGENTS];    // 1, or mass*accel with the fork knob (apply_action_force)
+    float agent_max_speed[PW_MAX_AGENTS]; // < 0: None
+};
+
+// Per-lane view of "its" env inside the wave.
+struct Lane {
+    int e_local, a, base;  // env slot in wave, agent index, first lane of the env
+    int env;               // local env index
+    size_t g;              // env * N + a
+    bool valid;
+};
+
+__device__ __forceinline__ Lane make_lane(const KParams &P)
+{
+    Lane ln;
+    const int lane = threadIdx.x;
+    ln.e_local = lane / P.N;
+    ln.a = lane - ln.e_local * P.N;
+    ln.base = ln.e_local * P.N;
+    ln.env = blockIdx.x * P.epw + ln.e_local;
+    ln.valid = ln.e_local < P.epw && ln.env < P.B;
+    if (!ln.valid) {  // idle lanes alias env slot 0 for reads; they never write
+        ln.e_local = 0; ln.a = 0; ln.base = 0; ln.env = 0;
+    }
+    ln.g = (size_t)ln.env * P.N + ln.a;
+    return ln;
+}
+
+// get_collision_force seen from entity i against entity j: force on i.
+// delta = p_i - p_j; dist = sqrt(sum(delta^2)); pen = logaddexp(0, -(dist - dist_min)/k) * k;
+// force = contact_force * delta / dist * pen.  (The force on the pair's second entity is
+// the exact negation, which is what this evaluates to from that entity's side.)
+__device__ __forceinline__ void collision_force(float px, float py, float qx, float qy, float dist_min,
+                                                float k, float cf, float &fx, float &fy)
+{
+    const float dx = px - qx, dy = py - qy;
+    const float dist = sqrtf(dx * dx + dy * dy);
+    const float pen = pw_softplus(-(dist - dist_min) / k) * k;
+    const float Fx = cf * dx / dist * pen;
+    const float Fy = cf * dy / dist * pen;
+    fx = Fx + fx;
+    fy = Fy + fy;
+}
+
+__device__ __forceinline__ float tag_bound(float x)
+{
+    if (x < 0.9f) return 0.0f;
+    if (x < 1.0f) return (x - 0.9f) * 10.0f;
+    const float b = pw_exp(2.0f * x - 2.0f);
+    return b < 10.0f ? b : 10.0f;
+}
+
+// scenario.observation for lane's agent -> row o[0..D).  LDS holds the current
+// positions (and velocities for simple_tag) of the wave's envs.
+template <int SCEN, int OBS>
+__device__ __forceinline__ void write_obs(const KParams &P, const Lane &ln, float *__restrict__ o,
+                                          float px, float py, float vx, float vy,
+                                          const float2 *s_pos, const float2 *s_vel, const float2 *s_lm)
+{
+    const int N = P.N, L = P.L;
+    const float2 *lm = s_lm + ln.e_local * L;
+    if (SCEN == PW_SIMPLE_SPREAD && OBS == PW_OBS_LOCAL && (L & 1) == 0) {
+        // D = 4 + 2L is a multiple of 4: 16-byte row stores (experiments/scenarios.py:6-20 layout)
+        float4 *o4 = reinterpret_cast<float4 *>(o);
+        o4[0] = make_float4(vx, vy, px, py);
+        for (int c = 0; c < L / 2; ++c) {
+            const float2 l0 = lm[2 * c], l1 = lm[2 * c + 1];
+            o4[1 + c] = make_float4(l0.x - px, l0.y - py, l1.x - px, l1.y - py);
+        }
+        return;
+    }
+    int k = 0;
+    o[k++] = vx; o[k++] = vy; o[k++] = px; o[k++] = py;
+    for (int l = 0; l < L; ++l) {
+        const float2 q = lm[l];
+        o[k++] = q.x - px;
+        o[k++] = q.y - py;
+    }
+    if (SCEN == PW_SIMPLE_TAG || OBS == PW_OBS_FULL) {
+        const float2 *pp = s_pos + ln.base;
+        for (int j = 0; j < N; ++j) {
+            if (j == ln.a) continue;
+            const float2 q = pp[j];
+            o[k++] = q.x - px;
+            o[k++] = q.y - py;
+        }
+        if (SCEN == PW_SIMPLE_TAG) {
+            const float2 *vv = s_vel + ln.base;
+            for (int j = P.A; j < N; ++j) {  // velocities of the OTHER good agents
+                if (j == ln.a) continue;
+                const float2 q = vv[j];
+                o[k++] = q.x;
+                o[k++] = q.y;
+            }
+        } else {
+            for (int j = 0; j < 2 * (N - 1); ++j) o[k++] = 0.0f;  // comm of silent agents
+        }
+    }
+    while (k < P.D) o[k++] = 0.0f;
+}
+
+// scenario.reward + is_collision mask for the lane's agent from the positions in LDS.
+// s_red: EPW*L floats of wave-private scratch (per-landmark min distance).
+template <int SCEN>
+__device__ __forceinline__ float reward_and_mask(const KParams &P, const Lane &ln, float px, float py,
+                                                 float my_size, const float2 *s_pos, const float2 *s_lm,
+                                                 float *s_red, uint64_t &mask_out)
+{
+    const int N = P.N, L = P.L;
+    const float2 *pp = s_pos + ln.base;
+    uint64_t m = 0;
+    for (int j = 0; j < N; ++j) {
+        const float2 q = pp[j];
+        const float dx = q.x - px, dy = q.y - py;
+        const float d = sqrtf(dx * dx + dy * dy);
+        if (d < P.agent_size[j] + my_size) m |= 1ull << j;
+    }
+    mask_out = m;
+    float r = 0.0f;
+    if (SCEN == PW_SIMPLE_SPREAD) {
+        // shared term: -sum_l min_a |p_a - p_l|.  Lane a owns landmarks a, a+N, ...; sqrt is
+        // monotone and correctly rounded, so min over distances == sqrt(min over squares).
+        const float2 *lm = s_lm + ln.e_local * L;
+        float own = 0.0f;
+        for (int l = ln.a; l < L; l += N) {
+            const float2 q = lm[l];
+            float best = 0.0f;
+            for (int a = 0; a < N; ++a) {
+                const float2 p = pp[a];
+                const float dx = p.x - q.x, dy = p.y - q.y;
+                const float d2 = dx * dx + dy * dy;
+                best = (a == 0 || d2 < best) ? d2 : best;
+            }
+            own = sqrtf(best);
+            if (L > N && ln.valid) s_red[ln.e_local * L + l] = own;
+        }
+        if (L > N) {
+            __syncthreads();
+            for (int l = 0; l < L; ++l) r -= s_red[ln.e_local * L + l];
+        } else {
+            // per-env ordered reduction over the env's lanes by wave shuffle (ds_bpermute)
+            for (int l = 0; l < L; ++l) r -= __shfl(own, ln.base + l, kWave);
+        }
+        for (int a = 0; a < N; ++a)
+            if ((m >> a) & 1) r -= 1.0f;  // includes a == agent, as upstream
+    } else {
+        const int A = P.A;
+        if (ln.a >= A) {
+            for (int a = 0; a < A; ++a)
+                if ((m >> a) & 1) r -= 10.0f;
+            r -= tag_bound(fabsf(px));
+            r -= tag_bound(fabsf(py));
+        }
+        // adversaries: +10 per colliding (good, adversary) pair; bit a of good lane g's mask
+        const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
+        float radv = 0.0f;
+        for (int g = A; g < N; ++g) {
+            const uint64_t mg = ((uint64_t)(uint32_t)__shfl((int)mhi, ln.base + g, kWave) << 32) |
+                                (uint32_t)__shfl((int)mlo, ln.base + g, kWave);
+            for (int a = 0; a < A; ++a)
+                if ((mg >> a) & 1) radv += 10.0f;
+        }
+        if (ln.a < A) r = radv;
+    }
+    return r;
+}
+
+__device__ __forceinline__ void reset_lane(const KParams &P, const Lane &ln, uint32_t episode, int SCEN,
+                                           float &px, float &py, float2 *s_lm)
+{
+    const uint64_t env_id = P.env_id_base + (uint64_t)ln.env;
+    pw_reset_xy(P.seed, env_id, episode, (uint32_t)ln.a, -1.0f, 1.0f, &px, &py);
+    const float lo = SCEN == PW_SIMPLE_TAG ? -0.9f : -1.0f;
+    for (int l = ln.a; l < P.L; l += P.N) {
+        float x, y;
+        pw_reset_xy(P.seed, env_id, episode, (uint32_t)(P.N + l), lo, -lo, &x, &y);
+        s_lm[ln.e_local * P.L + l] = make_float2(x, y);
+    }
+}
+
+// LDS carve-up of one (single-wave) workgroup
+struct Smem {
+    float2 *pos, *vel, *lm;
+    float *red;
+};
+__device__ __forceinline__ Smem carve(const KParams &P, unsigned char *raw)
+{
+    Smem s;
+    const int nl = P.epw * P.N, ll = P.epw * P.L;
+    s.pos = reinterpret_cast<float2 *>(raw);
+    s.vel = s.pos + nl;
+    s.lm = s.vel + nl;
+    s.red = reinterpret_cast<float *>(s.lm + ll);
+    return s;
+}
+size_t smem_bytes(const KParams &P)
+{
+    return (size_t)P.epw * (2 * P.N + P.L) * sizeof(float2) + (size_t)P.epw * P.L * sizeof(float);
+}
+
+// ------------------------------------------------------------------------------------------
+// MultiAgentEnv.step for T consecutive steps.
+// ------------------------------------------------------------------------------------------
+template <int SCEN, int OBS>
+__global__ void __launch_bounds__(kWave) pw_rollout_kernel(const KParams P, const pw_step_io io, const int T)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const Smem S = carve(P, smem_raw);
+    const Lane ln = make_lane(P);
+    const int N = P.N, L = P.L, D = P.D;
+    const size_t BN = (size_t)P.B * N;
+
+    float px = 0.f, py = 0.f, vx = 0.f, vy = 0.f;
+    int ep_step = 0;
+    uint32_t ep_count = 0;
+    float my_size = 0.f, my_sens = 0.f, my_fscale = 1.f, my_maxspeed = -1.f;
+    if (ln.valid) {
+        px = P.pos_x[ln.g]; py = P.pos_y[ln.g];
+        vx = P.vel_x[ln.g]; vy = P.vel_y[ln.g];
+        ep_step = P.ep_step[ln.env];
+        ep_count = P.ep_count[ln.env];
+        my_size = P.agent_size[ln.a];
+        my_sens = P.agent_sens[ln.a];
+        my_fscale = P.agent_fscale[ln.a];
+        my_maxspeed = P.agent_max_speed[ln.a];
+        for (int l = ln.a; l < L; l += N)
+            S.lm[ln.e_local * L + l] = make_float2(P.lm_x[(size_t)ln.env * L + l], P.lm_y[(size_t)ln.env * L + l]);
+        S.pos[threadIdx.x] = make_float2(px, py);
+        if (SCEN == PW_SIMPLE_TAG) S.vel[threadIdx.x] = make_float2(vx, vy);
+    }
+    __syncthreads();
+
+    const float k = P.contact_margin, cf = P.contact_force, dt = P.dt, damp = P.damp, mass = P.mass;
+
+    for (int t = 0; t < T; ++t) {
+        const size_t row = (size_t)t * BN + ln.g;  // flattened [t, env, agent]
+        // ---- U2 _set_action + U4 apply_action_force
+        float fx = 0.f, fy = 0.f;
+        if (ln.valid) {
+            float ux, uy;
+            if (io.act_idx) {
+                const int a = io.act_idx[row];
+                ux = 0.0f + ((a == 1 ? 1.0f : 0.0f) - (a == 2 ? 1.0f : 0.0f));
+                uy = 0.0f + ((a == 3 ? 1.0f : 0.0f) - (a == 4 ? 1.0f : 0.0f));
+            } else {
+                const float *av = io.act_vec + row * 5;
+                float a0 = av[0], a1 = av[1], a2 = av[2], a3 = av[3], a4 = av[4];
+                if (P.force_discrete) {  // np.argmax: first maximum wins
+                    int d = 0;
+                    float best = a0;
+                    if (a1 > best) { best = a1; d = 1; }
+                    if (a2 > best) { best = a2; d = 2; }
+                    if (a3 > best) { best = a3; d = 3; }
+                    if (a4 > best) { best = a4; d = 4; }
+                    a1 = d == 1; a2 = d == 2; a3 = d == 3; a4 = d == 4;
+                }
+                ux = 0.0f + (a1 - a2);
+                uy = 0.0f + (a3 - a4);
+            }
+            ux *= my_sens; uy *= my_sens;
+            if (my_fscale != 1.0f) { ux = my_fscale * ux; uy = my_fscale * uy; }
+            fx = ux + 0.0f; fy = uy + 0.0f;
+            // ---- U5 apply_environment_force: entities j ascending (agents, then landmarks)
+            const float2 *pp = S.pos + ln.base;
+            for (int j = 0; j < N; ++j) {
+                if (j == ln.a) continue;
+                const float2 q = pp[j];
+                // dist_min = size_a + size_b is commutative, so either pair order gives the same bits
+                collision_force(px, py, q.x, q.y, my_size + P.agent_size[j], k, cf, fx, fy);
+            }
+            if (P.landmark_collide) {
+                const float2 *lm = S.lm + ln.e_local * L;
+                for (int l = 0; l < L; ++l) {
+                    const float2 q = lm[l];
+                    collision_force(px, py, q.x, q.y, my_size + P.landmark_size, k, cf, fx, fy);
+                }
+            }
+            // ---- U6 integrate_state
+            vx = vx * damp; vy = vy * damp;
+            vx = vx + (fx / mass) * dt;
+            vy = vy + (fy / mass) * dt;
+            if (my_maxspeed >= 0.0f) {
+                const float speed = sqrtf(vx * vx + vy * vy);
+                if (speed > my_maxspeed) {
+                    vx = vx / speed * my_maxspeed;
+                    vy = vy / speed * my_maxspeed;
+                }
+            }
+            px = px + vx * dt;
+            py = py + vy * dt;
+        }
+        __syncthreads();  // every lane has read the old positions
+        if (ln.valid) {
+            S.pos[threadIdx.x] = make_float2(px, py);
+            if (SCEN == PW_SIMPLE_TAG) S.vel[threadIdx.x] = make_float2(vx, vy);
+        }
+        __syncthreads();
+
+        // ---- reward / masks from the new state
+        uint64_t mask = 0;
+        float r = reward_and_mask<SCEN>(P, ln, px, py, my_size, S.pos, S.lm, S.red, mask);
+        if (ln.valid) {
+            if (io.rew) io.rew[row] = r;
+            if (io.done) io.done[row] = 0;
+            if (io.coll) io.coll[row] = mask;
+        }
+        if (io.rew_shared) {  // np.sum(rew_n), run.py:46, in agent order
+            float acc = 0.0f;
+            for (int i = 0; i < N; ++i) acc += __shfl(r, ln.base + i, kWave);
+            if (ln.valid && ln.a == 0) io.rew_shared[(size_t)t * P.B + ln.env] = acc;
+        }
+        // ---- terminal rule (run.py:48-50) and auto-reset (run.py:59-60)
+        ep_step += 1;
+        const bool term = P.max_episode_len > 0 && ep_step >= P.max_episode_len;
+        if (ln.valid && ln.a == 0 && io.terminal) io.terminal[(size_t)t * P.B + ln.env] = term ? 1 : 0;
+        const bool do_reset = ln.valid && term && P.auto_reset;
+        if (__any(do_reset)) {
+            if (do_reset && io.final_obs)
+                write_obs<SCEN, OBS>(P, ln, io.final_obs + row * D, px, py, vx, vy, S.pos, S.vel, S.lm);
+            __syncthreads();
+            if (do_reset) {
+                ep_count += 1;
+                ep_step = 0;
+                reset_lane(P, ln, ep_count, SCEN, px, py, S.lm);
+                vx = 0.f; vy = 0.f;
+                S.pos[threadIdx.x] = make_float2(px, py);
+                if (SCEN == PW_SIMPLE_TAG) S.vel[threadIdx.x] = make_float2(0.f, 0.f);
+            }
+            __syncthreads();
+        }
+        if (ln.valid && io.obs)
+            write_obs<SCEN, OBS>(P, ln, io.obs + row * D, px, py, vx, vy, S.pos, S.vel, S.lm);
+    }
+
+    if (ln.valid) {
+        P.pos_x[ln.g] = px; P.pos_y[ln.g] = py;
+        P.vel_x[ln.g] = vx; P.vel_y[ln.g] = vy;
+        for (int l = ln.a; l < L; l += N) {
+            const float2 q = S.lm[ln.e_local * L + l];
+            P.lm_x[(size_t)ln.env * L + l] = q.x;
+            P.lm_y[(size_t)ln.env * L + l] = q.y;
+        }
+        if (ln.a == 0) {
+            P.ep_step[ln.env] = ep_step;
+            P.ep_count[ln.env] = ep_count;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// reset / observe / reward from the stored state (no physics).  mode bit 0: reset masked envs,
+// bit 1: write obs, bit 2: write reward/coll.
+// ------------------------------------------------------------------------------------------
+template <int SCEN, int OBS>
+__global__ void __launch_bounds__(kWave) pw_aux_kernel(const KParams P, const int mode, const uint8_t *env_mask,
+                                                       float *obs, float *rew, uint64_t *coll)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const Smem S = carve(P, smem_raw);
+    const Lane ln = make_lane(P);
+    const int N = P.N, L = P.L;
+    float px = 0.f, py = 0.f, vx = 0.f, vy = 0.f, my_size = 0.f;
+    if (ln.valid) {
+        my_size = P.agent_size[ln.a];
+        const bool rs = (mode & 1) && (!env_mask || env_mask[ln.env]);
+        if (rs) {
+            const uint32_t ep = P.ep_count[ln.env] + 1;
+            reset_lane(P, ln, ep, SCEN, px, py, S.lm);
+        } else {
+            px = P.pos_x[ln.g]; py = P.pos_y[ln.g];
+            vx = P.vel_x[ln.g]; vy = P.vel_y[ln.g];
+            for (int l = ln.a; l < L; l += N)
+                S.lm[ln.e_local * L + l] = make_float2(P.lm_x[(size_t)ln.env * L + l], P.lm_y[(size_t)ln.env * L + l]);
+        }
+        S.pos[threadIdx.x] = make_float2(px, py);
+        if (SCEN == PW_SIMPLE_TAG) S.vel[threadIdx.x] = make_float2(vx, vy);
+    }
+    __syncthreads();
+    if (ln.valid && (mode & 1) && (!env_mask || env_mask[ln.env])) {
+        P.pos_x[ln.g] = px; P.pos_y[ln.g] = py;
+        P.vel_x[ln.g] = 0.f; P.vel_y[ln.g] = 0.f;
+        for (int l = ln.a; l < L; l += N) {
+            const float2 q = S.lm[ln.e_local * L + l];
+            P.lm_x[(size_t)ln.env * L + l] = q.x;
+            P.lm_y[(size_t)ln.env * L + l] = q.y;
+        }
+    }
+    if (mode & 4) {
+        uint64_t mask = 0;
+        const float r = reward_and_mask<SCEN>(P, ln, px, py, my_size, S.pos, S.lm, S.red, mask);
+        if (ln.valid) {
+            if (rew) rew[ln.g] = r;
+            if (coll) coll[ln.g] = mask;
+        }
+    }
+    if ((mode & 2) && ln.valid && obs)
+        write_obs<SCEN, OBS>(P, ln, obs + ln.g * P.D, px, py, vx, vy, S.pos, S.vel, S.lm);
+    // counters last: every lane of the env has read ep_count above (same wave, program order)
+    __syncthreads();
+    if (ln.valid && (mode & 1) && ln.a == 0 && (!env_mask || env_mask[ln.env])) {
+        P.ep_count[ln.env] += 1;
+        P.ep_step[ln.env] = 0;
+    }
+}
+
+// AoS [B,N,2] <-> SoA planes
+__global__ void pw_scatter_state_kernel(const KParams P, const float *pos, const float *vel, const float *lm,
+                                        const int32_t *ep_step, const uint32_t *ep_count)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t BN = (size_t)P.B * P.N, BL = (size_t)P.B * P.L;
+    if (i < BN) {
+        if (pos) { P.pos_x[i] = pos[2 * i]; P.pos_y[i] = pos[2 * i + 1]; }
+        if (vel) { P.vel_x[i] = vel[2 * i]; P.vel_y[i] = vel[2 * i + 1]; }
+    }
+    if (i < BL && lm) { P.lm_x[i] = lm[2 * i]; P.lm_y[i] = lm[2 * i + 1]; }
+    if (i < (size_t)P.B) {
+        P.ep_step[i] = ep_step ? ep_step[i] : 0;
+        P.ep_count[i] = ep_count ? ep_count[i] : 0;
+    }
+}
+
+__global__ void pw_gather_state_kernel(const KParams P, float *pos, float *vel, float *lm,
+                                       int32_t *ep_step, uint32_t *ep_count)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t BN = (size_t)P.B * P.N, BL = (size_t)P.B * P.L;
+    if (i < BN) {
+        if (pos) { pos[2 * i] = P.pos_x[i]; pos[2 * i + 1] = P.pos_y[i]; }
+        if (vel) { vel[2 * i] = P.vel_x[i]; vel[2 * i + 1] = P.vel_y[i]; }
+    }
+    if (i < BL && lm) { lm[2 * i] = P.lm_x[i]; lm[2 * i + 1] = P.lm_y[i]; }
+    if (i < (size_t)P.B) {
+        if (ep_step) ep_step[i] = P.ep_step[i];
+        if (ep_count) ep_count[i] = P.ep_count[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// device replay ring (rls/replay_buffer.py ReplayBuffer.add / _encode_sample)
+// ------------------------------------------------------------------------------------------
+__global__ void pw_replay_add_kernel(const pw_replay_store st, const int64_t start, const int B,
+                                     const float *obs, const int32_t *act_idx, const float *rew_shared,
+                                     const float *next_obs, const float *final_obs, const uint8_t *terminal,
+                                     const float *done)
+{
+    const int ND = st.num_agents * st.obs_dim, N = st.num_agents;
+    const size_t total = (size_t)B * ND;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / ND, c = i - e * ND;
+        const size_t slot = (size_t)((start + (int64_t)e) % st.capacity);
+        st.obs[slot * ND + c] = obs[i];
+        const bool fin = final_obs && terminal && terminal[e];
+        st.next_obs[slot * ND + c] = fin ? final_obs[i] : next_obs[i];
+        if (c < (size_t)N) st.act[slot * N + c] = (uint8_t)act_idx[e * N + c];
+        if (c == 0) {
+            st.rew[slot] = rew_shared[e];
+            st.done[slot] = done ? done[e] : 0.0f;
+        }
+    }
+}
+
+__global__ void pw_replay_gather_kernel(const pw_replay_store st, const int64_t *idx, const int b,
+                                        float *out_obs, float *out_act, float *out_rew, float *out_next_obs,
+                                        float *out_done)
+{
+    const int ND = st.num_agents * st.obs_dim, N = st.num_agents;
+    const size_t total = (size_t)b * ND;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / ND, c = i - e * ND;
+        const size_t slot = (size_t)idx[e];
+        if (out_obs) out_obs[i] = st.obs[slot * ND + c];
+        if (out_next_obs) out_next_obs[i] = st.next_obs[slot * ND + c];
+        if (out_act && c < (size_t)N * 5) {  // ND >= 5N always (obs_dim >= 6)
+            const size_t ag = c / 5, kk = c - ag * 5;
+            out_act[e * N * 5 + c] = st.act[slot * N + ag] == kk ? 1.0f : 0.0f;
+        }
+        if (c == 0) {
+            if (out_rew) out_rew[e] = st.rew[slot];
+            if (out_done) out_done[e] = st.done[slot];
+        }
+    }
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct pw_handle {
+    pw_config cfg;
+    KParams kp;
+    pw_state_layout layout;
+    bool bound;
+};
+
+namespace {
+
+int obs_dim_of(const pw_config &c)
+{
+    const int N = c.num_agents, L = c.num_landmarks;
+    if (c.scenario == PW_SIMPLE_SPREAD) return c.obs_mode == PW_OBS_FULL ? 4 + 2 * L + 4 * (N - 1) : 4 + 2 * L;
+    const int G = N - c.num_adversaries;
+    return 4 + 2 * L + 2 * (N - 1) + 2 * (c.num_adversaries > 0 ? G : G - 1);
+}
+
+template <typename F>
+int dispatch(const pw_handle *h, F &&f)
+{
+    if (h->cfg.scenario == PW_SIMPLE_TAG) return f(std::integral_constant<int, PW_SIMPLE_TAG>(), std::integral_constant<int, PW_OBS_LOCAL>());
+    if (h->cfg.obs_mode == PW_OBS_FULL) return f(std::integral_constant<int, PW_SIMPLE_SPREAD>(), std::integral_constant<int, PW_OBS_FULL>());
+    return f(std::integral_constant<int, PW_SIMPLE_SPREAD>(), std::integral_constant<int, PW_OBS_LOCAL>());
+}
+
+int check_ready(const pw_handle *h)
+{
+    if (!h) return fail(PW_EINVAL, "null handle");
+    if (!h->bound) return fail(PW_ESTATE, "state block not bound: call pw_bind_state first");
+    return PW_OK;
+}
+
+int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
+{
+    if (int rc = check_ready(h)) return rc;
+    if (!io) return fail(PW_EINVAL, "null pw_step_io");
+    if (T < 1) return fail(PW_EINVAL, "num_steps must be >= 1");
+    if ((io->act_idx == nullptr) == (io->act_vec == nullptr))
+        return fail(PW_EINVAL, "exactly one of act_idx / act_vec must be given");
+    if (io->obs && (reinterpret_cast<uintptr_t>(io->obs) & 15))
+        return fail(PW_EINVAL, "obs must be 16-byte aligned");
+    if (io->final_obs && (reinterpret_cast<uintptr_t>(io->final_obs) & 15))
+        return fail(PW_EINVAL, "final_obs must be 16-byte aligned");
+    const KParams &kp = h->kp;
+    const dim3 grid((kp.B + kp.epw - 1) / kp.epw), block(kWave);
+    const size_t shmem = smem_bytes(kp);
+    return dispatch(h, [&](auto scen, auto obs) {
+        hipLaunchKernelGGL((pw_rollout_kernel<decltype(scen)::value, decltype(obs)::value>), grid, block, shmem,
+                           static_cast<hipStream_t>(stream), kp, *io, T);
+        PW_HIP_CHECK(hipGetLastError());
+        return (int)PW_OK;
+    });
+}
+
+int launch_aux(pw_handle *h, int mode, const uint8_t *env_mask, float *obs, float *rew, uint64_t *coll, void *stream)
+{
+    if (int rc = check_ready(h)) return rc;
+    if (obs && (reinterpret_cast<uintptr_t>(obs) & 15)) return fail(PW_EINVAL, "obs must be 16-byte aligned");
+    const KParams &kp = h->kp;
+    const dim3 grid((kp.B + kp.epw - 1) / kp.epw), block(kWave);
+    const size_t shmem = smem_bytes(kp);
+    return dispatch(h, [&](auto scen, auto om) {
+        hipLaunchKernelGGL((pw_aux_kernel<decltype(scen)::value, decltype(om)::value>), grid, block, shmem,
+                           static_cast<hipStream_t>(stream), kp, mode, env_mask, obs, rew, coll);
+        PW_HIP_CHECK(hipGetLastError());
+        return (int)PW_OK;
+    });
+}
+
+}  // namespace
+
+extern "C" {
+
+int pw_version(void) { return PW_VERSION; }
+
+const char *pw_last_error(void) { return g_last_error.c_str(); }
+
+int pw_config_default(pw_config *cfg, int scenario, int num_envs, int num_agents, int num_landmarks,
+                      int num_adversaries)
+{
+    if (!cfg) return fail(PW_EINVAL, "null cfg");
+    if (num_agents < 1 || num_agents > PW_MAX_AGENTS) return fail(PW_EINVAL, "num_agents out of range [1, 64]");
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = sizeof(pw_config);
+    cfg->scenario = scenario;
+    cfg->num_envs = num_envs;
+    cfg->num_agents = num_agents;
+    cfg->obs_mode = PW_OBS_LOCAL;
+    cfg->max_episode_len = 25;       // rls/arglist.py:5
+    cfg->auto_reset = 0;
+    cfg->force_discrete_action = 1;  // experiments/scenarios.py:191
+    cfg->seed = 12345678;            // main.py:41
+    cfg->dt = 0.1f;
+    cfg->damping = 0.25f;
+    cfg->contact_force = 100.0f;
+    cfg->contact_margin = 1e-3f;
+    cfg->default_sensitivity = 5.0f;
+    cfg->mass = 1.0f;
+    if (scenario == PW_SIMPLE_SPREAD) {
+        cfg->num_landmarks = num_landmarks < 0 ? num_agents : num_landmarks;
+        cfg->num_adversaries = 0;
+        cfg->landmark_collide = 0;
+        cfg->landmark_size = 0.05f;
+        for (int i = 0; i < num_agents; ++i) {
+            cfg->agent_size[i] = 0.15f;
+            cfg->agent_accel[i] = -1.0f;
+            cfg->agent_max_speed[i] = -1.0f;
+        }
+    } else if (scenario == PW_SIMPLE_TAG) {
+        if (num_adversaries < 0 || num_adversaries > num_agents) return fail(PW_EINVAL, "num_adversaries out of range");
+        cfg->num_landmarks = num_landmarks < 0 ? 2 : num_landmarks;
+        cfg->num_adversaries = num_adversaries;
+        cfg->landmark_collide = 1;
+        cfg->landmark_size = 0.2f;
+        for (int i = 0; i < num_agents; ++i) {
+            const bool adv = i < num_adversaries;
+            cfg->agent_size[i] = adv ? 0.075f : 0.05f;
+            cfg->agent_accel[i] = adv ? 3.0f : 4.0f;
+            cfg->agent_max_speed[i] = adv ? 1.0f : 1.3f;
+        }
+    } else {
+        return fail(PW_EINVAL, "unknown scenario");
+    }
+    return PW_OK;
+}
+
+int pw_create(const pw_config *cfg, pw_handle **out)
+{
+    if (!cfg || !out) return fail(PW_EINVAL, "null argument");
+    if (cfg->struct_size != sizeof(pw_config)) return fail(PW_EINVAL, "pw_config.struct_size mismatch (ABI)");
+    if (cfg->scenario != PW_SIMPLE_SPREAD && cfg->scenario != PW_SIMPLE_TAG) return fail(PW_EINVAL, "unknown scenario");
+    if (cfg->num_envs < 1) return fail(PW_EINVAL, "num_envs must be >= 1");
+    if (cfg->num_agents < 1 || cfg->num_agents > PW_MAX_AGENTS) return fail(PW_EINVAL, "num_agents out of range [1, 64]");
+    if (cfg->num_landmarks < 0 || cfg->num_landmarks > PW_MAX_LANDMARKS) return fail(PW_EINVAL, "num_landmarks out of range [0, 64]");
+    if (cfg->scenario == PW_SIMPLE_TAG && (cfg->num_adversaries < 0 || cfg->num_adversaries > cfg->num_agents))
+        return fail(PW_EINVAL, "num_adversaries out of range");
+    if (cfg->scenario == PW_SIMPLE_TAG && cfg->num_adversaries == cfg->num_agents && cfg->num_agents > 0 &&
+        obs_dim_of(*cfg) < 4)
+        return fail(PW_EINVAL, "bad simple_tag roster");
+    if (cfg->obs_mode != PW_OBS_LOCAL && cfg->obs_mode != PW_OBS_FULL) return fail(PW_EINVAL, "unknown obs_mode");
+    if (!(cfg->contact_margin > 0.0f) || !(cfg->mass > 0.0f)) return fail(PW_EINVAL, "contact_margin and mass must be > 0");
+    pw_handle *h = new (std::nothrow) pw_handle;
+    if (!h) return fail(PW_ENOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->bound = false;
+    KParams &kp = h->kp;
+    std::memset(&kp, 0, sizeof(kp));
+    kp.B = cfg->num_envs; kp.N = cfg->num_agents; kp.L = cfg->num_landmarks;
+    kp.A = cfg->scenario == PW_SIMPLE_TAG ? cfg->num_adversaries : 0;
+    kp.D = obs_dim_of(*cfg);
+    kp.epw = kWave / kp.N;
+    kp.max_episode_len = cfg->max_episode_len;
+    kp.auto_reset = cfg->auto_reset;
+    kp.force_discrete = cfg->force_discrete_action;
+    kp.landmark_collide = cfg->landmark_collide;
+    kp.seed = cfg->seed; kp.env_id_base = cfg->env_id_base;
+    kp.dt = cfg->dt; kp.damp = 1.0f - cfg->damping;
+    kp.contact_force = cfg->contact_force; kp.contact_margin = cfg->contact_margin;
+    kp.mass = cfg->mass; kp.landmark_size = cfg->landmark_size;
+    for (int i = 0; i < kp.N; ++i) {
+        kp.agent_size[i] = cfg->agent_size[i];
+        kp.agent_sens[i] = cfg->agent_accel[i] >= 0.0f ? cfg->agent_accel[i] : cfg->default_sensitivity;
+        kp.agent_fscale[i] = cfg->action_force_uses_accel
+                                 ? (cfg->agent_accel[i] >= 0.0f ? cfg->mass * cfg->agent_accel[i] : cfg->mass)
+                                 : 1.0f;
+        kp.agent_max_speed[i] = cfg->agent_max_speed[i];
+    }
+    const size_t BN = (size_t)kp.B * kp.N, BL = (size_t)kp.B * kp.L;
+    pw_state_layout &lo = h->layout;
+    size_t off = 0;
+    lo.pos_x = off; off = align_up(off + BN * 4, 256);
+    lo.pos_y = off; off = align_up(off + BN * 4, 256);
+    lo.vel_x = off; off = align_up(off + BN * 4, 256);
+    lo.vel_y = off; off = align_up(off + BN * 4, 256);
+    lo.lm_x = off; off = align_up(off + BL * 4, 256);
+    lo.lm_y = off; off = align_up(off + BL * 4, 256);
+    lo.ep_step = off; off = align_up(off + (size_t)kp.B * 4, 256);
+    lo.ep_count = off; off = align_up(off + (size_t)kp.B * 4, 256);
+    lo.total_bytes = off;
+    *out = h;
+    return PW_OK;
+}
+
+void pw_destroy(pw_handle *h) { delete h; }
+
+int pw_obs_dim(const pw_handle *h) { return h ? h->kp.D : fail(PW_EINVAL, "null handle"); }
+
+int pw_get_config(const pw_handle *h, pw_config *out)
+{
+    if (!h || !out) return fail(PW_EINVAL, "null argument");
+    *out = h->cfg;
+    return PW_OK;
+}
+
+int pw_set_force_discrete_action(pw_handle *h, int on)
+{
+    if (!h) return fail(PW_EINVAL, "null handle");
+    h->cfg.force_discrete_action = on ? 1 : 0;
+    h->kp.force_discrete = on ? 1 : 0;
+    return PW_OK;
+}
+
+int pw_get_state_layout(const pw_handle *h, pw_state_layout *out)
+{
+    if (!h || !out) return fail(PW_EINVAL, "null argument");
+    *out = h->layout;
+    return PW_OK;
+}
+
+size_t pw_state_bytes(const pw_handle *h) { return h ? h->layout.total_bytes : 0; }
+
+int pw_bind_state(pw_handle *h, void *block)
+{
+    if (!h || !block) return fail(PW_EINVAL, "null argument");
+    if (reinterpret_cast<uintptr_t>(block) & 255) return fail(PW_EINVAL, "state block must be 256-byte aligned");
+    unsigned char *b = static_cast<unsigned char *>(block);
+    KParams &kp = h->kp;
+    kp.pos_x = reinterpret_cast<float *>(b + h->layout.pos_x);
+    kp.pos_y = reinterpret_cast<float *>(b + h->layout.pos_y);
+    kp.vel_x = reinterpret_cast<float *>(b + h->layout.vel_x);
+    kp.vel_y = reinterpret_cast<float *>(b + h->layout.vel_y);
+    kp.lm_x = reinterpret_cast<float *>(b + h->layout.lm_x);
+    kp.lm_y = reinterpret_cast<float *>(b + h->layout.lm_y);
+    kp.ep_step = reinterpret_cast<int32_t *>(b + h->layout.ep_step);
+    kp.ep_count = reinterpret_cast<uint32_t *>(b + h->layout.ep_count);
+    h->bound = true;
+    return PW_OK;
+}
+
+int pw_set_state(pw_handle *h, const float *pos, const float *vel, const float *lm, const int32_t *ep_step,
+                 const uint32_t *ep_count, void *stream)
+{
+    if (int rc = check_ready(h)) return rc;
+    const KParams &kp = h->kp;
+    size_t n = (size_t)kp.B * (kp.N > kp.L ? kp.N : kp.L);
+    if (n < (size_t)kp.B) n = kp.B;
+    hipLaunchKernelGGL(pw_scatter_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), kp, pos, vel, lm, ep_step, ep_count);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_get_state(pw_handle *h, float *pos, float *vel, float *lm, int32_t *ep_step, uint32_t *ep_count, void *stream)
+{
+    if (int rc = check_ready(h)) return rc;
+    const KParams &kp = h->kp;
+    size_t n = (size_t)kp.B * (kp.N > kp.L ? kp.N : kp.L);
+    if (n < (size_t)kp.B) n = kp.B;
+    hipLaunchKernelGGL(pw_gather_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), kp, pos, vel, lm, ep_step, ep_count);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_reset(pw_handle *h, const uint8_t *env_mask, float *obs, void *stream)
+{
+    return launch_aux(h, 1 | (obs ? 2 : 0), env_mask, obs, nullptr, nullptr, stream);
+}
+
+int pw_observe(pw_handle *h, float *obs, void *stream)
+{
+    if (!obs) return fail(PW_EINVAL, "null obs");
+    return launch_aux(h, 2, nullptr, obs, nullptr, nullptr, stream);
+}
+
+int pw_reward(pw_handle *h, float *rew, uint64_t *coll, void *stream)
+{
+    if (!rew && !coll) return fail(PW_EINVAL, "nothing to write");
+    return launch_aux(h, 4, nullptr, nullptr, rew, coll, stream);
+}
+
+int pw_step(pw_handle *h, const pw_step_io *io, void *stream) { return launch_rollout(h, io, 1, stream); }
+
+int pw_rollout(pw_handle *h, const pw_step_io *io, int num_steps, void *stream)
+{
+    return launch_rollout(h, io, num_steps, stream);
+}
+
+size_t pw_algorithmic_bytes_per_env_step(const pw_handle *h)
+{
+    if (!h) return 0;
+    const size_t N = h->kp.N, L = h->kp.L, D = h->kp.D;
+    // read: state 16N + landmarks 8L + action 4N; write: state 16N + obs 4ND + reward 4N + done N
+    return 16 * N + 8 * L + 4 * N + 16 * N + 4 * N * D + 4 * N + N;
+}
+
+int pw_replay_add(const pw_replay_store *st, int64_t start, int32_t B, const float *obs, const int32_t *act_idx,
+                  const float *rew_shared, const float *next_obs, const float *final_obs, const uint8_t *terminal,
+                  const float *done, void *stream)
+{
+    if (!st || !obs || !act_idx || !rew_shared || !next_obs) return fail(PW_EINVAL, "null argument");
+    if (st->capacity < 1 || B < 1 || B > st->capacity || start < 0) return fail(PW_EINVAL, "bad ring arguments");
+    if (st->obs_dim < 5) return fail(PW_EINVAL, "obs_dim must be >= 5");
+    const size_t total = (size_t)B * st->num_agents * st->obs_dim;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pw_replay_add_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       *st, start, B, obs, act_idx, rew_shared, next_obs, final_obs, terminal, done);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b, float *out_obs, float *out_act,
+                     float *out_rew, float *out_next_obs, float *out_done, void *stream)
+{
+    if (!st || !idx) return fail(PW_EINVAL, "null argument");
+    if (b < 1) return fail(PW_EINVAL, "batch must be >= 1");
+    if (st->obs_dim < 5) return fail(PW_EINVAL, "obs_dim must be >= 5");
+    const size_t total = (size_t)b * st->num_agents * st->obs_dim;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pw_replay_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       *st, idx, b, out_obs, out_act, out_rew, out_next_obs, out_done);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+"""GPU parity: the HIP path (through the C ABI, via multiagent_rl_amd) against the CPU oracle.
+
+Bars (BASELINE.json north_star): integer done / collision masks BIT-EXACT, float32 state
+within 1e-5 of the float64 reference semantics.  Because the kernels follow the upstream
+operation order with deterministic float32 math, we assert the stronger property too:
+every output equals the float32 C oracle bit for bit.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+from oracle import c_oracle as co  # noqa: E402  (checker only)
+
+
+def _mk(scenario='simple_spread', num_envs=64, num_agents=3, num_landmarks=None, num_adversaries=0,
+        obs_mode='local', max_episode_len=25, auto_reset=False, seed=12345678, env_id_base=0,
+        force_discrete_action=True, want_coll=True):
+    from multiagent_rl_amd.env import BatchedParticleEnv
+    kw = dict(num_agents=num_agents, num_landmarks=num_landmarks, local_observation=obs_mode == 'local',
+              max_episode_len=max_episode_len, auto_reset=auto_reset, seed=seed, env_id_base=env_id_base,
+              force_discrete_action=force_discrete_action)
+    if scenario == 'simple_tag':
+        kw.update(num_adversaries=num_adversaries, num_good=num_agents - num_adversaries)
+        kw.pop('num_agents')
+    env = BatchedParticleEnv(scenario, num_envs, want_coll=want_coll, **kw)
+    cfg = co.make_config(scenario, num_agents, num_landmarks=num_landmarks, num_adversaries=num_adversaries,
+                         obs_mode=obs_mode, max_episode_len=max_episode_len, auto_reset=auto_reset, seed=seed,
+                         env_id_base=env_id_base, force_discrete_action=force_discrete_action)
+    return env, cfg
+
+
+def _rand_state(rng, B, N, L, crowded=True):
+    pos = rng.uniform(-0.5, 0.5, (B, N, 2)) if crowded else rng.uniform(-1, 1, (B, N, 2))
+    h = B // 2
+    pos[h:] = rng.uniform(0.6, 1.15, (B - h, N, 2)) * rng.choice([-1, 1], (B - h, N, 2))
+    vel = rng.uniform(-1.5, 1.5, (B, N, 2))
+    lm = rng.uniform(-0.9, 0.9, (B, L, 2))
+    return pos.astype(np.float32), vel.astype(np.float32), lm.astype(np.float32)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _coll(t):
+    return _np(t).view(np.uint64)
+
+
+def _assert_same_bits(got, want, name):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    if got.dtype.kind == 'f':
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    else:
+        same = got == want
+    assert same.all(), '%s: %d / %d elements differ; max abs diff %g' % (
+        name, (~same).sum(), same.size, np.nanmax(np.abs(got.astype(np.float64) - want.astype(np.float64))))
+
+
+CASES = [
+    dict(scenario='simple_spread', num_agents=3, num_envs=1),               # configs[0] shape
+    dict(scenario='simple_spread', num_agents=3, num_envs=1000),            # 21 envs / wave, ragged tail
+    dict(scenario='simple_spread', num_agents=6, num_envs=4096),            # configs[1] (C2) full size
+    dict(scenario='simple_spread', num_agents=12, num_envs=333),
+    dict(scenario='simple_spread', num_agents=24, num_envs=65),
+    dict(scenario='simple_spread', num_agents=48, num_envs=33),
+    dict(scenario='simple_spread', num_agents=64, num_envs=5),              # maximum N
+    dict(scenario='simple_spread', num_agents=1, num_envs=130),
+    dict(scenario='simple_spread', num_agents=4, num_envs=200, obs_mode='full'),
+    dict(scenario='simple_spread', num_agents=5, num_landmarks=2, num_envs=77),
+    dict(scenario='simple_spread', num_agents=3, num_landmarks=7, num_envs=77),   # L > N path
+    dict(scenario='simple_spread', num_agents=3, num_landmarks=0, num_envs=9),    # empty landmark set
+    dict(scenario='simple_tag', num_agents=4, num_adversaries=3, num_envs=500),   # canonical 3+1
+    dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192),  # configs[2] (C3) full size
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: '%s-N%d-L%s-B%d-%s' % (
+    c['scenario'], c['num_agents'], c.get('num_landmarks'), c['num_envs'], c.get('obs_mode', 'local')))
+def test_single_step_from_injected_states(case):
+    env, cfg = _mk(max_episode_len=0, **case)
+    B, N, L = env.num_envs, env.n, env.num_landmarks
+    rng = np.random.RandomState(B * 131 + N)
+    pos, vel, lm = _rand_state(rng, B, N, L)
+    act = rng.randint(0, 5, (B, N)).astype(np.int32)
+    env.set_state(pos, vel, lm)
+    obs, rew, done, info = env.step(torch.from_numpy(act))
+    st = env.get_state()
+    o32 = co.COracle(cfg, B, np.float32)
+    o32.set_state(pos, vel, lm)
+    w = o32.step(act_idx=act)
+    _assert_same_bits(_np(st['pos']), o32.pos, 'pos')
+    _assert_same_bits(_np(st['vel']), o32.vel, 'vel')
+    _assert_same_bits(_np(st['landmarks']), o32.lm, 'landmarks')
+    _assert_same_bits(_np(obs), w['obs'], 'obs')
+    _assert_same_bits(_np(rew), w['rew'], 'rew')
+    _assert_same_bits(_coll(info['coll']), w['coll'], 'coll')            # integer masks: bit-exact
+    _assert_same_bits(_np(done).astype(np.uint8), w['done'], 'done')
+    _assert_same_bits(_np(info['terminal']).astype(np.uint8), w['terminal'], 'terminal')
+    assert not _np(done).any()
+    # shared reward (run.py:46) = agent-order sum
+    want_shared = np.zeros(B, np.float32)
+    for i in range(N):
+        want_shared = want_shared + w['rew'][:, i]
+    _assert_same_bits(_np(info['rew_shared']), want_shared, 'rew_shared')
+    # float64 reference semantics: state within 1e-5 (north_star tolerance)
+    o64 = co.COracle(cfg, B, np.float64)
+    o64.set_state(pos, vel, lm)
+    w64 = o64.step(act_idx=act)
+    np.testing.assert_allclose(_np(st['pos']), o64.pos, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(_np(st['vel']), o64.vel, rtol=0, atol=1e-4)   # vel = dpos / dt
+    np.testing.assert_allclose(_np(obs), w64['obs'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(_np(rew), w64['rew'], rtol=0, atol=1e-4)
+    # masks vs float64: identical except pairs whose distance is within 1e-6 of the threshold
+    diff = _coll(info['coll']) ^ w64['coll']
+    assert np.count_nonzero(diff) <= 2, 'collision masks differ from the float64 oracle in %d rows' % np.count_nonzero(diff)
+    assert (w['coll'] != (np.uint64(1) << np.arange(N, dtype=np.uint64))[None, :]).any() or N == 1
+
+
+@pytest.mark.parametrize('case', [
+    dict(scenario='simple_spread', num_agents=6, num_envs=257),
+    dict(scenario='simple_spread', num_agents=3, num_envs=100, obs_mode='full'),
+    dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=123),
+], ids=['spread6', 'spread3full', 'tag4+2'])
+def test_rollout_with_auto_reset_matches_oracle_bitwise(case):
+    T, ep_len = 58, 25
+    env, cfg = _mk(max_episode_len=ep_len, auto_reset=True, seed=99, env_id_base=1 << 33, **case)
+    B, N = env.num_envs, env.n
+    rng = np.random.RandomState(5)
+    acts = rng.randint(0, 5, (T, B, N)).astype(np.int32)
+    obs0 = env.reset()
+    o32 = co.COracle(cfg, B, np.float32)
+    _assert_same_bits(_np(obs0), o32.reset(), 'reset obs')
+    out = env.rollout(torch.from_numpy(acts))
+    resets = 0
+    for t in range(T):
+        w = o32.step(act_idx=acts[t])
+        _assert_same_bits(_np(out['obs'][t]), w['obs'], 'obs[%d]' % t)
+        _assert_same_bits(_np(out['rew'][t]), w['rew'], 'rew[%d]' % t)
+        _assert_same_bits(_np(out['terminal'][t]).astype(np.uint8), w['terminal'], 'terminal[%d]' % t)
+        if w['terminal'].any():
+            resets += 1
+            _assert_same_bits(_np(out['final_obs'][t]), w['final_obs'], 'final_obs[%d]' % t)
+            assert w['terminal'].all() and (t + 1) % ep_len == 0
+    assert resets == T // ep_len
+    st = env.get_state()
+    _assert_same_bits(_np(st['pos']), o32.pos, 'pos')
+    _assert_same_bits(_np(st['vel']), o32.vel, 'vel')
+    _assert_same_bits(_np(st['landmarks']), o32.lm, 'landmarks')
+    assert np.array_equal(_np(st['ep_step']), o32.ep_step) and np.array_equal(_np(st['ep_count']).astype(np.uint32), o32.ep_count)
+
+
+def test_rollout_equals_repeated_steps_and_onehot_equals_index():
+    T = 30
+    rng = np.random.RandomState(11)
+    acts = rng.randint(0, 5, (T, 300, 6)).astype(np.int32)
+    a, _ = _mk(num_agents=6, num_envs=300, max_episode_len=25, auto_reset=True, seed=3)
+    b, _ = _mk(num_agents=6, num_envs=300, max_episode_len=25, auto_reset=True, seed=3)
+    c, _ = _mk(num_agents=6, num_envs=300, max_episode_len=25, auto_reset=True, seed=3)
+    for e in (a, b, c):
+        e.reset()
+    out = a.rollout(torch.from_numpy(acts))
+    eye = np.eye(5, dtype=np.float32)
+    for t in range(T):
+        obs, rew, done, info = b.step(torch.from_numpy(acts[t]))
+        soft = eye[acts[t]] * 0.6 + 0.05  # arg-maxed because force_discrete_action (scenarios.py:191)
+        obs_c, rew_c, _, info_c = c.step(torch.from_numpy(soft))
+        _assert_same_bits(_np(obs), _np(out['obs'][t]), 'obs')
+        _assert_same_bits(_np(rew), _np(out['rew'][t]), 'rew')
+        _assert_same_bits(_np(obs_c), _np(out['obs'][t]), 'obs(one-hot)')
+        _assert_same_bits(_np(info['terminal']), _np(out['terminal'][t]), 'terminal')
+        if _np(info['terminal']).any():
+            _assert_same_bits(_np(info['final_obs']), _np(out['final_obs'][t]), 'final_obs')
+            _assert_same_bits(_np(info_c['final_obs']), _np(out['final_obs'][t]), 'final_obs(one-hot)')
+
+
+def test_soft_actions_without_force_discrete():
+    env, cfg = _mk(num_agents=3, num_envs=50, max_episode_len=0, force_discrete_action=False)
+    rng = np.random.RandomState(2)
+    pos, vel, lm = _rand_state(rng, 50, 3, 3)
+    soft = rng.uniform(0, 1, (50, 3, 5)).astype(np.float32)
+    env.set_state(pos, vel, lm)
+    env.step(torch.from_numpy(soft))
+    o32 = co.COracle(cfg, 50, np.float32)
+    o32.set_state(pos, vel, lm)
+    o32.step(act_vec=soft)
+    _assert_same_bits(_np(env.get_state()['pos']), o32.pos, 'pos')
+
+
+def test_masked_reset_and_shard_invariance():
+    full, cfg = _mk(num_agents=6, num_envs=96, seed=2024)
+    o = co.COracle(cfg, 96, np.float32)
+    obs = full.reset()
+    _assert_same_bits(_np(obs), o.reset(), 'reset')
+    # the same 96 envs as two shards (env_id_base) draw the same states
+    lo, _ = _mk(num_agents=6, num_envs=40, seed=2024, env_id_base=0)
+    hi, _ = _mk(num_agents=6, num_envs=56, seed=2024, env_id_base=40)
+    _assert_same_bits(np.concatenate([_np(lo.reset()), _np(hi.reset())]), _np(obs), 'sharded reset')
+    # masked reset: only masked-in envs change; their episode counter advances
+    mask = (np.arange(96) % 3 == 0).astype(np.uint8)
+    before = full.get_state()
+    obs2 = full.reset(torch.from_numpy(mask))
+    _assert_same_bits(_np(obs2), o.reset(mask), 'masked reset')
+    after = full.get_state()
+    keep = mask == 0
+    assert np.array_equal(_np(after['pos'])[keep], _np(before['pos'])[keep])
+    assert (_np(after['pos'])[~keep] != _np(before['pos'])[~keep]).any()
+    assert np.array_equal(_np(after['ep_count']), 1 + mask.astype(np.int32))
+
+
+def test_coincident_agents_propagate_nan_like_upstream():
+    env, cfg = _mk(num_agents=3, num_envs=2, max_episode_len=0)
+    pos = np.array([[[0.1, 0.1], [0.1, 0.1], [0.7, 0.7]], [[0, 0], [0.5, 0.5], [-0.5, 0.5]]], np.float32)
+    lm = np.zeros((2, 3, 2), np.float32)
+    env.set_state(pos, None, lm)
+    env.step(torch.zeros(2, 3, dtype=torch.int32))
+    o32 = co.COracle(cfg, 2, np.float32)
+    o32.set_state(pos, 0, lm)
+    o32.step(act_idx=np.zeros((2, 3), np.int32))
+    got = _np(env.get_state()['pos'])
+    assert np.isnan(got[0, :2]).all() and np.isnan(o32.pos[0, :2]).all()   # 0/0 in delta/dist, as NumPy
+    _assert_same_bits(got, o32.pos, 'pos')
+
+
+def test_full_size_properties_c2():
+    """BASELINE configs[1]: size-independent invariants at B=4096, N=6 over one episode."""
+    env, cfg = _mk(num_agents=6, num_envs=4096, max_episode_len=25, auto_reset=True, want_coll=True)
+    obs0 = env.reset()
+    T = 25
+    acts = torch.zeros(T, 4096, 6, dtype=torch.int32, device='cuda')      # no-op: only contact forces act
+    st0 = env.get_state()
+    out = env.rollout(acts)
+    obs, coll = _np(out['obs']), _coll(out['coll'])
+    # obs layout (experiments/scenarios.py:6-20): [vel, pos, landmark - pos]
+    lm = _np(st0['landmarks'])
+    for t in (0, 10, 23):
+        pos_t = obs[t, :, :, 2:4]
+        want = (lm[:, None, :, :] - pos_t[:, :, None, :]).reshape(4096, 6, 12)
+        np.testing.assert_array_equal(obs[t, :, :, 4:], want)
+    # momentum: contact forces are pairwise antisymmetric, v' = 0.75 v + F dt  =>  sum_i v_i decays by 0.75
+    mom = obs[:24, :, :, 0:2].astype(np.float64).sum(axis=2)
+    np.testing.assert_allclose(mom[1:], 0.75 * mom[:-1], rtol=0, atol=2e-5)
+    # collision masks: symmetric, self bit always set, and consistent with the reward's -1 terms
+    bits = (coll[..., None] >> np.arange(6, dtype=np.uint64)) & np.uint64(1)
+    assert (bits == bits.swapaxes(-1, -2)).all() and (np.diagonal(bits, axis1=-2, axis2=-1) == 1).all()
+    rew = _np(out['rew']).astype(np.float64)
+    shared_term = rew + bits.sum(-1)
+    np.testing.assert_allclose(shared_term, shared_term[:, :, :1].repeat(6, 2), atol=2e-5)
+    # the episode boundary: step 25 resets every env; post-reset velocities are zero
+    assert _np(out['terminal'])[24].all() and not _np(out['terminal'])[:24].any()
+    assert not obs[24, :, :, 0:2].any() and obs[23, :, :, 0:2].any()
+    assert np.array_equal(_np(env.get_state()['ep_count']), np.full(4096, 2, np.int32))
+    assert not _np(out['done']).any()
