@@ -10,7 +10,7 @@
 // whole envs, so every per-env exchange is a wave-local LDS broadcast or a
 // ds_bpermute shuffle and no env ever straddles a wave.  A workgroup is ONE wave
 // (64 threads): at B = 4096, N = 6 that is 410 independent workgroups over the
-// 256 CUs, and __syncthreads() degenerates to an LDS fence (no s_barrier wait).
+// 256 CUs, and cross-lane hand-offs need only an LDS wait (wave_lds_sync), never a barrier.
 // State planes are SoA over the flattened [B x N] index g = env * N + agent, so a
 // wave's loads/stores are one contiguous run of EPW*N floats per plane.
 //
@@ -19,7 +19,9 @@
 // restatement reproduces every output bit (tests/ compare against oracle/).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -46,6 +48,13 @@ int fail(int code, const std::string &msg)
     } while (0)
 
 constexpr int kWave = 64;
+
+// Every workgroup is ONE wave, and a wave's LDS instructions execute in issue order, so the
+// only thing a write -> cross-lane read hand-off through LDS needs is (a) that the compiler
+// keeps the program order of the accesses and (b) that the data has landed before it is
+// consumed.  Unlike __syncthreads() this does NOT drain vmcnt: the step's global stores
+// (16 B x 4 per lane of observations) stay in flight across steps.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // Everything a kernel needs, passed by value in the kernarg segment.
 struct KParams {
@@ -196,7 +205,7 @@ __device__ __forceinline__ float reward_and_mask(const KParams &P, const Lane &l
             if (L > N && ln.valid) s_red[ln.e_local * L + l] = own;
         }
         if (L > N) {
-            __syncthreads();
+            wave_lds_sync();
             for (int l = 0; l < L; ++l) r -= s_red[ln.e_local * L + l];
         } else {
             // per-env ordered reduction over the env's lanes by wave shuffle (ds_bpermute)
@@ -259,6 +268,370 @@ size_t smem_bytes(const KParams &P)
     return (size_t)P.epw * (2 * P.N + P.L) * sizeof(float2) + (size_t)P.epw * P.L * sizeof(float);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Fast path: simple_spread, local observation, homogeneous agents (one size, no max_speed),
+// landmarks that do not collide, L <= N.  Same arithmetic, same bits, fewer instructions:
+//  * far pairs are skipped: beyond dist_min + 88 k the softplus is EXACTLY 0 (pw_exp underflow
+//    cut), the force term is +-0 and adding it never changes the accumulator (which cannot be -0);
+//  * is_collision needs no sqrt: sqrt is monotone and correctly rounded, so
+//    sqrt(d2) < dist_min  <=>  d2 < coll_thr2 with coll_thr2 = min{y : sqrtf(y) >= dist_min},
+//    found on the host;
+//  * one pass over the env's positions in LDS after integration yields the collision mask of
+//    step t, the near-pair mask of step t+1 and the owned landmark's min distance;
+//  * NT > 0 fixes N at compile time (loops unrolled); the next step's action is prefetched.
+// ------------------------------------------------------------------------------------------
+struct FastConsts {
+    float dist_min, coll_thr2, near_thr2, sens, fscale, size;
+};
+
+template <int NT>
+__device__ __forceinline__ void partner_pass(const int N, const Lane &ln, const float2 *pp, float px, float py,
+                                             bool own_lm, float olx, float oly, const FastConsts &C,
+                                             uint64_t &coll, uint64_t &near, float &best)
+{
+    coll = 0; near = 0; best = 0.0f;
+#pragma unroll(NT > 0 ? NT : 1)
+    for (int j = 0; j < (NT ? NT : N); ++j) {
+        const float2 q = pp[j];
+        const float dx = q.x - px, dy = q.y - py;
+        const float d2 = dx * dx + dy * dy;  // (q - p)^2 == (p - q)^2 bit for bit
+        if (d2 < C.coll_thr2) coll |= 1ull << j;
+        const bool far = d2 >= C.near_thr2 && d2 <= 3.402823466e+38f;  // NaN / inf stay "near"
+        if (!far && j != ln.a) near |= 1ull << j;
+        const float ex = q.x - olx, ey = q.y - oly;
+        const float e2 = ex * ex + ey * ey;
+        best = (j == 0 || e2 < best) ? e2 : best;
+    }
+    (void)own_lm;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(kWave) pw_spread_fast_kernel(const KParams P, const pw_step_io io, const int T,
+                                                               const FastConsts C)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const Smem S = carve(P, smem_raw);
+    const Lane ln = make_lane(P);
+    const int N = NT ? NT : P.N, L = P.L, D = P.D;
+    const size_t BN = (size_t)P.B * N;
+    const float2 *pp = S.pos + ln.base;
+    float2 *lmv = S.lm + ln.e_local * L;
+
+    float px = 0.f, py = 0.f, vx = 0.f, vy = 0.f, olx = 0.f, oly = 0.f;
+    int ep_step = 0;
+    uint32_t ep_count = 0;
+    const bool own_lm = ln.a < L;
+    if (ln.valid) {
+        px = P.pos_x[ln.g]; py = P.pos_y[ln.g];
+        vx = P.vel_x[ln.g]; vy = P.vel_y[ln.g];
+        ep_step = P.ep_step[ln.env];
+        ep_count = P.ep_count[ln.env];
+        if (own_lm) {
+            olx = P.lm_x[(size_t)ln.env * L + ln.a];
+            oly = P.lm_y[(size_t)ln.env * L + ln.a];
+            lmv[ln.a] = make_float2(olx, oly);
+        }
+        S.pos[threadIdx.x] = make_float2(px, py);
+    }
+    wave_lds_sync();
+    uint64_t coll, near;
+    float best;
+    partner_pass<NT>(N, ln, pp, px, py, own_lm, olx, oly, C, coll, near, best);
+
+    const float k = P.contact_margin, cf = P.contact_force, dt = P.dt, damp = P.damp, mass = P.mass;
+    int act_next = 0;
+    if (ln.valid && io.act_idx) act_next = io.act_idx[ln.g];
+
+    for (int t = 0; t < T; ++t) {
+        const size_t row = (size_t)t * BN + ln.g;
+        // ---- U2 + U4
+        float ux, uy;
+        if (io.act_idx) {
+            const int a = act_next;
+            if (t + 1 < T && ln.valid) act_next = io.act_idx[row + BN];  // prefetch step t+1
+            ux = 0.0f + ((a == 1 ? 1.0f : 0.0f) - (a == 2 ? 1.0f : 0.0f));
+            uy = 0.0f + ((a == 3 ? 1.0f : 0.0f) - (a == 4 ? 1.0f : 0.0f));
+        } else {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+            if (ln.valid) {
+                const float *av = io.act_vec + row * 5;
+                a0 = av[0]; a1 = av[1]; a2 = av[2]; a3 = av[3]; a4 = av[4];
+            }
+            if (P.force_discrete) {
+                int d = 0;
+                float bst = a0;
+                if (a1 > bst) { bst = a1; d = 1; }
+                if (a2 > bst) { bst = a2; d = 2; }
+                if (a3 > bst) { bst = a3; d = 3; }
+                if (a4 > bst) { bst = a4; d = 4; }
+                a1 = d == 1; a2 = d == 2; a3 = d == 3; a4 = d == 4;
+            }
+            ux = 0.0f + (a1 - a2);
+            uy = 0.0f + (a3 - a4);
+        }
+        ux *= C.sens; uy *= C.sens;
+        if (C.fscale != 1.0f) { ux = C.fscale * ux; uy = C.fscale * uy; }
+        float fx = ux + 0.0f, fy = uy + 0.0f;
+        // ---- U5: only partners whose force can be non-zero, ascending j
+        for (uint64_t m = ln.valid ? near : 0; m; m &= m - 1) {
+            const int j = __builtin_ctzll(m);
+            const float2 q = pp[j];
+            collision_force(px, py, q.x, q.y, C.dist_min, k, cf, fx, fy);
+        }
+        // ---- U6
+        vx = vx * damp; vy = vy * damp;
+        vx = vx + (fx / mass) * dt;
+        vy = vy + (fy / mass) * dt;
+        px = px + vx * dt;
+        py = py + vy * dt;
+        wave_lds_sync();
+        if (ln.valid) S.pos[threadIdx.x] = make_float2(px, py);
+        wave_lds_sync();
+
+        partner_pass<NT>(N, ln, pp, px, py, own_lm, olx, oly, C, coll, near, best);
+        // ---- simple_spread.reward
+        const float own = sqrtf(best);
+        float r = 0.0f;
+        for (int l = 0; l < L; ++l) r -= __shfl(own, ln.base + l, kWave);
+#pragma unroll(NT > 0 ? NT : 1)
+        for (int a = 0; a < (NT ? NT : N); ++a)
+            if ((coll >> a) & 1) r -= 1.0f;
+        if (ln.valid) {
+            if (io.rew) io.rew[row] = r;
+            if (io.done) io.done[row] = 0;
+            if (io.coll) io.coll[row] = coll;
+        }
+        if (io.rew_shared) {
+            float acc = 0.0f;
+#pragma unroll(NT > 0 ? NT : 1)
+            for (int i = 0; i < (NT ? NT : N); ++i) acc += __shfl(r, ln.base + i, kWave);
+            if (ln.valid && ln.a == 0) io.rew_shared[(size_t)t * P.B + ln.env] = acc;
+        }
+        ep_step += 1;
+        const bool term = P.max_episode_len > 0 && ep_step >= P.max_episode_len;
+        if (ln.valid && ln.a == 0 && io.terminal) io.terminal[(size_t)t * P.B + ln.env] = term ? 1 : 0;
+        const bool do_reset = ln.valid && term && P.auto_reset;
+        if (__any(do_reset)) {
+            if (do_reset && io.final_obs)
+                write_obs<PW_SIMPLE_SPREAD, PW_OBS_LOCAL>(P, ln, io.final_obs + row * D, px, py, vx, vy, S.pos, S.vel, S.lm);
+            wave_lds_sync();
+            if (do_reset) {
+                ep_count += 1;
+                ep_step = 0;
+                reset_lane(P, ln, ep_count, PW_SIMPLE_SPREAD, px, py, S.lm);
+                vx = 0.f; vy = 0.f;
+                S.pos[threadIdx.x] = make_float2(px, py);
+            }
+            wave_lds_sync();
+            if (own_lm) { const float2 q = lmv[ln.a]; olx = q.x; oly = q.y; }
+            partner_pass<NT>(N, ln, pp, px, py, own_lm, olx, oly, C, coll, near, best);
+        }
+        if (ln.valid && io.obs)
+            write_obs<PW_SIMPLE_SPREAD, PW_OBS_LOCAL>(P, ln, io.obs + row * D, px, py, vx, vy, S.pos, S.vel, S.lm);
+    }
+
+    if (ln.valid) {
+        P.pos_x[ln.g] = px; P.pos_y[ln.g] = py;
+        P.vel_x[ln.g] = vx; P.vel_y[ln.g] = vy;
+        if (own_lm) {
+            P.lm_x[(size_t)ln.env * L + ln.a] = olx;
+            P.lm_y[(size_t)ln.env * L + ln.a] = oly;
+        }
+        if (ln.a == 0) {
+            P.ep_step[ln.env] = ep_step;
+            P.ep_count[ln.env] = ep_count;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Streaming variant of the fast path: the same arithmetic as pw_spread_fast_kernel, laid out
+// so the memory pipeline never stalls the step loop.
+//  * gfx950 counts loads AND stores in one in-order vmcnt.  The next step's action is loaded
+//    at the top of a step, before that step's stores; the wait for it is exact only if the
+//    compiler knows how many stores follow, so every store here is unconditional: outputs
+//    are all present (checked on the host), per-env values are stored by every lane of the
+//    env (same address, same value), and idle lanes SHADOW lane 0 of their wave -- same
+//    loads, same arithmetic, same stores -- instead of being branched around.
+//  * NT / LT fix N and L at compile time; collision / near masks are 32-bit when N <= 32.
+// ------------------------------------------------------------------------------------------
+struct StreamParams {
+    int B, N, L, epw, max_episode_len, auto_reset;
+    uint64_t seed, env_id_base;
+    float dt, damp, contact_force, contact_margin, mass;
+    float dist_min, coll_thr2, near_thr2, sens, fscale;
+    float *pos_x, *pos_y, *vel_x, *vel_y, *lm_x, *lm_y;
+    int32_t *ep_step;
+    uint32_t *ep_count;
+    const int32_t *act;
+    float *obs, *final_obs, *rew, *rew_shared;
+    uint8_t *done, *terminal;
+};
+
+template <int LT>
+__device__ __forceinline__ void stream_write_obs(float *__restrict__ o, const int L, const float2 *lm, float px,
+                                                 float py, float vx, float vy)
+{
+    if ((LT ? LT : L) % 2 == 0) {
+        float4 *o4 = reinterpret_cast<float4 *>(o);
+        o4[0] = make_float4(vx, vy, px, py);
+#pragma unroll(LT > 0 ? LT / 2 : 1)
+        for (int c = 0; c < (LT ? LT : L) / 2; ++c) {
+            const float2 l0 = lm[2 * c], l1 = lm[2 * c + 1];
+            o4[1 + c] = make_float4(l0.x - px, l0.y - py, l1.x - px, l1.y - py);
+        }
+    } else {
+        float2 *o2 = reinterpret_cast<float2 *>(o);
+        o2[0] = make_float2(vx, vy);
+        o2[1] = make_float2(px, py);
+#pragma unroll(LT > 0 ? LT : 1)
+        for (int l = 0; l < (LT ? LT : L); ++l) {
+            const float2 q = lm[l];
+            o2[2 + l] = make_float2(q.x - px, q.y - py);
+        }
+    }
+}
+
+template <int NT, typename MaskT>
+__device__ __forceinline__ void stream_partner_pass(const int N, const int a, const float2 *pp, float px, float py,
+                                                    float olx, float oly, float coll_thr2, float near_thr2,
+                                                    MaskT &coll, MaskT &near, float &best)
+{
+    coll = 0; near = 0; best = 0.0f;
+#pragma unroll(NT > 0 ? NT : 1)
+    for (int j = 0; j < (NT ? NT : N); ++j) {
+        const float2 q = pp[j];
+        const float dx = q.x - px, dy = q.y - py;
+        const float d2 = dx * dx + dy * dy;
+        if (d2 < coll_thr2) coll |= (MaskT)1 << j;
+        const bool far = d2 >= near_thr2 && d2 <= 3.402823466e+38f;
+        if (!far && j != a) near |= (MaskT)1 << j;
+        const float ex = q.x - olx, ey = q.y - oly;
+        const float e2 = ex * ex + ey * ey;
+        best = (j == 0 || e2 < best) ? e2 : best;
+    }
+}
+
+template <int NT, int LT>
+__global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamParams A, const int T)
+{
+    using MaskT = typename std::conditional<(NT > 0 && NT <= 32), uint32_t, uint64_t>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int N = NT ? NT : A.N, L = LT ? LT : A.L, D = 4 + 2 * L;
+    float2 *s_pos = reinterpret_cast<float2 *>(smem_raw);  // [64]
+    float2 *s_lm = s_pos + kWave;                          // [epw * L]
+
+    int e_local = (int)threadIdx.x / N;
+    int a = (int)threadIdx.x - e_local * N;
+    int env = blockIdx.x * A.epw + e_local;
+    if (e_local >= A.epw || env >= A.B) {  // idle lane: shadow lane 0 (env slot 0, agent 0)
+        e_local = 0; a = 0; env = blockIdx.x * A.epw;
+    }
+    const int base = e_local * N;
+    const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
+    const size_t BN = (size_t)A.B * N;
+    const float2 *pp = s_pos + base;
+    float2 *lmv = s_lm + e_local * L;
+    const int la = a < L ? a : 0;  // the landmark this lane "owns" (lanes a >= L duplicate 0, unused)
+
+    float px = A.pos_x[g], py = A.pos_y[g], vx = A.vel_x[g], vy = A.vel_y[g];
+    int ep_step = A.ep_step[env];
+    uint32_t ep_count = A.ep_count[env];
+    float olx = 0.f, oly = 0.f;
+    if (L > 0) {
+        olx = A.lm_x[(size_t)env * L + la];
+        oly = A.lm_y[(size_t)env * L + la];
+        lmv[la] = make_float2(olx, oly);
+    }
+    s_pos[base + a] = make_float2(px, py);
+    wave_lds_sync();
+    MaskT coll, near;
+    float best;
+    stream_partner_pass<NT, MaskT>(N, a, pp, px, py, olx, oly, A.coll_thr2, A.near_thr2, coll, near, best);
+
+    const float k = A.contact_margin, cf = A.contact_force, dt = A.dt, damp = A.damp, mass = A.mass;
+    int act_next = A.act[g];
+
+    for (int t = 0; t < T; ++t) {
+        const size_t tBN = (size_t)t * BN;
+        // ---- U2 + U4 (action index path); prefetch the next step's action before any store
+        const int ai = act_next;
+        {
+            const int tn = t + 1 < T ? t + 1 : t;
+            act_next = A.act[(size_t)tn * BN + g];
+        }
+        float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
+        float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
+        ux *= A.sens; uy *= A.sens;
+        if (A.fscale != 1.0f) { ux = A.fscale * ux; uy = A.fscale * uy; }
+        float fx = ux + 0.0f, fy = uy + 0.0f;
+        // ---- U5
+        for (MaskT m = near; m; m &= m - 1) {
+            const int j = sizeof(MaskT) == 4 ? __builtin_ctz((uint32_t)m) : __builtin_ctzll((uint64_t)m);
+            const float2 q = pp[j];
+            collision_force(px, py, q.x, q.y, A.dist_min, k, cf, fx, fy);
+        }
+        // ---- U6
+        vx = vx * damp; vy = vy * damp;
+        vx = vx + (fx / mass) * dt;
+        vy = vy + (fy / mass) * dt;
+        px = px + vx * dt;
+        py = py + vy * dt;
+        wave_lds_sync();
+        s_pos[base + a] = make_float2(px, py);
+        wave_lds_sync();
+
+        stream_partner_pass<NT, MaskT>(N, a, pp, px, py, olx, oly, A.coll_thr2, A.near_thr2, coll, near, best);
+        // ---- simple_spread.reward
+        const float own = sqrtf(best);
+        float r = 0.0f;
+#pragma unroll(LT > 0 ? LT : 1)
+        for (int l = 0; l < (LT ? LT : L); ++l) r -= __shfl(own, base + l, kWave);
+#pragma unroll(NT > 0 ? NT : 1)
+        for (int j = 0; j < (NT ? NT : N); ++j)
+            if ((coll >> j) & 1) r -= 1.0f;
+        float acc = 0.0f;
+#pragma unroll(NT > 0 ? NT : 1)
+        for (int i = 0; i < (NT ? NT : N); ++i) acc += __shfl(r, base + i, kWave);
+        A.rew[tBN + g] = r;
+        A.done[tBN + g] = 0;
+        A.rew_shared[(size_t)t * A.B + env] = acc;
+        ep_step += 1;
+        const bool term = A.max_episode_len > 0 && ep_step >= A.max_episode_len;
+        A.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+        if (term && A.auto_reset) {  // same for every lane of an env; rare (1 step in max_episode_len)
+            if (A.final_obs) stream_write_obs<LT>(A.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+            wave_lds_sync();
+            ep_count += 1;
+            ep_step = 0;
+            const uint64_t env_id = A.env_id_base + (uint64_t)env;
+            pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
+            vx = 0.f; vy = 0.f;
+            if (L > 0) {
+                pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)(N + la), -1.0f, 1.0f, &olx, &oly);
+                lmv[la] = make_float2(olx, oly);
+            }
+            s_pos[base + a] = make_float2(px, py);
+        }
+        // (lanes whose env did not reset wait here for the ones that did: one wave, reconverged)
+        wave_lds_sync();
+        if (A.auto_reset && __any(term))
+            stream_partner_pass<NT, MaskT>(N, a, pp, px, py, olx, oly, A.coll_thr2, A.near_thr2, coll, near, best);
+        stream_write_obs<LT>(A.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+    }
+
+    A.pos_x[g] = px; A.pos_y[g] = py;
+    A.vel_x[g] = vx; A.vel_y[g] = vy;
+    if (L > 0) {
+        A.lm_x[(size_t)env * L + la] = olx;
+        A.lm_y[(size_t)env * L + la] = oly;
+    }
+    A.ep_step[env] = ep_step;
+    A.ep_count[env] = ep_count;
+}
+
 // ------------------------------------------------------------------------------------------
 // MultiAgentEnv.step for T consecutive steps.
 // ------------------------------------------------------------------------------------------
@@ -289,7 +662,7 @@ __global__ void __launch_bounds__(kWave) pw_rollout_kernel(const KParams P, cons
         S.pos[threadIdx.x] = make_float2(px, py);
         if (SCEN == PW_SIMPLE_TAG) S.vel[threadIdx.x] = make_float2(vx, vy);
     }
-    __syncthreads();
+    wave_lds_sync();
 
     const float k = P.contact_margin, cf = P.contact_force, dt = P.dt, damp = P.damp, mass = P.mass;
 
@@ -350,12 +723,12 @@ __global__ void __launch_bounds__(kWave) pw_rollout_kernel(const KParams P, cons
             px = px + vx * dt;
             py = py + vy * dt;
         }
-        __syncthreads();  // every lane has read the old positions
+        wave_lds_sync();  // every lane has read the old positions
         if (ln.valid) {
             S.pos[threadIdx.x] = make_float2(px, py);
             if (SCEN == PW_SIMPLE_TAG) S.vel[threadIdx.x] = make_float2(vx, vy);
         }
-        __syncthreads();
+        wave_lds_sync();
 
         // ---- reward / masks from the new state
         uint64_t mask = 0;
@@ -378,7 +751,7 @@ __global__ void __launch_bounds__(kWave) pw_rollout_kernel(const KParams P, cons
         if (__any(do_reset)) {
             if (do_reset && io.final_obs)
                 write_obs<SCEN, OBS>(P, ln, io.final_obs + row * D, px, py, vx, vy, S.pos, S.vel, S.lm);
-            __syncthreads();
+            wave_lds_sync();
             if (do_reset) {
                 ep_count += 1;
                 ep_step = 0;
@@ -387,7 +760,7 @@ __global__ void __launch_bounds__(kWave) pw_rollout_kernel(const KParams P, cons
                 S.pos[threadIdx.x] = make_float2(px, py);
                 if (SCEN == PW_SIMPLE_TAG) S.vel[threadIdx.x] = make_float2(0.f, 0.f);
             }
-            __syncthreads();
+            wave_lds_sync();
         }
         if (ln.valid && io.obs)
             write_obs<SCEN, OBS>(P, ln, io.obs + row * D, px, py, vx, vy, S.pos, S.vel, S.lm);
@@ -436,7 +809,7 @@ __global__ void __launch_bounds__(kWave) pw_aux_kernel(const KParams P, const in
         S.pos[threadIdx.x] = make_float2(px, py);
         if (SCEN == PW_SIMPLE_TAG) S.vel[threadIdx.x] = make_float2(vx, vy);
     }
-    __syncthreads();
+    wave_lds_sync();
     if (ln.valid && (mode & 1) && (!env_mask || env_mask[ln.env])) {
         P.pos_x[ln.g] = px; P.pos_y[ln.g] = py;
         P.vel_x[ln.g] = 0.f; P.vel_y[ln.g] = 0.f;
@@ -457,7 +830,7 @@ __global__ void __launch_bounds__(kWave) pw_aux_kernel(const KParams P, const in
     if ((mode & 2) && ln.valid && obs)
         write_obs<SCEN, OBS>(P, ln, obs + ln.g * P.D, px, py, vx, vy, S.pos, S.vel, S.lm);
     // counters last: every lane of the env has read ep_count above (same wave, program order)
-    __syncthreads();
+    wave_lds_sync();
     if (ln.valid && (mode & 1) && ln.a == 0 && (!env_mask || env_mask[ln.env])) {
         P.ep_count[ln.env] += 1;
         P.ep_step[ln.env] = 0;
@@ -552,6 +925,8 @@ struct pw_handle {
     KParams kp;
     pw_state_layout layout;
     bool bound;
+    bool fast;      // pw_spread_fast_kernel applies
+    FastConsts fc;
 };
 
 namespace {
@@ -570,6 +945,43 @@ int dispatch(const pw_handle *h, F &&f)
     if (h->cfg.scenario == PW_SIMPLE_TAG) return f(std::integral_constant<int, PW_SIMPLE_TAG>(), std::integral_constant<int, PW_OBS_LOCAL>());
     if (h->cfg.obs_mode == PW_OBS_FULL) return f(std::integral_constant<int, PW_SIMPLE_SPREAD>(), std::integral_constant<int, PW_OBS_FULL>());
     return f(std::integral_constant<int, PW_SIMPLE_SPREAD>(), std::integral_constant<int, PW_OBS_LOCAL>());
+}
+
+// Decide whether pw_spread_fast_kernel applies and derive its exact thresholds on the host.
+void setup_fast_path(pw_handle *h)
+{
+    const pw_config &c = h->cfg;
+    const KParams &kp = h->kp;
+    h->fast = false;
+    if (std::getenv("PWORLD_FORCE_GENERIC")) return;
+    if (c.scenario != PW_SIMPLE_SPREAD || c.obs_mode != PW_OBS_LOCAL || c.landmark_collide) return;
+    if (kp.L > kp.N) return;
+    for (int i = 0; i < kp.N; ++i) {
+        if (kp.agent_size[i] != kp.agent_size[0] || kp.agent_sens[i] != kp.agent_sens[0] ||
+            kp.agent_fscale[i] != kp.agent_fscale[0] || kp.agent_max_speed[i] >= 0.0f)
+            return;
+    }
+    FastConsts &fc = h->fc;
+    fc.size = kp.agent_size[0];
+    fc.sens = kp.agent_sens[0];
+    fc.fscale = kp.agent_fscale[0];
+    const volatile float dmin = fc.size + fc.size;  // float add, as the kernels do
+    fc.dist_min = dmin;
+    if (!(dmin > 0.0f) || !std::isfinite(dmin)) return;
+    // coll_thr2 = min{y : sqrtf(y) >= dist_min}: then sqrtf(d2) < dist_min <=> d2 < coll_thr2
+    float y = dmin * dmin;
+    while (sqrtf(y) >= dmin) y = std::nextafterf(y, 0.0f);
+    while (!(sqrtf(y) >= dmin)) y = std::nextafterf(y, INFINITY);
+    fc.coll_thr2 = y;
+    // beyond near_r the softplus argument is <= -88 < -87 (pw_exp's exact-zero cut), with margin
+    const double near_r = (double)dmin + 88.5 * (double)kp.contact_margin;
+    float n2 = (float)(near_r * near_r * (1.0 + 1e-6));
+    n2 = std::nextafterf(n2, INFINITY);
+    const float dist_at = sqrtf(n2);
+    const float x_at = -(dist_at - dmin) / kp.contact_margin;
+    if (!(x_at <= -87.5f) || !std::isfinite(n2)) return;
+    fc.near_thr2 = n2;
+    h->fast = true;
 }
 
 int check_ready(const pw_handle *h)
@@ -593,6 +1005,51 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
     const KParams &kp = h->kp;
     const dim3 grid((kp.B + kp.epw - 1) / kp.epw), block(kWave);
     const size_t shmem = smem_bytes(kp);
+    if (h->fast && io->act_idx && io->obs && io->rew && io->rew_shared && io->done && io->terminal && !io->coll &&
+        (size_t)kp.B * kp.N * kp.D * sizeof(float) < (1ull << 31) && !std::getenv("PWORLD_NO_STREAM")) {
+        StreamParams A;
+        A.B = kp.B; A.N = kp.N; A.L = kp.L; A.epw = kp.epw;
+        A.max_episode_len = kp.max_episode_len; A.auto_reset = kp.auto_reset;
+        A.seed = kp.seed; A.env_id_base = kp.env_id_base;
+        A.dt = kp.dt; A.damp = kp.damp; A.contact_force = kp.contact_force; A.contact_margin = kp.contact_margin;
+        A.mass = kp.mass;
+        A.dist_min = h->fc.dist_min; A.coll_thr2 = h->fc.coll_thr2; A.near_thr2 = h->fc.near_thr2;
+        A.sens = h->fc.sens; A.fscale = h->fc.fscale;
+        A.pos_x = kp.pos_x; A.pos_y = kp.pos_y; A.vel_x = kp.vel_x; A.vel_y = kp.vel_y;
+        A.lm_x = kp.lm_x; A.lm_y = kp.lm_y; A.ep_step = kp.ep_step; A.ep_count = kp.ep_count;
+        A.act = io->act_idx; A.obs = io->obs; A.final_obs = io->final_obs; A.rew = io->rew;
+        A.rew_shared = io->rew_shared; A.done = io->done; A.terminal = io->terminal;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const size_t shm = (size_t)(kWave + kp.epw * kp.L) * sizeof(float2);
+        const int key = kp.N == kp.L ? kp.N : 0;
+        switch (key) {
+#define PW_STREAM_CASE(n)                                                                                    \
+    case n:                                                                                                  \
+        hipLaunchKernelGGL((pw_spread_stream_kernel<n, n>), grid, block, shm, st, A, T);                     \
+        break;
+            PW_STREAM_CASE(3) PW_STREAM_CASE(6) PW_STREAM_CASE(9) PW_STREAM_CASE(12)
+#undef PW_STREAM_CASE
+        default:
+            hipLaunchKernelGGL((pw_spread_stream_kernel<0, 0>), grid, block, shm, st, A, T);
+        }
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
+    if (h->fast) {
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        switch (kp.N) {
+#define PW_FAST_CASE(n)                                                                                      \
+    case n:                                                                                                  \
+        hipLaunchKernelGGL((pw_spread_fast_kernel<n>), grid, block, shmem, st, kp, *io, T, h->fc);           \
+        break;
+            PW_FAST_CASE(3) PW_FAST_CASE(6) PW_FAST_CASE(9) PW_FAST_CASE(12)
+#undef PW_FAST_CASE
+        default:
+            hipLaunchKernelGGL((pw_spread_fast_kernel<0>), grid, block, shmem, st, kp, *io, T, h->fc);
+        }
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
     return dispatch(h, [&](auto scen, auto obs) {
         hipLaunchKernelGGL((pw_rollout_kernel<decltype(scen)::value, decltype(obs)::value>), grid, block, shmem,
                            static_cast<hipStream_t>(stream), kp, *io, T);
@@ -714,6 +1171,7 @@ int pw_create(const pw_config *cfg, pw_handle **out)
                                  : 1.0f;
         kp.agent_max_speed[i] = cfg->agent_max_speed[i];
     }
+    setup_fast_path(h);
     const size_t BN = (size_t)kp.B * kp.N, BL = (size_t)kp.B * kp.L;
     pw_state_layout &lo = h->layout;
     size_t off = 0;
