@@ -168,6 +168,21 @@ def main():
     bytes_per_launch = env.bytes_per_env_step * B * steps_per_launch
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
 
+    # HBM traffic per launch: PMC counters cannot be collected from inside this process; use the committed
+    # rocprofv3 --pmc summary of this exact workload (profiles/, collected per the MI355X guide) if present.
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_summary.json')), reverse=True):
+            sm = json.load(open(f))
+            cfgw = sm.get('bench', {}).get('config', {}).get('workload', '')
+            if 'traffic_bytes_per_launch' in sm and ('N=%d ' % N) in cfgw and ('B=%d ' % B) in cfgw and \
+                    ('%d steps per pw_rollout' % T) in cfgw and args.scenario in cfgw:
+                traffic, traffic_src = sm['traffic_bytes_per_launch'], os.path.relpath(f, ROOT)
+                break
+    except Exception:
+        pass
+
     finite = bool(torch.isfinite(outs['obs'][-1]).all().item()) and (K < 25 or bool(outs['terminal'][24].all().item()))
 
     if rank == 0:
@@ -183,8 +198,9 @@ def main():
                        'global_batch': world * B, 'parallelism': 'env-shard x%d' % world,
                        'outputs_finite': finite},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
-                         'kernel': 'pw_rollout_kernel', 'launch_ms': launch_ms,
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'algorithmic_bytes_per_launch': bytes_per_launch,
+                         'kernel': 'pw_spread_stream_kernel<6,6>' if (args.scenario == 'simple_spread' and N == 6) else 'pw_rollout', 'launch_ms': launch_ms,
                          'bytes_per_env_step': env.bytes_per_env_step, 'env_steps_per_launch': B * steps_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline and args.scenario == 'simple_spread':

@@ -457,6 +457,30 @@ __global__ void __launch_bounds__(kWave) pw_spread_fast_kernel(const KParams P, 
 //    loads, same arithmetic, same stores -- instead of being branched around.
 //  * NT / LT fix N and L at compile time; collision / near masks are 32-bit when N <= 32.
 // ------------------------------------------------------------------------------------------
+// Diagnostic build only (tools/stamp_probe.hip defines PW_STAMPS): per-segment shader-cycle sums of
+// workgroup 0, written to a buffer nothing else reads.  The product build has no stamps.
+#ifdef PW_STAMPS
+__device__ unsigned long long g_pw_stamps[16];
+#define PW_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_now = 0; (void)st_now
+#define PW_STAMP_START asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory")
+#define PW_STAMP(i)                                                                      \
+    do {                                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory");   \
+        st_acc[i] += st_now - st_prev;                                                   \
+        st_prev = st_now;                                                                \
+    } while (0)
+#define PW_STAMP_FLUSH                                                                   \
+    do {                                                                                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0)                                         \
+            for (int i_ = 0; i_ < 8; ++i_) g_pw_stamps[i_] = st_acc[i_];                 \
+    } while (0)
+#else
+#define PW_STAMP_DECL
+#define PW_STAMP_START
+#define PW_STAMP(i)
+#define PW_STAMP_FLUSH
+#endif
+
 struct StreamParams {
     int B, N, L, epw, max_episode_len, auto_reset;
     uint64_t seed, env_id_base;
@@ -553,8 +577,17 @@ __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamPar
 
     const float k = A.contact_margin, cf = A.contact_force, dt = A.dt, damp = A.damp, mass = A.mass;
     int act_next = A.act[g];
+    // Vector-memory ops issued per step AFTER the action prefetch: rew, done, rew_shared, terminal
+    // + the observation row.  An explicit vmcnt(K) at the end of the step tells the compiler's
+    // waitcnt pass that the prefetched load has retired while the K stores stay in flight (it is
+    // a hint only: the compiler still inserts any wait it cannot prove redundant).
+    constexpr int kStoresPerStep = LT > 0 ? 4 + (LT % 2 == 0 ? 1 + LT / 2 : 2 + LT) : 0;
+    constexpr int kVm = kStoresPerStep < 63 ? kStoresPerStep : 63;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): enter the loop with nothing pending
+    PW_STAMP_DECL;
 
     for (int t = 0; t < T; ++t) {
+        PW_STAMP_START;
         const size_t tBN = (size_t)t * BN;
         // ---- U2 + U4 (action index path); prefetch the next step's action before any store
         const int ai = act_next;
@@ -567,12 +600,14 @@ __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamPar
         ux *= A.sens; uy *= A.sens;
         if (A.fscale != 1.0f) { ux = A.fscale * ux; uy = A.fscale * uy; }
         float fx = ux + 0.0f, fy = uy + 0.0f;
+        PW_STAMP(0);
         // ---- U5
         for (MaskT m = near; m; m &= m - 1) {
             const int j = sizeof(MaskT) == 4 ? __builtin_ctz((uint32_t)m) : __builtin_ctzll((uint64_t)m);
             const float2 q = pp[j];
             collision_force(px, py, q.x, q.y, A.dist_min, k, cf, fx, fy);
         }
+        PW_STAMP(1);
         // ---- U6
         vx = vx * damp; vy = vy * damp;
         vx = vx + (fx / mass) * dt;
@@ -582,8 +617,10 @@ __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamPar
         wave_lds_sync();
         s_pos[base + a] = make_float2(px, py);
         wave_lds_sync();
+        PW_STAMP(2);
 
         stream_partner_pass<NT, MaskT>(N, a, pp, px, py, olx, oly, A.coll_thr2, A.near_thr2, coll, near, best);
+        PW_STAMP(3);
         // ---- simple_spread.reward
         const float own = sqrtf(best);
         float r = 0.0f;
@@ -595,6 +632,7 @@ __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamPar
         float acc = 0.0f;
 #pragma unroll(NT > 0 ? NT : 1)
         for (int i = 0; i < (NT ? NT : N); ++i) acc += __shfl(r, base + i, kWave);
+        PW_STAMP(4);
         A.rew[tBN + g] = r;
         A.done[tBN + g] = 0;
         A.rew_shared[(size_t)t * A.B + env] = acc;
@@ -619,8 +657,13 @@ __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamPar
         wave_lds_sync();
         if (A.auto_reset && __any(term))
             stream_partner_pass<NT, MaskT>(N, a, pp, px, py, olx, oly, A.coll_thr2, A.near_thr2, coll, near, best);
+        PW_STAMP(5);
         stream_write_obs<LT>(A.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+        PW_STAMP(6);
+        if (LT > 0) __builtin_amdgcn_s_waitcnt((kVm & 0xF) | 0x0F70 | ((kVm >> 4) << 14));  // vmcnt(kVm)
+        PW_STAMP(7);
     }
+    PW_STAMP_FLUSH;
 
     A.pos_x[g] = px; A.pos_y[g] = py;
     A.vel_x[g] = vx; A.vel_y[g] = vy;

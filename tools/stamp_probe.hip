@@ -1,0 +1,44 @@
+// Diagnostic build (never shipped): the product translation unit compiled with PW_STAMPS, driven
+// through its own C ABI, printing the share of shader cycles per segment of one wave's step loop.
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -I include tools/stamp_probe.hip -o /tmp/stamp_probe
+#define PW_STAMPS 1
+#include "../multiagent_rl_amd/csrc/pworld.hip"
+#include <vector>
+
+int main(int argc, char **argv)
+{
+    const int B = argc > 1 ? atoi(argv[1]) : 4096, N = 6, T = 25, reps = 40;
+    pw_config cfg;
+    pw_config_default(&cfg, PW_SIMPLE_SPREAD, B, N, -1, 0);
+    cfg.auto_reset = 1;
+    pw_handle *h;
+    if (pw_create(&cfg, &h)) { printf("create: %s\n", pw_last_error()); return 1; }
+    void *state; hipMalloc(&state, pw_state_bytes(h)); hipMemset(state, 0, pw_state_bytes(h));
+    pw_bind_state(h, state);
+    const int D = pw_obs_dim(h);
+    size_t BN = (size_t)B * N;
+    int32_t *act; hipMalloc(&act, T * BN * 4);
+    std::vector<int32_t> ha(T * BN); for (auto &a : ha) a = rand() % 5;
+    hipMemcpy(act, ha.data(), T * BN * 4, hipMemcpyHostToDevice);
+    pw_step_io io = {};
+    io.act_idx = act;
+    hipMalloc((void **)&io.obs, T * BN * D * 4); hipMalloc((void **)&io.final_obs, T * BN * D * 4);
+    hipMalloc((void **)&io.rew, T * BN * 4); hipMalloc((void **)&io.rew_shared, (size_t)T * B * 4);
+    hipMalloc((void **)&io.done, T * BN); hipMalloc((void **)&io.terminal, (size_t)T * B);
+    pw_reset(h, nullptr, nullptr, nullptr);
+    unsigned long long tot[8] = {0};
+    for (int r = 0; r < reps; ++r) {
+        if (pw_rollout(h, &io, T, nullptr)) { printf("rollout: %s\n", pw_last_error()); return 1; }
+        hipDeviceSynchronize();
+        unsigned long long s[16];
+        hipMemcpyFromSymbol(s, HIP_SYMBOL(g_pw_stamps), sizeof(s));
+        if (r >= 5) for (int i = 0; i < 8; ++i) tot[i] += s[i];
+    }
+    const char *names[8] = {"action decode + prefetch issue", "near-pair force loop", "integrate + LDS exchange",
+                            "partner pass (d2, masks, min)", "reward: sqrt + 12 shuffles", "stores rew/done/.. + reset check",
+                            "obs row build + stores", "vmcnt(K) hint"};
+    double sum = 0; for (int i = 0; i < 8; ++i) sum += tot[i];
+    printf("B=%d: cycles per step (wave 0, incl. ~40/stamp overhead): %.0f\n", B, sum / ((reps - 5) * T));
+    for (int i = 0; i < 8; ++i) printf("  %-36s %7.0f cycles  %5.1f%%\n", names[i], tot[i] / (double)((reps - 5) * T), 100.0 * tot[i] / sum);
+    return 0;
+}
