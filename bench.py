@@ -128,6 +128,8 @@ def main():
             if shard is not None:
                 shard(view, acts[s:s + n])
             s += n
+        if shard is not None:
+            shard.finish()
 
     shard = None
     if world > 1:

@@ -177,6 +177,15 @@ int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b,
                      float *out_obs, float *out_act, float *out_rew, float *out_next_obs,
                      float *out_done, void *stream);
 
+/* ---- multi-GPU exchange (one rank per GPU; the collective itself is RCCL, driven by the host) ----
+ * A transition row is f32 [obs N*D | next_obs N*D | act N | rew | done], width 2*N*D + N + 2.
+ * pw_pack_transitions: row r = transition (sel_t[r] >= 1, sel_e[r]) of a T-step chunk described by
+ * io (obs[t-1] is the observation acted on; next_obs is final_obs where terminal, else obs[t]).
+ * pw_replay_add_packed: ReplayBuffer.add() of R received rows at ring positions (start + r) % capacity. */
+int pw_pack_transitions(const pw_step_io *io, int32_t B, int32_t N, int32_t D, const int32_t *sel_t,
+                        const int32_t *sel_e, int32_t R, float *rows, void *stream);
+int pw_replay_add_packed(const pw_replay_store *st, int64_t start, int32_t R, const float *rows, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

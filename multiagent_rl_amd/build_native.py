@@ -13,7 +13,6 @@ DEPS = [SRC, os.path.join(ROOT, 'include', 'pworld.h'), os.path.join(ROOT, 'incl
 # oracle bit for bit (HIP's device default is fp-contract=fast).
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared',
          '-ffp-contract=off', '-fno-fast-math', '-fhip-fp32-correctly-rounded-divide-sqrt',
-         '-fgpu-flush-denormals-to-zero' if False else '-fno-gpu-flush-denormals-to-zero' if False else '',
          '-Wall', '-Wno-unused-function', '-I', os.path.join(ROOT, 'include')]
 
 

@@ -959,6 +959,52 @@ __global__ void pw_replay_gather_kernel(const pw_replay_store st, const int64_t 
     }
 }
 
+// Transition rows for the multi-GPU exchange: [obs ND | next_obs ND | act N | rew | done], f32.
+// Row r is transition (t, e) = (sel_t[r], sel_e[r]) of a rollout chunk, t >= 1: the observation the
+// policy acted on is obs[t-1], the stored next observation is the PRE-reset one (run.py:52 vs :60).
+__global__ void pw_pack_transitions_kernel(const pw_step_io io, const int B, const int N, const int D,
+                                           const int32_t *sel_t, const int32_t *sel_e, const int R, float *rows)
+{
+    const int ND = N * D, W = 2 * ND + N + 2;
+    const size_t total = (size_t)R * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / W), c = (int)(i - (size_t)r * W);
+        const int t = sel_t[r], e = sel_e[r];
+        const size_t te = (size_t)t * B + e;
+        float v;
+        if (c < ND) {
+            v = io.obs[((size_t)(t - 1) * B + e) * ND + c];
+        } else if (c < 2 * ND) {
+            const bool fin = io.final_obs && io.terminal && io.terminal[te];
+            v = (fin ? io.final_obs : io.obs)[te * ND + (c - ND)];
+        } else if (c < 2 * ND + N) {
+            v = (float)io.act_idx[te * N + (c - 2 * ND)];
+        } else if (c == 2 * ND + N) {
+            v = io.rew_shared[te];
+        } else {
+            v = 0.0f;  // done: upstream done_callback is None
+        }
+        rows[i] = v;
+    }
+}
+
+__global__ void pw_replay_add_packed_kernel(const pw_replay_store st, const int64_t start, const int R,
+                                            const float *rows)
+{
+    const int N = st.num_agents, ND = N * st.obs_dim, W = 2 * ND + N + 2;
+    const size_t total = (size_t)R * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / W), c = (int)(i - (size_t)r * W);
+        const size_t slot = (size_t)((start + r) % st.capacity);
+        const float v = rows[i];
+        if (c < ND) st.obs[slot * ND + c] = v;
+        else if (c < 2 * ND) st.next_obs[slot * ND + (c - ND)] = v;
+        else if (c < 2 * ND + N) st.act[slot * N + (c - 2 * ND)] = (uint8_t)v;
+        else if (c == 2 * ND + N) st.rew[slot] = v;
+        else st.done[slot] = v;
+    }
+}
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -1361,6 +1407,34 @@ int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b, f
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pw_replay_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        *st, idx, b, out_obs, out_act, out_rew, out_next_obs, out_done);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_pack_transitions(const pw_step_io *io, int32_t B, int32_t N, int32_t D, const int32_t *sel_t,
+                        const int32_t *sel_e, int32_t R, float *rows, void *stream)
+{
+    if (!io || !sel_t || !sel_e || !rows) return fail(PW_EINVAL, "null argument");
+    if (!io->obs || !io->act_idx || !io->rew_shared) return fail(PW_EINVAL, "chunk needs obs, act_idx and rew_shared");
+    if (B < 1 || N < 1 || D < 1 || R < 1) return fail(PW_EINVAL, "bad sizes");
+    const size_t total = (size_t)R * (2 * (size_t)N * D + N + 2);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pw_pack_transitions_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       *io, B, N, D, sel_t, sel_e, R, rows);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_replay_add_packed(const pw_replay_store *st, int64_t start, int32_t R, const float *rows, void *stream)
+{
+    if (!st || !rows) return fail(PW_EINVAL, "null argument");
+    if (st->capacity < 1 || R < 1 || R > st->capacity || start < 0) return fail(PW_EINVAL, "bad ring arguments");
+    const size_t total = (size_t)R * (2 * (size_t)st->num_agents * st->obs_dim + st->num_agents + 2);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pw_replay_add_packed_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       *st, start, R, rows);
     PW_HIP_CHECK(hipGetLastError());
     return PW_OK;
 }

@@ -303,10 +303,10 @@ class MultiAgentEnv(object):
         a = np.stack([np.asarray(x, dtype=np.float32).reshape(5) for x in action_n])[None]
         self._sync_force_discrete()
         obs, rew, done, info = self.batched.step(torch.from_numpy(a))
-        rew_n = [float(x) for x in rew[0].cpu().numpy().astype(np.float64)]
+        rew_n = list(rew[0].cpu().numpy().astype(np.float64))  # np.float64 scalars, as upstream's reward()
         done_n = [bool(x) for x in done[0].cpu().numpy()]
         if self.shared_reward:
-            rew_n = [float(np.sum(rew_n))] * self.n
+            rew_n = [np.sum(rew_n)] * self.n
         info_n = {'n': [{} for _ in range(self.n)]}
         if self.benchmark:
             info_n = {'n': self._benchmark_data(rew_n, info['coll'][0].cpu().numpy())}

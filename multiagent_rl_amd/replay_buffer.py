@@ -1,0 +1,139 @@
+"""Device-resident replay ring with the API of ``rls/replay_buffer.py:9-91`` (ReplayBuffer).
+
+Same method names, argument meaning and ring semantics as the reference
+(``add`` overwrites at ``_next_idx`` modulo ``_maxsize``; ``make_index`` draws
+``random.randint(0, len - 1)`` from Python's global ``random`` exactly like
+``rls/replay_buffer.py:51-52``; ``sample_index`` returns
+``(obs[b,N,D], act[b,N,5], rew[b], obs'[b,N,D], done[b])`` as
+``_encode_sample`` does), but the storage is SoA tensors in HBM and the
+encode step is one HIP gather launch (``pw_replay_gather``) instead of a Python
+loop over 1024 tuples.  ``add_batch`` appends B transitions of a batched step in
+one launch (``pw_replay_add``).
+
+Deliberate deviation: the reference's ``_encode_sample`` calls
+``np.array(list, copy=False)``, which raises under NumPy >= 2;
+the intended NumPy-1 behaviour (``np.asarray``) is what is reproduced.
+Returned batches are float32 torch tensors on the device (the reference's
+trainer converts to float32 tensors right away, ddpg_gumbel_fix.py:121-127).
+"""
+import ctypes as C
+import random
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PwReplayStore, check
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class ReplayBuffer(object):
+    def __init__(self, size, num_agents=None, obs_dim=None, device=None):
+        """size: max number of transitions (``ReplayBuffer(size=1e+6)``, experiments/run.py:20).
+        Storage is allocated on the first add (when N and D are known) unless given here."""
+        self._maxsize = int(size)
+        self._next_idx = 0
+        self._len = 0
+        self._device = None if device is None else torch.device(device)
+        self._store = None
+        self._lib = None
+        self.num_agents, self.obs_dim = num_agents, obs_dim
+        if num_agents is not None and obs_dim is not None:
+            self._allocate(num_agents, obs_dim)
+
+    # -- storage
+    def _allocate(self, N, D):
+        if not torch.cuda.is_available():
+            raise _lib.PworldError('ReplayBuffer needs a GPU: libpworld has no CPU fallback')
+        self._lib = _lib.load()
+        if self._device is None:
+            self._device = torch.device('cuda', torch.cuda.current_device())
+        cap, dev = self._maxsize, self._device
+        self.num_agents, self.obs_dim = int(N), int(D)
+        self.obs = torch.empty(cap, N, D, dtype=torch.float32, device=dev)
+        self.next_obs = torch.empty(cap, N, D, dtype=torch.float32, device=dev)
+        self.act = torch.empty(cap, N, dtype=torch.uint8, device=dev)
+        self.rew = torch.empty(cap, dtype=torch.float32, device=dev)
+        self.done = torch.empty(cap, dtype=torch.float32, device=dev)
+        st = PwReplayStore()
+        st.obs, st.next_obs, st.rew, st.done = (self.obs.data_ptr(), self.next_obs.data_ptr(),
+                                                self.rew.data_ptr(), self.done.data_ptr())
+        st.act = self.act.data_ptr()
+        st.capacity, st.num_agents, st.obs_dim = cap, N, D
+        self._store = st
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+    def __len__(self):
+        return self._len
+
+    def clear(self):
+        self._next_idx = 0
+        self._len = 0
+
+    # -- rls/replay_buffer.py:30-37
+    def add(self, obs_t, action, reward, obs_tp1, done):
+        """One transition in the reference's host format: lists of N arrays (D,), list of N
+        one-hot (5,) arrays, float, lists of N arrays, float."""
+        obs = torch.as_tensor(np.stack([np.asarray(o, dtype=np.float32) for o in obs_t]))[None]
+        nxt = torch.as_tensor(np.stack([np.asarray(o, dtype=np.float32) for o in obs_tp1]))[None]
+        act = torch.as_tensor(np.stack([np.asarray(a) for a in action]).argmax(-1).astype(np.int32))[None]
+        self.add_batch(obs, act, torch.tensor([float(reward)]), nxt, done=torch.tensor([float(done)]))
+
+    def add_batch(self, obs, act_idx, rew_shared, next_obs, final_obs=None, terminal=None, done=None):
+        """B transitions of one batched step: obs/next_obs [B,N,D], act_idx [B,N] int, rew_shared [B].
+        Where ``terminal[b]`` is set, next_obs is taken from ``final_obs`` (the pre-reset
+        observation: the reference stores new_obs_n BEFORE env.reset(), run.py:52 vs :60)."""
+        B, N, D = obs.shape
+        if self._store is None:
+            self._device = obs.device if obs.is_cuda and self._device is None else self._device
+            self._allocate(N, D)
+        assert (N, D) == (self.num_agents, self.obs_dim) and B <= self._maxsize
+        dev = self._device
+        f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        obs, next_obs, final_obs = f32(obs), f32(next_obs), f32(final_obs)
+        rew_shared, done = f32(rew_shared), f32(done)
+        act_idx = act_idx.to(device=dev, dtype=torch.int32).contiguous()
+        term = None if terminal is None else terminal.to(device=dev).contiguous().view(torch.uint8)
+        check(self._lib.pw_replay_add(C.byref(self._store), self._next_idx, B, _ptr(obs), _ptr(act_idx),
+                                      _ptr(rew_shared), _ptr(next_obs), _ptr(final_obs), _ptr(term), _ptr(done),
+                                      self._stream()))
+        self._next_idx = (self._next_idx + B) % self._maxsize
+        self._len = min(self._len + B, self._maxsize)
+
+    # -- rls/replay_buffer.py:51-57
+    def make_index(self, batch_size):
+        return [random.randint(0, self._len - 1) for _ in range(batch_size)]
+
+    def make_latest_index(self, batch_size):
+        idx = [(self._next_idx - 1 - i) % self._maxsize for i in range(batch_size)]
+        np.random.shuffle(idx)
+        return idx
+
+    # -- rls/replay_buffer.py:39-49, 59-60
+    def _encode_sample(self, idxes):
+        idx = torch.as_tensor(list(idxes) if not torch.is_tensor(idxes) else idxes, dtype=torch.int64,
+                              device=self._device).contiguous()
+        b, N, D, dev = idx.numel(), self.num_agents, self.obs_dim, self._device
+        out = (torch.empty(b, N, D, device=dev), torch.empty(b, N, 5, device=dev), torch.empty(b, device=dev),
+               torch.empty(b, N, D, device=dev), torch.empty(b, device=dev))
+        check(self._lib.pw_replay_gather(C.byref(self._store), _ptr(idx), b, _ptr(out[0]), _ptr(out[1]),
+                                         _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), self._stream()))
+        return out
+
+    def sample_index(self, idxes):
+        return self._encode_sample(idxes)
+
+    def sample(self, batch_size):
+        if batch_size > 0:
+            idxes = self.make_index(batch_size)
+        else:
+            idxes = range(0, self._len)
+        return self._encode_sample(idxes)
+
+    def collect(self):
+        return self.sample(-1)

@@ -1,0 +1,102 @@
+"""CPU: libpworld.so loads and exports every symbol include/pworld.h declares; host-side argument
+checking of the C ABI (no compute launches without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from multiagent_rl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'pworld.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(pw_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), 'libpworld.so lacks %s declared in include/pworld.h' % n
+    assert set(names) == set(_lib.SIGNATURES), 'ctypes table and header disagree: %s' % (
+        set(names) ^ set(_lib.SIGNATURES))
+    assert lib.pw_version() == 100
+
+
+def test_config_default_matches_canonical_constants():
+    lib = _lib.load()
+    cfg = _lib.PwConfig()
+    assert lib.pw_config_default(C.byref(cfg), _lib.PW_SIMPLE_SPREAD, 4096, 6, -1, 0) == 0
+    assert cfg.struct_size == C.sizeof(_lib.PwConfig)
+    assert (cfg.num_agents, cfg.num_landmarks, cfg.max_episode_len, cfg.seed) == (6, 6, 25, 12345678)
+    assert abs(cfg.dt - 0.1) < 1e-7 and cfg.damping == 0.25 and cfg.contact_force == 100.0
+    assert abs(cfg.contact_margin - 1e-3) < 1e-9 and cfg.default_sensitivity == 5.0
+    assert abs(cfg.agent_size[0] - 0.15) < 1e-7 and cfg.agent_accel[0] < 0 and cfg.landmark_collide == 0
+    assert lib.pw_config_default(C.byref(cfg), _lib.PW_SIMPLE_TAG, 8192, 6, -1, 4) == 0
+    assert (cfg.num_landmarks, cfg.num_adversaries, cfg.landmark_collide) == (2, 4, 1)
+    assert abs(cfg.agent_size[0] - 0.075) < 1e-7 and abs(cfg.agent_size[5] - 0.05) < 1e-7
+    assert (cfg.agent_accel[0], cfg.agent_accel[5]) == (3.0, 4.0)
+    assert abs(cfg.agent_max_speed[5] - 1.3) < 1e-6 and abs(cfg.landmark_size - 0.2) < 1e-7
+
+
+def test_handle_geometry_and_errors():
+    lib = _lib.load()
+    cfg = _lib.PwConfig()
+    lib.pw_config_default(C.byref(cfg), _lib.PW_SIMPLE_SPREAD, 4096, 6, -1, 0)
+    h = C.c_void_p()
+    assert lib.pw_create(C.byref(cfg), C.byref(h)) == 0
+    assert lib.pw_obs_dim(h) == 16
+    assert lib.pw_algorithmic_bytes_per_env_step(h) == 678          # 57N + 8L + 8NL
+    lay = _lib.PwStateLayout()
+    assert lib.pw_get_state_layout(h, C.byref(lay)) == 0
+    assert lay.total_bytes == lib.pw_state_bytes(h) and lay.pos_y - lay.pos_x >= 4096 * 6 * 4
+    assert all(getattr(lay, f) % 256 == 0 for f, _ in lay._fields_)
+    # stepping before a state block is bound is an error, not a crash
+    io = _lib.PwStepIO()
+    assert lib.pw_step(h, C.byref(io), None) == -2 and b'not bound' in lib.pw_last_error()
+    assert lib.pw_bind_state(h, C.c_void_p(0x1001)) == -1 and b'aligned' in lib.pw_last_error()
+    lib.pw_destroy(h)
+    for n, want in [(3, 267), (12, 1932), (24, 6168), (48, 21552)]:
+        lib.pw_config_default(C.byref(cfg), _lib.PW_SIMPLE_SPREAD, 4096, n, -1, 0)
+        assert lib.pw_create(C.byref(cfg), C.byref(h)) == 0
+        assert lib.pw_algorithmic_bytes_per_env_step(h) == want
+        lib.pw_destroy(h)
+    # bad configurations
+    lib.pw_config_default(C.byref(cfg), _lib.PW_SIMPLE_SPREAD, 16, 6, -1, 0)
+    cfg.num_agents = 65
+    assert lib.pw_create(C.byref(cfg), C.byref(h)) == -1 and b'num_agents' in lib.pw_last_error()
+    cfg.num_agents, cfg.struct_size = 6, 12
+    assert lib.pw_create(C.byref(cfg), C.byref(h)) == -1 and b'struct_size' in lib.pw_last_error()
+    assert lib.pw_config_default(C.byref(cfg), 7, 16, 6, -1, 0) == -1 and b'scenario' in lib.pw_last_error()
+
+
+def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):
+    import torch
+    from multiagent_rl_amd.env import BatchedParticleEnv
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.PworldError, match='no CPU fallback'):
+            BatchedParticleEnv('simple_spread', 4, num_agents=3)
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'libpworld.so'))
+    with pytest.raises(_lib.PworldError, match='HIP extension is required'):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    """The product path may not import, link or execute anything under oracle/."""
+    pat = re.compile(r'(^|\n)\s*(from|import)\s+oracle\b|oracle[/\\.]c_oracle|libpworld_oracle|particle_oracle|'
+                     r'pworld_oracle|["\']oracle["\']')
+    pkg = os.path.join(ROOT, 'multiagent_rl_amd')
+    seen = 0
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                seen += 1
+                m = pat.search(open(os.path.join(d, f)).read())
+                assert m is None, '%s references the oracle (%r): the product must not depend on it' % (f, m.group(0))
+    assert seen >= 8

@@ -1,0 +1,214 @@
+"""GPU: the pieces either side of the step kernels -- device replay ring, transition packing,
+the B = 1 MultiAgentEnv drop-in, the reference-shaped run() loop on the HIP env, BatchedRollout."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+from oracle import particle_oracle as po  # noqa: E402  (checker only)
+from tests.trace_util import RecordingEnv, RecordingMemory, StubTrainer  # noqa: E402
+
+GOLD_DIR = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_replay_buffer_matches_reference_semantics():
+    """tests/golden/replay_buffer.json was produced by rls.replay_buffer.ReplayBuffer itself."""
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    g = json.load(open(os.path.join(GOLD_DIR, 'replay_buffer.json')))
+    rb = ReplayBuffer(g['size'])
+    for tr in g['transitions']:
+        rb.add([np.array(o) for o in tr['obs']], [np.array(a) for a in tr['act']], tr['rew'],
+               [np.array(o) for o in tr['next_obs']], tr['done'])
+    assert len(rb) == g['len'] and rb._next_idx == g['next_idx']
+    np.testing.assert_allclose(rb.rew.cpu().numpy(), g['storage_rewards'], rtol=1e-6)   # ring overwrite order
+    random.seed(0)
+    idx = rb.make_index(4)
+    assert idx == g['make_index_seed0']
+    enc = rb.sample_index(idx)
+    assert [list(e.shape) for e in enc] == g['encode_shapes']
+    for got, want in zip(enc, g['encode']):
+        np.testing.assert_allclose(got.cpu().numpy(), np.asarray(want), rtol=1e-6, atol=1e-6)
+    big = ReplayBuffer(1e6, 3, 10)
+    big._len = 8
+    random.seed(0)
+    assert big.make_index(4) == g['make_index_seed0_len8_batch4'] == [6, 6, 0, 4]
+    allb = rb.collect()
+    assert allb[0].shape[0] == 5
+
+
+def test_add_batch_ring_and_pre_reset_next_obs():
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    rb = ReplayBuffer(10, 2, 6)
+    rng = np.random.RandomState(0)
+    log = []
+    for k in range(4):
+        B = 4
+        obs, nxt, fin = (torch.from_numpy(rng.randn(B, 2, 6).astype(np.float32)) for _ in range(3))
+        act = torch.from_numpy(rng.randint(0, 5, (B, 2)).astype(np.int32))
+        rew = torch.from_numpy(rng.randn(B).astype(np.float32))
+        term = torch.tensor([False, True, False, True])
+        rb.add_batch(obs.cuda(), act.cuda(), rew.cuda(), nxt.cuda(), fin.cuda(), term.cuda())
+        for b in range(B):
+            log.append((obs[b], act[b], rew[b], fin[b] if term[b] else nxt[b]))
+    assert len(rb) == 10 and rb._next_idx == 16 % 10
+    o, a, r, n, d = rb.sample_index(list(range(10)))
+    for slot in range(10):
+        src = log[slot + 10] if slot < 6 else log[slot]     # slots 0..5 were overwritten by transitions 10..15
+        assert torch.equal(o[slot].cpu(), src[0]) and torch.equal(n[slot].cpu(), src[3])
+        assert torch.equal(a[slot].cpu().argmax(-1).int(), src[1]) and r[slot].item() == src[2].item()
+        assert (a[slot].sum(-1) == 1).all() and d[slot].item() == 0.0
+
+
+def test_pack_transitions_and_packed_ingest():
+    from tests.test_dist_gloo import pack_reference
+    from multiagent_rl_amd.dist import SampledTransitionGather
+    from multiagent_rl_amd.env import BatchedParticleEnv
+    env = BatchedParticleEnv('simple_spread', 64, num_agents=3, max_episode_len=5, auto_reset=True)
+    env.reset()
+    T = 12
+    acts = torch.randint(0, 5, (T, 64, 3), device='cuda', dtype=torch.int32)
+    out = env.rollout(acts)
+    gat = SampledTransitionGather.__new__(SampledTransitionGather)   # single process: no process group needed
+    gat.rank, gat.world, gat.device, gat.B, gat.N, gat.D = 0, 1, torch.device('cuda', 0), 64, 3, env.obs_dim
+    gat.R, gat._sel, gat._seed = 40, {}, 1
+    sel_t, sel_e = gat._selection(T)
+    rows = torch.zeros(40, 2 * 3 * env.obs_dim + 3 + 2, device='cuda')
+    gat._pack(out, acts, sel_t, sel_e, rows)
+    cpu = {k: v.cpu() for k, v in out.items()}
+    want = pack_reference(cpu, acts.cpu(), sel_t.cpu(), sel_e.cpu())
+    assert torch.equal(rows.cpu(), want)
+    assert cpu['terminal'][sel_t.cpu().long(), sel_e.cpu().long()].any()   # some rows used final_obs
+    gat.memory = gat._make_memory()
+    gat._ingest(rows)
+    gat._ingest(rows[:7])
+    m = gat.memory
+    assert len(m) == 47 and m._next_idx == 47
+    o, a, r, n, d = m.sample_index(list(range(40)))
+    nd = 3 * env.obs_dim
+    assert torch.equal(o.reshape(40, -1).cpu(), want[:, :nd]) and torch.equal(n.reshape(40, -1).cpu(), want[:, nd:2 * nd])
+    assert torch.equal(a.argmax(-1).float().cpu(), want[:, 2 * nd:2 * nd + 3]) and torch.equal(r.cpu(), want[:, -2])
+
+
+def _drive_pair(scenario, steps, seed, **kw):
+    """The HIP MultiAgentEnv and the float64 scalar oracle env under the same NumPy seed and actions."""
+    from multiagent_rl_amd import make_env
+    np.random.seed(seed)
+    gpu = make_env(scenario, **kw)
+    np.random.seed(seed)
+    ref = po.make_oracle_env(scenario, **kw)
+    np.random.seed(seed)
+    o_gpu = gpu.reset()
+    np.random.seed(seed)
+    o_ref = ref.reset()
+    rng = np.random.RandomState(1)
+    worst = 0.0
+    for t in range(steps):
+        for a, b in zip(o_gpu, o_ref):
+            assert a.shape == b.shape and a.dtype == np.float64
+            worst = max(worst, float(np.abs(a - b).max()))
+        idx = rng.randint(0, 5, gpu.n)
+        acts = [np.eye(5)[i] for i in idx]
+        o_gpu, r_gpu, d_gpu, i_gpu = gpu.step([a.copy() for a in acts])
+        o_ref, r_ref, d_ref, i_ref = ref.step([a.copy() for a in acts])
+        assert d_gpu == d_ref == [False] * gpu.n and i_gpu == i_ref == {'n': [{}] * gpu.n}
+        assert all(isinstance(r, float) for r in r_gpu)
+        np.testing.assert_allclose(r_gpu, r_ref, atol=2e-4)
+    return gpu, ref, worst
+
+
+def test_multiagentenv_dropin_tracks_float64_oracle():
+    """configs[0]: simple_spread, 3 agents, 1 env, seed protocol of main.py:41-49."""
+    gpu, ref, worst = _drive_pair('simple_spread', 25, 12345678)
+    assert gpu.n == 3 and gpu.observation_space[0].shape == (10,) and gpu.action_space[0].n == 5
+    assert not hasattr(gpu.action_space[0], 'high')
+    assert worst < 1e-4   # float32 trajectory vs float64 over an episode (per-step bound is 1e-5, see parity tests)
+    gpu6, _, worst6 = _drive_pair('simple_spread', 25, 12345679, n=6)
+    assert gpu6.observation_space[0].shape == (16,) and worst6 < 1e-4
+    tag, _, worst_t = _drive_pair('simple_tag', 25, 5)
+    assert [s.shape[0] for s in tag.observation_space] == [16, 16, 16, 14] and worst_t < 1e-4
+
+
+def test_reset_matches_numpy_legacy_stream_kat():
+    from multiagent_rl_amd import make_env
+    env = make_env('simple_spread')
+    np.random.seed(12345678)
+    obs = env.reset()
+    # SURVEY.md 8(c) KAT-reset, rounded to float32 by the upload
+    want_pos0 = np.float32([-0.5083915323501949, 0.19285721064295336])
+    want_lm0 = np.float32([-0.22413133239983196, 0.3610820860587127])
+    np.testing.assert_array_equal(obs[0][2:4].astype(np.float32), want_pos0)
+    np.testing.assert_array_equal(obs[0][4:6].astype(np.float32), want_lm0 - want_pos0)
+    assert not obs[0][:2].any()
+
+
+def test_benchmark_info_and_full_observation():
+    from multiagent_rl_amd import make_env
+    np.random.seed(3)
+    env = make_env('simple_spread', benchmark=True, local_observation=False)
+    np.random.seed(3)
+    ref = po.make_oracle_env('simple_spread', benchmark=True, local_observation=False)
+    np.random.seed(3); env.reset()
+    np.random.seed(3); ref.reset()
+    assert env.observation_space[0].shape == (18,)
+    a = [np.eye(5)[1] for _ in range(3)]
+    _, _, _, info = env.step([x.copy() for x in a])
+    _, _, _, info_ref = ref.step([x.copy() for x in a])
+    for got, want in zip(info['n'], info_ref['n']):
+        assert got[1] == want[1] and got[3] == want[3]
+        np.testing.assert_allclose([got[0], got[2]], [want[0], want[2]], atol=1e-4)
+
+
+def test_run_loop_on_hip_env_has_reference_call_shape(tmp_path):
+    """rollout.run (mirror of experiments/run.py) on the HIP MultiAgentEnv: same event kinds, shapes and
+    dtypes as the golden reference trace; values agree with the float64 oracle run to float32 accuracy."""
+    from multiagent_rl_amd import make_env, rollout
+    gold = json.load(open(os.path.join(GOLD_DIR, 'run_trace.json')))
+
+    class Args(object):
+        is_training, display = True, False
+    for k, v in gold['arglist'].items():
+        setattr(Args, k, v)
+    np.random.seed(12345678)
+    env = RecordingEnv(make_env('simple_spread'))
+    np.random.seed(12345678)
+    StubTrainer.trace = env.trace
+    hist = rollout.run(env, None, None, StubTrainer, 'simple_spread', 'Discrete', cnt=0, arglist=Args,
+                       memory=RecordingMemory(), out_dir=str(tmp_path), log=lambda *a: None)
+
+    def skeleton(x):
+        if isinstance(x, dict):
+            return {k: skeleton(v) for k, v in x.items() if k not in ('sum', 'value')}
+        if isinstance(x, list):
+            return [skeleton(v) for v in x]
+        return x
+    assert skeleton(json.loads(json.dumps(env.trace))) == skeleton(gold['trace'])
+    np.testing.assert_allclose(hist['reward_episodes'], gold['reward_episodes'], rtol=1e-4, atol=1e-3)
+
+
+def test_batched_rollout_feeds_replay():
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, GumbelPolicy
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    from multiagent_rl_amd.rollout import BatchedRollout
+    torch.manual_seed(0)
+    env = make_batched_env('simple_spread', 256, n=6, auto_reset=True, max_episode_len=25)
+    actor = ActorNetwork(env.obs_dim, 5).cuda()
+    mem = ReplayBuffer(256 * 30, 6, env.obs_dim)
+    ro = BatchedRollout(env, GumbelPolicy(actor), mem)
+    first_obs = ro.obs.clone()
+    ro.collect(27)
+    st = ro.stats()
+    assert st['env_steps'] == 27 * 256 and st['episodes'] == 256 and len(mem) == 27 * 256
+    assert -2000 < st['mean_episode_reward'] < -100      # ~ 6 agents x 25 steps x -(sum of 6 min-dists + 1)
+    o, a, r, n, d = mem.sample_index(list(range(256)))          # the first batched step's transitions
+    assert torch.equal(o, first_obs) and (a.sum(-1) == 1).all() and not d.any()
+    # transition 24 (the terminal step) stores the PRE-reset next_obs: velocities are non-zero there
+    o24, _, _, n24, _ = mem.sample_index(list(range(24 * 256, 25 * 256)))
+    assert n24[:, :, :2].abs().sum() > 0
+    o25, _, _, _, _ = mem.sample_index(list(range(25 * 256, 26 * 256)))
+    assert o25[:, :, :2].abs().sum() == 0                        # first obs of the next episode: at rest
