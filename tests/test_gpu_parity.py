@@ -78,15 +78,19 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=['stream', 'fast', 'generic'])
+@pytest.fixture(params=['duo', 'stream', 'fast', 'generic'])
 def kernel_path(request, monkeypatch):
-    """Three kernels serve simple_spread with homogeneous agents; all must give the same bits.
-    'stream'  pw_spread_stream_kernel (all standard outputs, no collision-mask output),
+    """Four kernels serve simple_spread with homogeneous agents; all must give the same bits.
+    'duo'     pw_spread_duo_kernel    (default when all standard outputs are present, no coll output),
+    'stream'  pw_spread_stream_kernel (PWORLD_NO_DUO),
     'fast'    pw_spread_fast_kernel   (PWORLD_NO_STREAM, or when coll is requested),
     'generic' pw_rollout_kernel       (PWORLD_FORCE_GENERIC, read by pw_create).
     Other scenarios always take the generic kernel."""
     monkeypatch.delenv('PWORLD_FORCE_GENERIC', raising=False)
     monkeypatch.delenv('PWORLD_NO_STREAM', raising=False)
+    monkeypatch.delenv('PWORLD_NO_DUO', raising=False)
+    if request.param == 'stream':
+        monkeypatch.setenv('PWORLD_NO_DUO', '1')
     if request.param == 'generic':
         monkeypatch.setenv('PWORLD_FORCE_GENERIC', '1')
     elif request.param == 'fast':
@@ -97,7 +101,7 @@ def kernel_path(request, monkeypatch):
 @pytest.mark.parametrize('case', CASES, ids=lambda c: '%s-N%d-L%s-B%d-%s' % (
     c['scenario'], c['num_agents'], c.get('num_landmarks'), c['num_envs'], c.get('obs_mode', 'local')))
 def test_single_step_from_injected_states(case, kernel_path):
-    env, cfg = _mk(max_episode_len=0, want_coll=kernel_path != 'stream', **case)
+    env, cfg = _mk(max_episode_len=0, want_coll=kernel_path not in ('stream', 'duo'), **case)
     B, N, L = env.num_envs, env.n, env.num_landmarks
     rng = np.random.RandomState(B * 131 + N)
     pos, vel, lm = _rand_state(rng, B, N, L)
@@ -146,7 +150,7 @@ def test_single_step_from_injected_states(case, kernel_path):
 def test_rollout_with_auto_reset_matches_oracle_bitwise(case, kernel_path):
     T, ep_len = 58, 25
     env, cfg = _mk(max_episode_len=ep_len, auto_reset=True, seed=99, env_id_base=1 << 33,
-                   want_coll=kernel_path != 'stream', **case)
+                   want_coll=kernel_path not in ('stream', 'duo'), **case)
     B, N = env.num_envs, env.n
     rng = np.random.RandomState(5)
     acts = rng.randint(0, 5, (T, B, N)).astype(np.int32)
@@ -198,7 +202,7 @@ def test_rollout_equals_repeated_steps_and_onehot_equals_index():
 
 def test_soft_actions_without_force_discrete(kernel_path):
     env, cfg = _mk(num_agents=3, num_envs=50, max_episode_len=0, force_discrete_action=False,
-                   want_coll=kernel_path != 'stream')
+                   want_coll=kernel_path not in ('stream', 'duo'))
     rng = np.random.RandomState(2)
     pos, vel, lm = _rand_state(rng, 50, 3, 3)
     soft = rng.uniform(0, 1, (50, 3, 5)).astype(np.float32)
@@ -232,7 +236,7 @@ def test_masked_reset_and_shard_invariance():
 
 
 def test_coincident_agents_propagate_nan_like_upstream(kernel_path):
-    env, cfg = _mk(num_agents=3, num_envs=2, max_episode_len=0, want_coll=kernel_path != 'stream')
+    env, cfg = _mk(num_agents=3, num_envs=2, max_episode_len=0, want_coll=kernel_path not in ('stream', 'duo'))
     pos = np.array([[[0.1, 0.1], [0.1, 0.1], [0.7, 0.7]], [[0, 0], [0.5, 0.5], [-0.5, 0.5]]], np.float32)
     lm = np.zeros((2, 3, 2), np.float32)
     env.set_state(pos, None, lm)

@@ -26,19 +26,30 @@ int main(int argc, char **argv)
     hipMalloc((void **)&io.rew, T * BN * 4); hipMalloc((void **)&io.rew_shared, (size_t)T * B * 4);
     hipMalloc((void **)&io.done, T * BN); hipMalloc((void **)&io.terminal, (size_t)T * B);
     pw_reset(h, nullptr, nullptr, nullptr);
-    unsigned long long tot[8] = {0};
+    unsigned long long tot[16] = {0};
     for (int r = 0; r < reps; ++r) {
         if (pw_rollout(h, &io, T, nullptr)) { printf("rollout: %s\n", pw_last_error()); return 1; }
         hipDeviceSynchronize();
         unsigned long long s[16];
         hipMemcpyFromSymbol(s, HIP_SYMBOL(g_pw_stamps), sizeof(s));
-        if (r >= 5) for (int i = 0; i < 8; ++i) tot[i] += s[i];
+        if (r >= 5) for (int i = 0; i < 16; ++i) tot[i] += s[i];
     }
-    const char *names[8] = {"action decode + prefetch issue", "near-pair force loop", "integrate + LDS exchange",
+    const bool duo = !getenv("PWORLD_NO_DUO");
+    const char *names_duo[8] = {"P: action decode + prefetch", "P: near-pair force loop", "P: integrate + publish slot",
+                                "P: barrier wait (O behind?)", "P: near-mask pass", "-", "-", "-"};
+    const char *names_stream[8] = {"action decode + prefetch issue", "near-pair force loop", "integrate + LDS exchange",
                             "partner pass (d2, masks, min)", "reward: sqrt + 12 shuffles", "stores rew/done/.. + reset check",
                             "obs row build + stores", "vmcnt(K) hint"};
+    const char **names = duo ? names_duo : names_stream;
     double sum = 0; for (int i = 0; i < 8; ++i) sum += tot[i];
     printf("B=%d: cycles per step (wave 0, incl. ~40/stamp overhead): %.0f\n", B, sum / ((reps - 5) * T));
     for (int i = 0; i < 8; ++i) printf("  %-36s %7.0f cycles  %5.1f%%\n", names[i], tot[i] / (double)((reps - 5) * T), 100.0 * tot[i] / sum);
+    if (duo) {
+        const char *on[4] = {"O: barrier wait (P behind)", "O: partner pass + reward + LDS exchanges",
+                             "O: stores + reset check + obs rows", "O: vmcnt(K) hint"};
+        double so = 0; for (int i = 8; i < 12; ++i) so += tot[i];
+        printf("wave O: cycles per step %.0f\n", so / ((reps - 5) * T));
+        for (int i = 0; i < 4; ++i) printf("  %-44s %7.0f cycles  %5.1f%%\n", on[i], tot[8 + i] / (double)((reps - 5) * T), 100.0 * tot[8 + i] / so);
+    }
     return 0;
 }
