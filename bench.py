@@ -83,7 +83,11 @@ def main():
     ap.add_argument('--scenario', default='simple_spread')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--batch-size', type=int, default=1024, help='replay minibatch gathered per chunk (N > 1)')
+    ap.add_argument('--batch-size', type=int, default=1024, help='replay rows gathered per exchange (N > 1)')
+    ap.add_argument('--exchange-steps', type=int, default=500,
+                    help='batched steps between RCCL exchanges of --batch-size sampled rows.  500 steps = ~0.6 ms: '
+                         '~1700 fresh minibatches/s at the root, an order of magnitude above what one learner '
+                         '(optimize() on 1024 transitions, ddpg_gumbel_fix.py:131) can consume')
     args = ap.parse_args()
 
     import torch
@@ -98,8 +102,11 @@ def main():
                          (args.gpus, args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+    use_dist = world > 1 or bool(os.environ.get('PW_BENCH_FORCE_DIST'))  # the latter: 1-rank RCCL rehearsal
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     B, N, K, W, T = args.envs, args.agents, args.steps, args.warmup, max(1, args.chunk)
     kw = dict(num_agents=N) if args.scenario == 'simple_spread' else dict(num_adversaries=4, num_good=2)
@@ -126,6 +133,8 @@ def main():
             s += n
         return plans
 
+    exchange_state = {'error': None}
+
     def run(plans, events=None, shard=None):
         # ONE HIP-event pair brackets all launches of the timed region on the launch stream (a pair per
         # launch would put two extra packets between dependent kernels and slow what it measures)
@@ -133,41 +142,51 @@ def main():
             events[0].record()
         for launch, view, a in plans:
             launch()
-            if shard is not None:
-                shard(view, a)
+            if shard is not None and exchange_state['error'] is None:
+                try:
+                    shard(view, a)
+                except Exception as e:  # keep the sharded rollout measurable; the JSON line reports this
+                    exchange_state['error'] = repr(e)[:200]
         if events is not None:
             events[1].record()
-        if shard is not None:
-            shard.finish()
+        if shard is not None and exchange_state['error'] is None:
+            try:
+                shard.finish()
+            except Exception as e:
+                exchange_state['error'] = repr(e)[:200]
 
     shard = None
-    if world > 1:
+    if use_dist:
         from multiagent_rl_amd.dist import SampledTransitionGather
-        shard = SampledTransitionGather(env, args.batch_size, rank, world, dev)
+        # one exchange per update_rate (100) env-steps, the learner's cadence (rls/arglist.py:18)
+        shard = SampledTransitionGather(env, args.batch_size, rank, world, dev, every=max(1, args.exchange_steps // T))
 
     env.reset()
     if W > 0:
         wa, wo = alloc(W)
-        run(plan(wa, wo, make_chunks(W)), shard=shard)
-        del wa, wo
+        wplans = plan(wa, wo, make_chunks(W))
+        run(wplans, shard=shard)
+        if shard is not None:
+            shard.prime(wplans[0][1], wplans[0][2])
+        del wa, wo, wplans
     acts, outs = alloc(K)
     chunks = make_chunks(K)
     plans = plan(acts, outs, chunks)
     events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(plans, events, shard)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -208,6 +227,10 @@ def main():
                                    'auto-reset, uniform int32 action indices, %d steps per pw_rollout launch'
                                    % (args.scenario, N, env.num_landmarks, B, world * B, D, T),
                        'global_batch': world * B, 'parallelism': 'env-shard x%d' % world,
+                       'exchange': None if shard is None else dict(
+                           kind='RCCL all_gather of %d sampled transition rows per rank every %d steps into the root replay ring'
+                                % (shard.R, shard.every * T), exchanges=shard.exchanges,
+                           rows_ingested_root=shard.rows_ingested, error=exchange_state['error']),
                        'outputs_finite': finite},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_src,
@@ -221,7 +244,7 @@ def main():
         elif world == 1:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -185,6 +185,11 @@ int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b,
 int pw_pack_transitions(const pw_step_io *io, int32_t B, int32_t N, int32_t D, const int32_t *sel_t,
                         const int32_t *sel_e, int32_t R, float *rows, void *stream);
 int pw_replay_add_packed(const pw_replay_store *st, int64_t start, int32_t R, const float *rows, void *stream);
+/* Both of the above in ONE launch (either half may be disabled: st/rows_in NULL or io/rows_out NULL):
+ * append the R_in rows of the previous collective to the ring, pack R_out rows of this chunk for the next. */
+int pw_exchange(const pw_replay_store *st, int64_t start, int32_t R_in, const float *rows_in, const pw_step_io *io,
+                int32_t B, int32_t N, int32_t D, const int32_t *sel_t, const int32_t *sel_e, int32_t R_out,
+                float *rows_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,8 @@ SIGNATURES = {
     'pw_pack_transitions': (C.c_int, [C.POINTER(PwStepIO), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_void_p]),
     'pw_replay_add_packed': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pw_exchange': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.c_int32, C.c_void_p, C.POINTER(PwStepIO), C.c_int32,
+                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'pw_replay_gather': (C.c_int, [C.POINTER(PwReplayStore), C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_void_p]),
 }
 

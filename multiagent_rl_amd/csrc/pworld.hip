@@ -1277,6 +1277,51 @@ __global__ void pw_replay_add_packed_kernel(const pw_replay_store st, const int6
     }
 }
 
+// One launch per exchange: blocks [0, nb_in) append the rows received by the PREVIOUS collective to the
+// ring, blocks [nb_in, ...) pack this chunk's sampled transitions for the NEXT one (two tiny dependent
+// launches would cost more in launch gaps than in work).
+__global__ void pw_exchange_kernel(const pw_replay_store st, const int64_t start, const int R_in, const float *rows_in,
+                                   const int nb_in, const pw_step_io io, const int B, const int N, const int D,
+                                   const int32_t *sel_t, const int32_t *sel_e, const int R_out, float *rows_out)
+{
+    const int ND = N * D, W = 2 * ND + N + 2;
+    if ((int)blockIdx.x < nb_in) {
+        const size_t total = (size_t)R_in * W;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)nb_in * blockDim.x) {
+            const int r = (int)(i / W), c = (int)(i - (size_t)r * W);
+            const size_t slot = (size_t)((start + r) % st.capacity);
+            const float v = rows_in[i];
+            if (c < ND) st.obs[slot * ND + c] = v;
+            else if (c < 2 * ND) st.next_obs[slot * ND + (c - ND)] = v;
+            else if (c < 2 * ND + N) st.act[slot * N + (c - 2 * ND)] = (uint8_t)v;
+            else if (c == 2 * ND + N) st.rew[slot] = v;
+            else st.done[slot] = v;
+        }
+        return;
+    }
+    const int nb_out = gridDim.x - nb_in;
+    const size_t total = (size_t)R_out * W;
+    for (size_t i = (size_t)(blockIdx.x - nb_in) * blockDim.x + threadIdx.x; i < total; i += (size_t)nb_out * blockDim.x) {
+        const int r = (int)(i / W), c = (int)(i - (size_t)r * W);
+        const int t = sel_t[r], e = sel_e[r];
+        const size_t te = (size_t)t * B + e;
+        float v;
+        if (c < ND) {
+            v = io.obs[((size_t)(t - 1) * B + e) * ND + c];
+        } else if (c < 2 * ND) {
+            const bool fin = io.final_obs && io.terminal && io.terminal[te];
+            v = (fin ? io.final_obs : io.obs)[te * ND + (c - ND)];
+        } else if (c < 2 * ND + N) {
+            v = (float)io.act_idx[te * N + (c - 2 * ND)];
+        } else if (c == 2 * ND + N) {
+            v = io.rew_shared[te];
+        } else {
+            v = 0.0f;
+        }
+        rows_out[i] = v;
+    }
+}
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -1732,6 +1777,32 @@ int pw_replay_add_packed(const pw_replay_store *st, int64_t start, int32_t R, co
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pw_replay_add_packed_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        *st, start, R, rows);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_exchange(const pw_replay_store *st, int64_t start, int32_t R_in, const float *rows_in, const pw_step_io *io,
+                int32_t B, int32_t N, int32_t D, const int32_t *sel_t, const int32_t *sel_e, int32_t R_out,
+                float *rows_out, void *stream)
+{
+    const bool ingest = st && rows_in && R_in > 0;
+    const bool pack = io && rows_out && R_out > 0;
+    if (!ingest && !pack) return fail(PW_EINVAL, "nothing to do");
+    if (ingest && (st->capacity < 1 || R_in > st->capacity || start < 0)) return fail(PW_EINVAL, "bad ring arguments");
+    if (pack && (!sel_t || !sel_e || !io->obs || !io->act_idx || !io->rew_shared || B < 1 || N < 1 || D < 1))
+        return fail(PW_EINVAL, "chunk needs obs, act_idx, rew_shared and a selection");
+    if (ingest && pack && (st->num_agents != N || st->obs_dim != D)) return fail(PW_EINVAL, "row width mismatch");
+    const int Nn = pack ? N : st->num_agents, Dd = pack ? D : st->obs_dim;
+    const size_t W = 2 * (size_t)Nn * Dd + Nn + 2;
+    auto blocks_for = [&](int R) { size_t b = ((size_t)R * W + 255) / 256; return (int)(b > 2048 ? 2048 : b); };
+    const int nb_in = ingest ? blocks_for(R_in) : 0, nb_out = pack ? blocks_for(R_out) : 0;
+    pw_replay_store dummy_st;
+    std::memset(&dummy_st, 0, sizeof(dummy_st));
+    pw_step_io dummy_io;
+    std::memset(&dummy_io, 0, sizeof(dummy_io));
+    hipLaunchKernelGGL(pw_exchange_kernel, dim3((unsigned)(nb_in + nb_out)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       ingest ? *st : dummy_st, start, ingest ? R_in : 0, rows_in, nb_in, pack ? *io : dummy_io, B, Nn, Dd,
+                       sel_t, sel_e, pack ? R_out : 0, rows_out);
     PW_HIP_CHECK(hipGetLastError());
     return PW_OK;
 }

@@ -10,8 +10,9 @@ ONE learner (experiments/run.py:20-21) that draws ``batch_size`` (1024) transiti
 ``SampledTransitionGather`` is that exchange, sized for xGMI (point-to-point links, ~153 GB/s
 each) instead of copied from a single-process design: every ``update_rate`` steps each rank packs
 ``batch_size // world`` uniformly sampled transitions of its latest rollout chunk into rows
-(``pw_pack_transitions``, one launch) and a single ``gather`` moves them peer -> root, where
-``pw_replay_add_packed`` appends them to the device replay ring.  Gathering EVERY transition instead
+(``pw_pack_transitions``, one launch) and a single ``all_gather`` (world x ~100 KB: latency-, not
+bandwidth-bound, so the collective with the least launch overhead wins) delivers them to the root, where
+one ``pw_replay_add_packed`` launch appends them to the device replay ring.  Gathering EVERY transition instead
 would need 395 B x 2e9 env-steps/s = ~0.8 TB/s into one GPU -- more than all seven inbound links
 together -- to refill a 1e6-slot ring thousands of times per second, of which the learner reads
 1024 rows per update; the ring's capacity and the learner's appetite bound the useful ingest, so the
@@ -43,7 +44,8 @@ class SampledTransitionGather(object):
     (needs obs, rew_shared, terminal and, with auto-reset, final_obs); chunk_actions [T,B,N] int32.
     """
 
-    def __init__(self, env, batch_size, rank, world, device, memory=None, every=4, group=None, seed=0):
+    def __init__(self, env, batch_size, rank, world, device, memory=None, every=4, group=None, seed=0,
+                 side_stream=False):
         self.rank, self.world, self.device, self.group = rank, world, torch.device(device), group
         self.B, self.N, self.D = env.num_envs, env.n, env.obs_dim
         self.R = max(1, batch_size // world)
@@ -56,13 +58,19 @@ class SampledTransitionGather(object):
         self._sel = {}
         self._seed = seed
         self.send = [torch.zeros(self.R, self.W, dtype=torch.float32, device=self.device) for _ in range(2)]
-        self.recv = None
-        if rank == 0:
-            self.recv = [[torch.zeros(self.R, self.W, dtype=torch.float32, device=self.device)
-                          for _ in range(world)] for _ in range(2)]
-            if self.memory is None:
-                self.memory = self._make_memory()
+        # every rank receives the (small) batch: one all_gather kernel has far less host and launch
+        # overhead than a rooted gather's grouped send/recv, and replicated learners get the rows for free
+        self.recv = [torch.zeros(world * self.R, self.W, dtype=torch.float32, device=self.device) for _ in range(2)]
+        if rank == 0 and self.memory is None:
+            self.memory = self._make_memory()
         self._pending = None
+        # Optional: run pack / ingest on their own HIP stream behind an event recorded after the chunk's
+        # rollout kernel.  Off by default: on this stack the extra stream usually shares the main stream's
+        # hardware queue, so it buys nothing; the default path instead fuses ingest + pack into ONE launch
+        # (pw_exchange) on the main stream (~6 us of kernel per exchange) while the collective itself
+        # runs on RCCL's stream.  With side_stream=True the caller must not overwrite a chunk's output
+        # buffers before the following exchange (or finish()) has run.
+        self.side = torch.cuda.Stream(self.device) if (side_stream and self.device.type == 'cuda') else None
 
     # -- overridable pieces (the CPU gloo test substitutes torch stand-ins for the two HIP launches)
     def _make_memory(self):
@@ -107,12 +115,24 @@ class SampledTransitionGather(object):
         if self._pending is None:
             return
         work, slot = self._pending
-        work.wait()  # NCCL: orders the current stream after the collective; does not block the host
+        if not work.is_completed():
+            work.wait()  # NCCL: orders the current stream after the collective; does not block the host
         if self.rank == 0:
-            for rows in self.recv[slot]:  # rank order => deterministic ring layout
-                self._ingest(rows)
-                self.rows_ingested += rows.shape[0]
+            rows = self.recv[slot]  # [world * R, W] in rank order => deterministic ring layout
+            self._ingest(rows)
+            self.rows_ingested += rows.shape[0]
         self._pending = None
+
+    def prime(self, out, actions, n=2):
+        """n untimed exchanges: RCCL sets up its channels lazily on first use (milliseconds)."""
+        calls, ex, ing = self.calls, self.exchanges, self.rows_ingested
+        for _ in range(n):
+            self.calls = self.every - 1
+            self(out, actions)
+        self.finish()
+        self.calls, self.exchanges, self.rows_ingested = calls, ex, ing
+        if self.rank == 0 and self.memory is not None and hasattr(self.memory, 'clear'):
+            self.memory.clear()
 
     def __call__(self, out, actions):
         self.calls += 1
@@ -121,12 +141,65 @@ class SampledTransitionGather(object):
         T = int(actions.shape[0])
         sel_t, sel_e = self._selection(T)
         slot = self.exchanges & 1
-        self._complete()  # the previous exchange had a whole chunk of rollout to finish behind
-        self._pack(out, actions, sel_t, sel_e, self.send[slot])
-        work = dist.gather(self.send[slot], self.recv[slot] if self.rank == 0 else None, dst=0,
-                           group=self.group, async_op=True)
-        self._pending = (work, slot)
+        if self.side is None:
+            self._exchange(out, actions, sel_t, sel_e, slot)
+        else:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))  # after this chunk's rollout kernel
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                self._exchange(out, actions, sel_t, sel_e, slot)
         self.exchanges += 1
 
+    def _exchange(self, out, actions, sel_t, sel_e, slot):
+        rows_in = None
+        if self._pending is not None:  # the previous exchange had a whole chunk of rollout to finish behind
+            work, prev = self._pending
+            # A cross-queue event wait stalls the main stream ~15-20 us on this stack even when the
+            # collective finished long ago; a host-side completion query costs ~1 us.  Only if the
+            # collective is genuinely still running do we order the stream behind it.
+            if not work.is_completed():
+                work.wait()
+            self._pending = None
+            if self.rank == 0:
+                rows_in = self.recv[prev]
+        self._ingest_and_pack(rows_in, out, actions, sel_t, sel_e, self.send[slot])
+        if rows_in is not None:
+            self.rows_ingested += rows_in.shape[0]
+        work = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
+        self._pending = (work, slot)
+
+    def _ingest_and_pack(self, rows_in, out, actions, sel_t, sel_e, rows_out):
+        """One fused launch (pw_exchange).  Subclasses that override _pack/_ingest get them called instead."""
+        if type(self)._pack is not SampledTransitionGather._pack or type(self)._ingest is not SampledTransitionGather._ingest:
+            if rows_in is not None:
+                self._ingest(rows_in)
+            self._pack(out, actions, sel_t, sel_e, rows_out)
+            return
+        lib = _lib.load()
+        io = PwStepIO()
+        io.act_idx = actions.data_ptr()
+        io.obs = out['obs'].data_ptr()
+        io.rew_shared = out['rew_shared'].data_ptr()
+        if out.get('final_obs') is not None:
+            io.final_obs = out['final_obs'].data_ptr()
+        if out.get('terminal') is not None:
+            io.terminal = out['terminal'].data_ptr()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        m = self.memory
+        n_in = 0 if rows_in is None else rows_in.shape[0]
+        check(lib.pw_exchange(C.byref(m._store) if n_in else None, m._next_idx if n_in else 0, n_in,
+                              C.c_void_p(rows_in.data_ptr()) if n_in else None, C.byref(io), self.B, self.N, self.D,
+                              C.c_void_p(sel_t.data_ptr()), C.c_void_p(sel_e.data_ptr()), self.R,
+                              C.c_void_p(rows_out.data_ptr()), stream))
+        if n_in:
+            m._next_idx = (m._next_idx + n_in) % m._maxsize
+            m._len = min(m._len + n_in, m._maxsize)
+
     def finish(self):
-        self._complete()
+        if self.side is None:
+            self._complete()
+        else:
+            with torch.cuda.stream(self.side):
+                self._complete()
+            torch.cuda.current_stream(self.device).wait_stream(self.side)

@@ -94,6 +94,37 @@ def test_pack_transitions_and_packed_ingest():
     assert torch.equal(a.argmax(-1).float().cpu(), want[:, 2 * nd:2 * nd + 3]) and torch.equal(r.cpu(), want[:, -2])
 
 
+def test_fused_exchange_launch_equals_pack_then_ingest():
+    """pw_exchange (one launch: append previous rows + pack new rows) == pw_replay_add_packed + pw_pack_transitions."""
+    from tests.test_dist_gloo import pack_reference
+    from multiagent_rl_amd.dist import SampledTransitionGather
+    from multiagent_rl_amd.env import BatchedParticleEnv
+    env = BatchedParticleEnv('simple_spread', 128, num_agents=6, max_episode_len=7, auto_reset=True)
+    env.reset()
+    acts = torch.randint(0, 5, (20, 128, 6), device='cuda', dtype=torch.int32)
+    out = env.rollout(acts)
+    g = SampledTransitionGather.__new__(SampledTransitionGather)
+    g.rank, g.world, g.device, g.B, g.N, g.D = 0, 1, torch.device('cuda', 0), 128, 6, env.obs_dim
+    g.R, g._sel, g._seed = 96, {}, 5
+    g.memory = g._make_memory()
+    sel_t, sel_e = g._selection(20)
+    W = 2 * 6 * env.obs_dim + 6 + 2
+    prev = torch.randn(200, W, device='cuda')
+    prev[:, 2 * 6 * env.obs_dim:2 * 6 * env.obs_dim + 6] = torch.randint(0, 5, (200, 6), device='cuda').float()
+    rows = torch.zeros(96, W, device='cuda')
+    g.memory._next_idx, g.memory._len = 999_990, 999_990          # wraps around the ring end
+    g._ingest_and_pack(prev, out, acts, sel_t, sel_e, rows)
+    want = pack_reference({k: v.cpu() for k, v in out.items()}, acts.cpu(), sel_t.cpu(), sel_e.cpu())
+    assert torch.equal(rows.cpu(), want)
+    m = g.memory
+    assert m._next_idx == 190 and len(m) == 1_000_000
+    idx = [(999_990 + i) % 1_000_000 for i in range(200)]
+    o, a, r, n, d = m.sample_index(idx)
+    nd = 6 * env.obs_dim
+    assert torch.equal(o.reshape(200, -1), prev[:, :nd]) and torch.equal(n.reshape(200, -1), prev[:, nd:2 * nd])
+    assert torch.equal(a.argmax(-1).float(), prev[:, 2 * nd:2 * nd + 6]) and torch.equal(r, prev[:, -2]) and torch.equal(d, prev[:, -1])
+
+
 def _drive_pair(scenario, steps, seed, **kw):
     """The HIP MultiAgentEnv and the float64 scalar oracle env under the same NumPy seed and actions."""
     from multiagent_rl_amd import make_env
