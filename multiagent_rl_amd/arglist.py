@@ -8,3 +8,4 @@ warmup_steps = batch_size  # rls/arglist.py:16
 update_rate = 100         # rls/arglist.py:18
 display = False           # rls/arglist.py:23
 save_rate = 1000          # rls/arglist.py:24
+appx = 'scalability/madr/'  # rls/arglist.py:29 (model path prefix used by run_test)

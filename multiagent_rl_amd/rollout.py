@@ -24,8 +24,26 @@ from . import arglist as _default_arglist
 
 
 def run(env, actor, critic, Trainer, scenario_name=None, action_type='Discrete', cnt=0,
-        arglist=None, memory=None, out_dir='Models', log=print):
-    """One env (B = 1), host loop.  Returns the history dict it also pickles."""
+        arglist=None, memory=None, out_dir='Models', log=print, per_agent_transition=False):
+    """Training rollout, one env (B = 1), host loop: experiments/run.py:11-103.
+    ``per_agent_transition=True`` stores the BiCNet tuple instead (per-agent ``rew_n`` and float
+    ``done_n``; experiments/run_BIC.py:46,50).  Returns the history dict it also pickles."""
+    return _loop(env, actor, critic, Trainer, scenario_name, action_type, cnt, arglist, memory, out_dir, log,
+                 evaluate=False, per_agent_transition=per_agent_transition)
+
+
+def run_test(env, actor, critic, Trainer, scenario_name=None, action_type='Discrete', cnt=0,
+             arglist=None, memory=None, out_dir='Models', log=print):
+    """Evaluation rollout: experiments/run.py:106-200 -- ``load_models(appx + scenario + '_fin_' + cnt)``
+    first, a progress line every 10 episodes, history pickled to ``test_history_<scenario>_<cnt>.pkl``
+    with the replay memory inside, no ``save_models``.  (It still calls ``optimize()``: the reference
+    leaves ``arglist.is_training`` True)"""
+    return _loop(env, actor, critic, Trainer, scenario_name, action_type, cnt, arglist, memory, out_dir, log,
+                 evaluate=True, per_agent_transition=False)
+
+
+def _loop(env, actor, critic, Trainer, scenario_name, action_type, cnt, arglist, memory, out_dir, log,
+          evaluate, per_agent_transition):
     cfg = _default_arglist if arglist is None else arglist
     if action_type != 'Discrete':
         raise NotImplementedError('MultiDiscrete scenarios (communication actions) are outside the hot path')
@@ -35,6 +53,9 @@ def run(env, actor, critic, Trainer, scenario_name=None, action_type='Discrete',
         from .replay_buffer import ReplayBuffer
         memory = ReplayBuffer(size=1e+6)
     learner = Trainer(actor, critic, memory, action_type=action_type)
+    if evaluate:
+        learner.load_models(getattr(cfg, 'appx', '') + scenario_name + '_fin_' + str(cnt))
+    report_every = 10 if evaluate else cfg.save_rate
 
     episode_rewards = [0.0]
     agent_rewards = [[0.0] for _ in range(env.n)]
@@ -47,11 +68,13 @@ def run(env, actor, critic, Trainer, scenario_name=None, action_type='Discrete',
         action_n = learner.get_exploration_action(obs_n)[0]
         action_n_env = [np.array(row) for row in action_n.tolist()]
         new_obs_n, rew_n, done_n, info_n = env.step(action_n_env)
-        rew_shared = np.sum(rew_n)
         episode_step += 1
         done = all(done_n)
         terminal = episode_step >= cfg.max_episode_len
-        learner.memory.add(obs_n, action_n_env, rew_shared, new_obs_n, float(done))
+        if per_agent_transition:
+            learner.memory.add(obs_n, action_n_env, rew_n, new_obs_n, [float(d) for d in done_n])
+        else:
+            learner.memory.add(obs_n, action_n_env, np.sum(rew_n), new_obs_n, float(done))
         obs_n = new_obs_n
         for i, rew in enumerate(rew_n):
             episode_rewards[-1] += rew
@@ -69,22 +92,26 @@ def run(env, actor, critic, Trainer, scenario_name=None, action_type='Discrete',
             continue
         if train_step > cfg.warmup_steps and train_step % cfg.update_rate == 0 and cfg.is_training:
             learner.optimize()
-        if terminal and len(episode_rewards) % cfg.save_rate == 0:
+        if terminal and len(episode_rewards) % report_every == 0:
             log('steps: {}, episodes: {}, mean episode reward: {}, time: {}'.format(
-                train_step, len(episode_rewards), np.mean(episode_rewards[-cfg.save_rate:]),
+                train_step, len(episode_rewards), np.mean(episode_rewards[-report_every:]),
                 round(time.time() - t_start, 3)))
             t_start = time.time()
-            final_ep_rewards.append(np.mean(episode_rewards[-cfg.save_rate:]))
+            final_ep_rewards.append(np.mean(episode_rewards[-report_every:]))
             for track in agent_rewards:
-                final_ep_ag_rewards.append(np.mean(track[-cfg.save_rate:]))
+                final_ep_ag_rewards.append(np.mean(track[-report_every:]))
         if len(episode_rewards) > cfg.num_episodes:
             hist = {'reward_episodes': episode_rewards, 'reward_episodes_by_agents': agent_rewards}
+            if evaluate:
+                hist['memory'] = memory
             if out_dir is not None:
                 os.makedirs(out_dir, exist_ok=True)
-                with open(os.path.join(out_dir, 'history_' + scenario_name + '_' + str(cnt) + '.pkl'), 'wb') as fp:
+                name = ('test_history_' if evaluate else 'history_') + scenario_name + '_' + str(cnt) + '.pkl'
+                with open(os.path.join(out_dir, name), 'wb') as fp:
                     pickle.dump(hist, fp)
             log('...Finished total of {} episodes.'.format(len(episode_rewards)))
-            learner.save_models(scenario_name + '_fin_' + str(cnt))
+            if not evaluate:
+                learner.save_models(scenario_name + '_fin_' + str(cnt))
             return hist
 
 

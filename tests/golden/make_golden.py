@@ -8,6 +8,7 @@ third-party package, so these fixtures pin the BOUNDARY, not the arithmetic:
   run_trace.json      experiments.run.run driven unmodified (reference loop, reference
                       ReplayBuffer) with the CPU oracle env + a recording stub Trainer: the exact
                       call sequence, container types/shapes/dtypes, per-episode rewards, history keys.
+  run_test_trace.json experiments.run.run_test the same way (load_models first, test_history_*.pkl with the memory).
   replay_buffer.json  rls.replay_buffer.ReplayBuffer: ring semantics, make_index under random.seed,
                       encode shapes (NumPy-1 semantics; the literal call raises under NumPy >= 2).
   actor_forward.npz   rls.model.ac_network_multi_gumbel.ActorNetwork: state_dict, input, logits, and the
@@ -60,6 +61,33 @@ def make_run_trace():
                first_transition=fingerprint(mem._storage[0]), last_transition=fingerprint(mem._storage[-1]))
     json.dump(out, open(os.path.join(HERE, 'run_trace.json'), 'w'), indent=0)
     print('run_trace.json: %d events' % len(trace))
+
+
+def make_run_test_trace():
+    """experiments.run.run_test (evaluation loop) driven the same way."""
+    from rls import arglist
+    from experiments.run import run_test
+    arglist.num_episodes, arglist.warmup_steps, arglist.update_rate, arglist.save_rate = 2, 10, 20, 2
+    arglist.max_episode_len, arglist.appx = 25, 'pfx/'
+    np.random.seed(12345679)
+    env = RecordingEnv(po.make_oracle_env('simple_spread', n=4))
+    np.random.seed(12345679)
+    StubTrainer.trace = env.trace
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        os.makedirs('Models')
+        try:
+            run_test(env, None, None, StubTrainer, 'simple_spread', 'Discrete', cnt=1)
+            files = sorted(os.listdir('Models'))
+            hist = pickle.load(open('Models/test_history_simple_spread_1.pkl', 'rb'))
+        finally:
+            os.chdir(cwd)
+    out = dict(arglist=dict(num_episodes=2, warmup_steps=10, update_rate=20, save_rate=2, max_episode_len=25, appx='pfx/'),
+               trace=env.trace, files=files, history_keys=sorted(hist.keys()),
+               reward_episodes=[float(x) for x in hist['reward_episodes']], memory_len=len(hist['memory']))
+    json.dump(out, open(os.path.join(HERE, 'run_test_trace.json'), 'w'), indent=0)
+    print('run_test_trace.json: %d events, files %s' % (len(env.trace), files))
 
 
 def make_replay():
@@ -116,5 +144,6 @@ def make_actor():
 
 if __name__ == '__main__':
     make_run_trace()
+    make_run_test_trace()
     make_replay()
     make_actor()
