@@ -167,10 +167,15 @@ typedef struct pw_replay_store {
 
 /* add(): append B transitions at ring positions (start + i) % capacity.
  * next_obs row i comes from final_obs where terminal[i] != 0 (and final_obs != NULL). */
-int pw_replay_add(const pw_replay_store *st, int64_t start, int32_t B,
-                  const float *obs, const int32_t *act_idx, const float *rew_shared,
+int pw_replay_add(const pw_replay_store *st, int64_t start, const int64_t *start_dev /* device, or NULL */,
+                  int32_t B, const float *obs, const int32_t *act_idx, const float *rew_shared,
                   const float *next_obs, const float *final_obs, const uint8_t *terminal,
                   const float *done /* [B] or NULL = 0 */, void *stream);
+/* hipGraph support: a captured launch freezes by-value arguments; the two values that change every
+ * step (ring position, Philox step) can instead live in device memory (start_dev / step_dev override the
+ * by-value argument when non-NULL) and be advanced by this one-thread launch inside the same graph:
+ * *counter = (*counter + delta) % modulo (modulo <= 0: no wrap). */
+int pw_counter_add(int64_t *counter, int64_t delta, int64_t modulo, void *stream);
 /* sample_index() / _encode_sample(): gather rows idx[0..b) into dense batch tensors;
  * out_act is one-hot f32 [b,N,5] exactly as the reference's trainer consumes it. */
 int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b,
@@ -190,6 +195,26 @@ int pw_replay_add_packed(const pw_replay_store *st, int64_t start, int32_t R, co
 int pw_exchange(const pw_replay_store *st, int64_t start, int32_t R_in, const float *rows_in, const pw_step_io *io,
                 int32_t B, int32_t N, int32_t D, const int32_t *sel_t, const int32_t *sel_e, int32_t R_out,
                 float *rows_out, void *stream);
+
+/* Episode bookkeeping of the rollout loop (experiments/run.py:55-65) over B envs in one launch:
+ * episode_return[b] += rew_shared[b]; where terminal[b]: *finished_sum += return (double),
+ * *finished_count += 1, return cleared.  Deterministic (single workgroup, fixed-order reduction). */
+int pw_episode_stats(const float *rew_shared, const uint8_t *terminal, int32_t B, float *episode_return,
+                     double *finished_sum, int64_t *finished_count, void *stream);
+
+/* ---- action producer (rls/model/ac_network_multi_gumbel.py:24-67, ddpg_gumbel_fix.py:86-116) --------
+ * The actor is Linear(D,64)-ReLU-BiLSTM(64->2x32 over the AGENT axis)-ReLU-Linear(64,5).  The two input
+ * GEMMs stay in rocBLAS; these two launches replace MIOpen's many-kernel RNN path and the sampling:
+ * pw_bilstm_forward: G [B,N,2,128] = x*W_ih^T + b_ih + b_hh per direction (PyTorch gate order i,f,g,o;
+ *   direction 1 = reverse), w_hh_* [128,32] row-major -> H [B,N,64] = [h_forward | h_reverse], ReLU'd
+ *   if relu_out (the next layer applies F.relu).  Hidden size is the reference's fixed 32.
+ * pw_actor_head: logits [rows,5] = H*W2^T + b2 (optional output) and act[rows] = argmax(logits + g),
+ *   g = -log(-log(u)) Gumbel noise from Philox4x32-10 keyed (seed; step, row): the hard one-hot of
+ *   F.gumbel_softmax(hard=True) kept as an int32 index on the device. */
+int pw_bilstm_forward(const float *G, const float *w_hh_fw, const float *w_hh_bw, int32_t B, int32_t N,
+                      int32_t relu_out, float *H, void *stream);
+int pw_actor_head(const float *H, const float *w2, const float *b2, int64_t rows, uint64_t seed, uint64_t step,
+                  const int64_t *step_dev /* device, or NULL */, float *logits, int32_t *act, void *stream);
 
 #ifdef __cplusplus
 }

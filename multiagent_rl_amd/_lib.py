@@ -70,12 +70,18 @@ SIGNATURES = {
     'pw_step': (C.c_int, [C.c_void_p, C.POINTER(PwStepIO), C.c_void_p]),
     'pw_rollout': (C.c_int, [C.c_void_p, C.POINTER(PwStepIO), C.c_int, C.c_void_p]),
     'pw_algorithmic_bytes_per_env_step': (C.c_size_t, [C.c_void_p]),
-    'pw_replay_add': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.c_int32] + [C.c_void_p] * 7 + [C.c_void_p]),
+    'pw_replay_add': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.c_void_p, C.c_int32] + [C.c_void_p] * 7 + [C.c_void_p]),
+    'pw_counter_add': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'pw_pack_transitions': (C.c_int, [C.POINTER(PwStepIO), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_void_p]),
     'pw_replay_add_packed': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     'pw_exchange': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.c_int32, C.c_void_p, C.POINTER(PwStepIO), C.c_int32,
                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pw_bilstm_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                   C.c_void_p]),
+    'pw_actor_head': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pw_episode_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pw_replay_gather': (C.c_int, [C.POINTER(PwReplayStore), C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_void_p]),
 }
 

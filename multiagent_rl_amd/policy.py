@@ -67,6 +67,84 @@ class GumbelPolicy(object):
         return (logits + gumbels).argmax(dim=-1).to(torch.int32)
 
 
+class FusedActor(object):
+    """The same ActorNetwork evaluated with two rocBLAS GEMMs + two launches of libpworld
+    (``pw_bilstm_forward``, ``pw_actor_head``) instead of MIOpen's ~45-kernel RNN path.
+
+    Weights are snapshotted from ``actor`` (call ``refresh()`` after the learner updates it).  Input
+    projections of both LSTM directions are one [B*N, 64] x [64, 256] GEMM; the recurrence over the
+    agent axis and the output head + Gumbel sampling run in hand-written HIP kernels.
+    """
+
+    def __init__(self, actor, seed=0):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib_mod, self.lib = C, _lib, _lib.load()
+        self.actor, self.seed, self.calls = actor, int(seed), 0
+        self.refresh()
+        self._step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)  # Philox step (hipGraph mode)
+        self.graph_mode = False
+
+    @torch.no_grad()
+    def refresh(self):
+        a = self.actor
+        lin1, lstm, lin2 = a.dense1.module, a.bilstm, a.dense2.module
+        assert lstm.hidden_size == 32 and lstm.bidirectional and lstm.num_layers == 1 and lin2.out_features == 5
+        dev = lin1.weight.device
+        assert dev.type == 'cuda', 'FusedActor needs the actor on the GPU (no CPU fallback)'
+        f = lambda t: t.detach().to(torch.float32).contiguous()  # noqa: E731
+        self.w1t, self.b1 = f(lin1.weight.t()), f(lin1.bias)
+        self.wih_t = f(torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], 0).t())       # [64, 256]
+        self.bih = f(torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0,
+                                lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse], 0))         # [256]
+        self.whh_f, self.whh_r = f(lstm.weight_hh_l0), f(lstm.weight_hh_l0_reverse)             # [128, 32]
+        self.w2, self.b2 = f(lin2.weight), f(lin2.bias)                                         # [5, 64]
+        self.device = dev
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @torch.no_grad()
+    def hidden(self, obs):
+        """obs [B,N,D] -> relu(BiLSTM(relu(dense1(obs)))) [B,N,64]."""
+        B, N, D = obs.shape
+        x = obs.reshape(B * N, D).to(torch.float32)
+        x1 = torch.addmm(self.b1, x, self.w1t).relu_()
+        g = torch.addmm(self.bih, x1, self.wih_t)            # [B*N, 256] = [B,N,2,128]
+        h = torch.empty(B, N, 64, dtype=torch.float32, device=self.device)
+        p = lambda t: self._C.c_void_p(t.data_ptr())  # noqa: E731
+        self._lib_mod.check(self.lib.pw_bilstm_forward(p(g), p(self.whh_f), p(self.whh_r), B, N, 1, p(h),
+                                                       self._stream()))
+        return h
+
+    @torch.no_grad()
+    def _head(self, h, want_logits, want_act):
+        B, N, _ = h.shape
+        logits = torch.empty(B, N, 5, dtype=torch.float32, device=self.device) if want_logits else None
+        act = torch.empty(B, N, dtype=torch.int32, device=self.device) if want_act else None
+        p = lambda t: None if t is None else self._C.c_void_p(t.data_ptr())  # noqa: E731
+        step_dev = p(self._step_dev) if (self.graph_mode and want_act) else None
+        self._lib_mod.check(self.lib.pw_actor_head(p(h), p(self.w2), p(self.b2), B * N, self.seed, self.calls,
+                                                   step_dev, p(logits), p(act), self._stream()))
+        if step_dev is not None:  # captured: the counter advances on the device with every replay
+            self._lib_mod.check(self.lib.pw_counter_add(p(self._step_dev), 1, 0, self._stream()))
+        return logits, act
+
+    def logits(self, obs):
+        return self._head(self.hidden(obs), True, False)[0]
+
+    def __call__(self, obs):
+        """-> Gumbel-sampled action index [B,N] int32 (one fresh Philox stream per call)."""
+        act = self._head(self.hidden(obs), False, True)[1]
+        self.calls += 1
+        return act
+
+    def begin_graph(self):
+        """Switch to the device-side step counter (call before hipGraph capture)."""
+        self._step_dev.fill_(self.calls)
+        self.graph_mode = True
+
+
 class UniformRandomPolicy(object):
     """i.i.d. uniform action indices (the synthetic-action workload of bench.py)."""
 

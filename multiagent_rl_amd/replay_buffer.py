@@ -64,6 +64,7 @@ class ReplayBuffer(object):
         st.act = self.act.data_ptr()
         st.capacity, st.num_agents, st.obs_dim = cap, N, D
         self._store = st
+        self._cursor = torch.zeros(1, dtype=torch.int64, device=dev)  # device copy of _next_idx (hipGraph mode)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
@@ -84,10 +85,22 @@ class ReplayBuffer(object):
         act = torch.as_tensor(np.stack([np.asarray(a) for a in action]).argmax(-1).astype(np.int32))[None]
         self.add_batch(obs, act, torch.tensor([float(reward)]), nxt, done=torch.tensor([float(done)]))
 
-    def add_batch(self, obs, act_idx, rew_shared, next_obs, final_obs=None, terminal=None, done=None):
+    def sync_cursor(self):
+        """Copy the host ring position to the device cursor (call before capturing a graph)."""
+        self._cursor.fill_(self._next_idx)
+
+    def note_graph_adds(self, num_transitions):
+        """Host bookkeeping for adds that ran inside a replayed graph (device cursor already advanced)."""
+        self._next_idx = (self._next_idx + num_transitions) % self._maxsize
+        self._len = min(self._len + num_transitions, self._maxsize)
+
+    def add_batch(self, obs, act_idx, rew_shared, next_obs, final_obs=None, terminal=None, done=None,
+                  device_cursor=False):
         """B transitions of one batched step: obs/next_obs [B,N,D], act_idx [B,N] int, rew_shared [B].
         Where ``terminal[b]`` is set, next_obs is taken from ``final_obs`` (the pre-reset
-        observation: the reference stores new_obs_n BEFORE env.reset(), run.py:52 vs :60)."""
+        observation: the reference stores new_obs_n BEFORE env.reset(), run.py:52 vs :60).
+        ``device_cursor=True`` (hipGraph capture): the ring position is read from, and advanced in,
+        device memory by the captured launches; the caller accounts for it with ``note_graph_adds``."""
         B, N, D = obs.shape
         if self._store is None:
             self._device = obs.device if obs.is_cuda and self._device is None else self._device
@@ -99,7 +112,13 @@ class ReplayBuffer(object):
         rew_shared, done = f32(rew_shared), f32(done)
         act_idx = act_idx.to(device=dev, dtype=torch.int32).contiguous()
         term = None if terminal is None else terminal.to(device=dev).contiguous().view(torch.uint8)
-        check(self._lib.pw_replay_add(C.byref(self._store), self._next_idx, B, _ptr(obs), _ptr(act_idx),
+        if device_cursor:
+            check(self._lib.pw_replay_add(C.byref(self._store), 0, _ptr(self._cursor), B, _ptr(obs), _ptr(act_idx),
+                                          _ptr(rew_shared), _ptr(next_obs), _ptr(final_obs), _ptr(term), _ptr(done),
+                                          self._stream()))
+            check(self._lib.pw_counter_add(_ptr(self._cursor), B, self._maxsize, self._stream()))
+            return
+        check(self._lib.pw_replay_add(C.byref(self._store), self._next_idx, None, B, _ptr(obs), _ptr(act_idx),
                                       _ptr(rew_shared), _ptr(next_obs), _ptr(final_obs), _ptr(term), _ptr(done),
                                       self._stream()))
         self._next_idx = (self._next_idx + B) % self._maxsize

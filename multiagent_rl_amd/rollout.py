@@ -132,8 +132,17 @@ class BatchedRollout(object):
         dev = self.obs.device
         self.env_steps = 0
         self.episode_return = torch.zeros(B, device=dev)
-        self.finished_return_sum = torch.zeros((), device=dev)
-        self.finished_episodes = torch.zeros((), device=dev)
+        self.finished_return_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        self.finished_episodes = torch.zeros((), dtype=torch.int64, device=dev)
+        self._graph = None
+
+    def _bookkeeping(self, rew_shared, terminal):
+        import ctypes as C
+        from ._lib import check
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        check(self.env.lib.pw_episode_stats(p(rew_shared), p(terminal), self.env.num_envs, p(self.episode_return),
+                                            p(self.finished_return_sum), p(self.finished_episodes),
+                                            self.env._stream()))
 
     def step(self):
         obs = self.obs
@@ -141,16 +150,68 @@ class BatchedRollout(object):
         nxt, rew, done, info = self.env.step(actions)
         if self.memory is not None:
             self.memory.add_batch(obs, actions, info['rew_shared'], nxt, info.get('final_obs'), info['terminal'])
-        self.episode_return += info['rew_shared']
-        term = info['terminal']
-        self.finished_return_sum += (self.episode_return * term).sum()
-        self.finished_episodes += term.sum()
-        self.episode_return *= ~term
+        self._bookkeeping(info['rew_shared'], info['terminal'])
         self.obs = nxt
         self.env_steps += self.env.num_envs
         return nxt, rew, done, info
 
+    def capture(self, steps_per_replay=2):
+        """Capture ``steps_per_replay`` (even) rollout steps -- policy forward, sampling, the fused env
+        step, the replay append, the return bookkeeping -- into ONE hipGraph.  Afterwards ``collect``
+        replays it: one host call per ``steps_per_replay`` steps instead of ~20 launches per step.
+        Values that change per step live in device memory (replay cursor, Philox step; see
+        pw_counter_add).  Observations ping-pong between two static buffers."""
+        assert steps_per_replay % 2 == 0 and self._graph is None
+        env, dev = self.env, self.obs.device
+        self._static = [dict(env.alloc_outputs(), obs_in=None) for _ in range(2)]
+        self._obs_buf = [self.obs.clone(), torch.empty_like(self.obs)]
+        if hasattr(self.policy, 'begin_graph'):
+            self.policy.begin_graph()
+        if self.memory is not None:
+            if self.memory._store is None:
+                self.memory._allocate(env.n, env.obs_dim)
+            self.memory.sync_cursor()
+
+        def one(i):
+            src, dst = self._obs_buf[i & 1], self._obs_buf[(i + 1) & 1]
+            out = self._static[i & 1]
+            out['obs'] = dst
+            actions = self.policy(src)
+            env.step(actions, out=out)
+            if self.memory is not None:
+                self.memory.add_batch(src, actions, out['rew_shared'], dst, out.get('final_obs'), out['terminal'],
+                                      device_cursor=True)
+            self._bookkeeping(out['rew_shared'], out['terminal'])
+
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up outside capture (allocator, rocBLAS workspaces, lazy inits)
+            for i in range(2):
+                one(i)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        if self.memory is not None:
+            self.memory.note_graph_adds(2 * env.num_envs)
+        if hasattr(self.policy, 'calls'):
+            pass  # begin_graph() moved the step counter to the device
+        self.env_steps += 2 * env.num_envs
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            for i in range(steps_per_replay):
+                one(i)
+        self._graph_steps = steps_per_replay
+        self.obs = self._obs_buf[0]
+        return self
+
     def collect(self, num_steps):
+        if self._graph is not None:
+            n = max(1, num_steps // self._graph_steps)
+            for _ in range(n):
+                self._graph.replay()
+            steps = n * self._graph_steps
+            if self.memory is not None:
+                self.memory.note_graph_adds(steps * self.env.num_envs)
+            self.env_steps += steps * self.env.num_envs
+            return self.env_steps
         for _ in range(num_steps):
             self.step()
         return self.env_steps

@@ -243,3 +243,71 @@ def test_batched_rollout_feeds_replay():
     assert n24[:, :, :2].abs().sum() > 0
     o25, _, _, _, _ = mem.sample_index(list(range(25 * 256, 26 * 256)))
     assert o25[:, :, :2].abs().sum() == 0                        # first obs of the next episode: at rest
+
+
+def test_fused_actor_matches_pytorch_float32_reference():
+    """HIP BiLSTM + head vs plain PyTorch fp32 (CPU) on the reference's own weights (golden state_dict)."""
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    g = np.load(os.path.join(GOLD_DIR, 'actor_forward.npz'))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd/')}
+    ref = ActorNetwork(16, 5)
+    ref.load_state_dict(sd)
+    fused = FusedActor(ActorNetwork(16, 5).cuda().eval())
+    fused.actor.load_state_dict(sd)
+    fused.refresh()
+    np.testing.assert_allclose(fused.logits(torch.from_numpy(g['obs']).cuda()).cpu().numpy(), g['logits'],
+                               rtol=0, atol=2e-5)                                     # the reference's own logits
+    torch.manual_seed(1)
+    for B, N in [(1, 3), (257, 6), (1000, 12), (33, 1)]:
+        obs = torch.randn(B, N, 16) * 2
+        with torch.no_grad():
+            want = ref(obs)
+            hid = torch.relu(ref.bilstm(torch.relu(ref.dense1(obs)))[0])
+        np.testing.assert_allclose(fused.hidden(obs.cuda()).cpu().numpy(), hid.numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(fused.logits(obs.cuda()).cpu().numpy(), want.numpy(), rtol=0, atol=2e-5)
+
+
+def test_fused_gumbel_sampling_distribution():
+    """act = argmax(logits + Gumbel): frequencies follow softmax(logits); streams differ per call and row."""
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    torch.manual_seed(0)
+    fused = FusedActor(ActorNetwork(16, 5).cuda().eval(), seed=123)
+    obs = torch.randn(1, 2, 16).cuda().repeat(20000, 1, 1)        # same two rows, 20000 independent draws
+    p = torch.softmax(fused.logits(obs[:1]), -1)[0].cpu().numpy()
+    a = fused(obs).cpu().numpy()
+    b = fused(obs).cpu().numpy()
+    assert a.dtype == np.int32 and a.min() >= 0 and a.max() <= 4 and (a != b).any()
+    for ag in range(2):
+        freq = np.bincount(a[:, ag], minlength=5) / 20000.0
+        assert np.abs(freq - p[ag]).max() < 0.015, (freq, p[ag])
+    fused2 = FusedActor(fused.actor, seed=123)
+    assert np.array_equal(fused2(obs).cpu().numpy(), a)            # same seed + call index => same actions
+
+
+def test_hipgraph_rollout_equals_eager_rollout():
+    """BatchedRollout.capture(): policy + fused env step + replay append replayed as ONE hipGraph
+    (device-side ring cursor and Philox step) fills the ring with exactly what the eager loop stores."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    from multiagent_rl_amd.rollout import BatchedRollout
+    torch.manual_seed(0)
+    actor = ActorNetwork(16, 5).cuda().eval()
+    rings = []
+    for graph in (False, True):
+        env = make_batched_env('simple_spread', 192, n=6, auto_reset=True, max_episode_len=5, seed=11)
+        mem = ReplayBuffer(192 * 8, 6, env.obs_dim)          # wraps: 12 steps into 8 slots-of-B
+        ro = BatchedRollout(env, FusedActor(actor, seed=7), mem)
+        if graph:
+            ro.capture(steps_per_replay=2)                    # 2 warm-up steps ran eagerly inside capture()
+            ro.collect(10)
+        else:
+            ro.collect(12)
+        st = ro.stats()
+        assert st['env_steps'] == 12 * 192 and st['episodes'] == 2 * 192 and len(mem) == 192 * 8
+        assert mem._next_idx == (12 * 192) % (192 * 8)
+        rings.append((mem.obs.clone(), mem.next_obs.clone(), mem.act.clone(), mem.rew.clone(), st['mean_episode_reward'],
+                      ro.obs.clone()))
+    for a, b in zip(rings[0][:4], rings[1][:4]):
+        assert torch.equal(a, b)
+    assert rings[0][4] == rings[1][4] and torch.equal(rings[0][5], rings[1][5])

@@ -36,3 +36,22 @@ with torch.no_grad(), profile(activities=[ProfilerActivity.CUDA, ProfilerActivit
     for _ in range(10): actor(obs)
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=12, max_name_column_width=60))
+
+# ---- fused HIP actor
+from multiagent_rl_amd.policy import FusedActor
+fa = FusedActor(actor)
+with torch.no_grad():
+    print('fused actor (2 GEMM + bilstm + head, sampled action) eager: %.1f us' % timeit(lambda: fa(obs)))
+    print('  hidden only: %.1f us' % timeit(lambda: fa.hidden(obs)))
+    g2 = torch.cuda.CUDAGraph()
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        for _ in range(3): fa(obs)
+    torch.cuda.current_stream().wait_stream(s2)
+    with torch.cuda.graph(g2):
+        out2 = fa(obs)
+    print('fused actor graph replay: %.1f us' % timeit(lambda: g2.replay()))
+with torch.no_grad(), profile(activities=[ProfilerActivity.CUDA]) as prof2:
+    for _ in range(10): fa(obs)
+    torch.cuda.synchronize()
+print(prof2.key_averages().table(sort_by='cuda_time_total', row_limit=8, max_name_column_width=70))

@@ -9,7 +9,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from multiagent_rl_amd import make_batched_env  # noqa: E402
-from multiagent_rl_amd.policy import ActorNetwork, GumbelPolicy, UniformRandomPolicy  # noqa: E402
+from multiagent_rl_amd.policy import ActorNetwork, FusedActor, GumbelPolicy, UniformRandomPolicy  # noqa: E402
 from multiagent_rl_amd.replay_buffer import ReplayBuffer  # noqa: E402
 from multiagent_rl_amd.rollout import BatchedRollout  # noqa: E402
 
@@ -17,13 +17,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--envs', type=int, default=4096)
 ap.add_argument('--agents', type=int, default=6)
 ap.add_argument('--steps', type=int, default=300)
-ap.add_argument('--policy', default='actor', choices=['actor', 'uniform'])
+ap.add_argument('--policy', default='actor', choices=['actor', 'fused', 'uniform'])
 ap.add_argument('--no-replay', action='store_true')
 ap.add_argument('--graph', action='store_true')
 a = ap.parse_args()
 torch.manual_seed(0)
 env = make_batched_env('simple_spread', a.envs, n=a.agents, auto_reset=True)
-pol = GumbelPolicy(ActorNetwork(env.obs_dim, 5).cuda()) if a.policy == 'actor' else UniformRandomPolicy()
+pol = {'actor': lambda: GumbelPolicy(ActorNetwork(env.obs_dim, 5).cuda()),
+       'fused': lambda: FusedActor(ActorNetwork(env.obs_dim, 5).cuda()),
+       'uniform': UniformRandomPolicy}[a.policy]()
 mem = None if a.no_replay else ReplayBuffer(1e6, a.agents, env.obs_dim)
 ro = BatchedRollout(env, pol, mem)
 if a.graph:
