@@ -57,6 +57,22 @@ def cpu_baseline(seconds, n_agents):
                        'via the MultiAgentEnv list API, %.1f s' % (steps, steps // 25, n_agents, el))
 
 
+def _cpu_worker(args):
+    seconds, n_agents = args
+    return cpu_baseline(seconds, n_agents)['value']
+
+
+def cpu_baseline_all_cores(seconds, n_agents):
+    """the same scalar oracle replicated over every host core (independent envs)."""
+    import multiprocessing as mp
+    # the GPU box reports every host core but grants one GPU's share (16); stay within it
+    n = max(1, min(len(os.sched_getaffinity(0)), 16))
+    with mp.get_context('fork').Pool(n) as pool:
+        rates = pool.map(_cpu_worker, [(seconds, n_agents)] * n)
+    return dict(value=float(sum(rates)), unit='env-steps/s', cores=n,
+                sample='%d processes x %.0f s of the same workload' % (n, seconds))
+
+
 def c_oracle_rate(B, n_agents, steps=50):
     import numpy as np
     from oracle import c_oracle as co
@@ -90,13 +106,21 @@ def main():
                          '(optimize() on 1024 transitions, ddpg_gumbel_fix.py:131) can consume')
     args = ap.parse_args()
 
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+
+    # CPU baseline first, on rank 0 at N = 1 only, BEFORE this process touches the GPU (it forks workers)
+    cpu_line = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.scenario == 'simple_spread':
+        cpu_line = cpu_baseline(args.cpu_seconds, args.agents)
+        cpu_line['c_oracle_f32_1core_env_steps_per_s'] = c_oracle_rate(args.envs, args.agents)
+        cpu_line['all_cores'] = cpu_baseline_all_cores(min(6.0, args.cpu_seconds), args.agents)
+
     import torch
     import torch.distributed as dist
     from multiagent_rl_amd.env import BatchedParticleEnv
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)' %
                          (args.gpus, args.gpus, world))
@@ -238,11 +262,8 @@ def main():
                          'kernel': 'pw_spread_duo_kernel<6,6,true>' if (args.scenario == 'simple_spread' and N == 6) else 'pw_rollout', 'launch_ms': launch_ms,
                          'bytes_per_env_step': env.bytes_per_env_step, 'env_steps_per_launch': B * steps_per_launch},
         }
-        if world == 1 and not args.no_cpu_baseline and args.scenario == 'simple_spread':
-            line['cpu_baseline'] = cpu_baseline(args.cpu_seconds, N)
-            line['cpu_baseline']['c_oracle_f32_1core_env_steps_per_s'] = c_oracle_rate(B, N)
-        elif world == 1:
-            line['cpu_baseline'] = None
+        if world == 1:
+            line['cpu_baseline'] = cpu_line
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -1358,20 +1358,29 @@ __global__ void __launch_bounds__(256) pw_bilstm_kernel(const float *__restrict_
                                                         const float *__restrict__ w_bw, const int B, const int N,
                                                         const int relu_out, float *__restrict__ H)
 {
+    // W_hh of both directions staged once per workgroup (32 KB), laid out [dir][gate][k/4][unit] as
+    // float4 so that the 32 lanes of a sequence read consecutive 16-B slots (conflict-free); the lanes
+    // then keep their 128 weights in VGPRs.  Global weight traffic: 32 KB per workgroup instead of
+    // 512 B per lane (4x less), read with fully coalesced float4 loads.
+    __shared__ float4 s_w[2 * 4 * 8 * 32];
     __shared__ __attribute__((aligned(16))) float s_h[256];  // [8 sequences per workgroup][32]
+    for (int f = threadIdx.x; f < 2048; f += 256) {
+        const int d = f >> 10, r = f & 1023, row = r >> 3, q = r & 7, gate = row >> 5, unit = row & 31;
+        s_w[((d * 4 + gate) * 8 + q) * 32 + unit] = reinterpret_cast<const float4 *>(d ? w_bw : w_fw)[r];
+    }
+    __syncthreads();
     const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;   // hidden unit, sequence slot in the workgroup
     const long seq = (long)blockIdx.x * 8 + grp;              // sequence id = env * 2 + dir
     const bool valid = seq < 2L * B;
     const long env = valid ? seq >> 1 : 0;
     const int dir = valid ? (int)(seq & 1) : 0;
-    const float *w = dir ? w_bw : w_fw;
     float wi[32], wf[32], wg[32], wo[32];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const float4 a = reinterpret_cast<const float4 *>(w + (0 * 32 + j) * 32)[q];
-        const float4 b = reinterpret_cast<const float4 *>(w + (1 * 32 + j) * 32)[q];
-        const float4 c = reinterpret_cast<const float4 *>(w + (2 * 32 + j) * 32)[q];
-        const float4 d = reinterpret_cast<const float4 *>(w + (3 * 32 + j) * 32)[q];
+        const float4 a = s_w[((dir * 4 + 0) * 8 + q) * 32 + j];
+        const float4 b = s_w[((dir * 4 + 1) * 8 + q) * 32 + j];
+        const float4 c = s_w[((dir * 4 + 2) * 8 + q) * 32 + j];
+        const float4 d = s_w[((dir * 4 + 3) * 8 + q) * 32 + j];
         wi[4 * q] = a.x; wi[4 * q + 1] = a.y; wi[4 * q + 2] = a.z; wi[4 * q + 3] = a.w;
         wf[4 * q] = b.x; wf[4 * q + 1] = b.y; wf[4 * q + 2] = b.z; wf[4 * q + 3] = b.w;
         wg[4 * q] = c.x; wg[4 * q + 1] = c.y; wg[4 * q + 2] = c.z; wg[4 * q + 3] = c.w;
@@ -1379,10 +1388,15 @@ __global__ void __launch_bounds__(256) pw_bilstm_kernel(const float *__restrict_
     }
     float h = 0.0f, c = 0.0f;
     float *hs = s_h + grp * 32;
+    const float *g0 = G + (((size_t)env * N + (dir ? N - 1 : 0)) * 2 + dir) * 128;
+    float ni = g0[j], nf = g0[32 + j], ng = g0[64 + j], no = g0[96 + j];
     for (int s = 0; s < N; ++s) {
         const int t = dir ? N - 1 - s : s;
-        const float *g = G + (((size_t)env * N + t) * 2 + dir) * 128;
-        float ai = g[j], af = g[32 + j], ag = g[64 + j], ao = g[96 + j];
+        float ai = ni, af = nf, ag = ng, ao = no;
+        if (s + 1 < N) {  // prefetch the next timestep's pre-activations under this step's FMAs
+            const float *g = G + (((size_t)env * N + (dir ? t - 1 : t + 1)) * 2 + dir) * 128;
+            ni = g[j]; nf = g[32 + j]; ng = g[64 + j]; no = g[96 + j];
+        }
         hs[j] = h;
         wave_lds_sync();  // a sequence's 32 lanes sit in one wave
 #pragma unroll

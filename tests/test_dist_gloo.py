@@ -81,6 +81,8 @@ def _free_port():
 
 
 @pytest.mark.timeout(120)
+@pytest.mark.skipif(torch.cuda.device_count() > 0, reason='CPU-container test: it spawns (execs) worker processes, '
+                    'which a process that may have initialised the GPU must not do')
 def test_sampled_transition_gather_world2():
     world = 2
     ctx = mp.get_context('spawn')
