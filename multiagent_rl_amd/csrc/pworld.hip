@@ -160,6 +160,15 @@ __device__ __forceinline__ void collision_force(float px, float py, float qx, fl
     fy = Fy + fy;
 }
 
+// True only if the pair force is exactly +-0: d2 >= (dist_min + margin)^2 (1 + 1e-6) with margin = 88.5 k
+// puts the softplus argument below -88.4 < -87, pw_exp's exact-zero cut; float rounding in this test is
+// ~1e-7 relative against a slack of 1.4 k.  NaN and +inf are never "far" (they must propagate).
+__device__ __forceinline__ bool provably_far(float d2, float dist_min, float margin)
+{
+    const float r = dist_min + margin;
+    return d2 >= r * r * 1.000001f && d2 <= 3.402823466e+38f;
+}
+
 __device__ __forceinline__ float tag_bound(float x)
 {
     if (x < 0.9f) return 0.0f;
@@ -187,34 +196,33 @@ __device__ __forceinline__ void write_obs(const KParams &P, const Lane &ln, floa
         }
         return;
     }
+    // every observation component is an (x, y) pair and D is even: 8-byte stores, half the store count
+    float2 *o2 = reinterpret_cast<float2 *>(o);
     int k = 0;
-    o[k++] = vx; o[k++] = vy; o[k++] = px; o[k++] = py;
+    o2[k++] = make_float2(vx, vy);
+    o2[k++] = make_float2(px, py);
     for (int l = 0; l < L; ++l) {
         const float2 q = lm[l];
-        o[k++] = q.x - px;
-        o[k++] = q.y - py;
+        o2[k++] = make_float2(q.x - px, q.y - py);
     }
     if (SCEN == PW_SIMPLE_TAG || OBS == PW_OBS_FULL) {
         const float2 *pp = s_pos + ln.base;
         for (int j = 0; j < N; ++j) {
             if (j == ln.a) continue;
             const float2 q = pp[j];
-            o[k++] = q.x - px;
-            o[k++] = q.y - py;
+            o2[k++] = make_float2(q.x - px, q.y - py);
         }
         if (SCEN == PW_SIMPLE_TAG) {
             const float2 *vv = s_vel + ln.base;
             for (int j = P.A; j < N; ++j) {  // velocities of the OTHER good agents
                 if (j == ln.a) continue;
-                const float2 q = vv[j];
-                o[k++] = q.x;
-                o[k++] = q.y;
+                o2[k++] = vv[j];
             }
         } else {
-            for (int j = 0; j < 2 * (N - 1); ++j) o[k++] = 0.0f;  // comm of silent agents
+            for (int j = 0; j < N - 1; ++j) o2[k++] = make_float2(0.0f, 0.0f);  // comm of silent agents
         }
     }
-    while (k < P.D) o[k++] = 0.0f;
+    while (2 * k < P.D) o2[k++] = make_float2(0.0f, 0.0f);
 }
 
 // scenario.reward + is_collision mask for the lane's agent from the positions in LDS.
@@ -980,6 +988,7 @@ __global__ void __launch_bounds__(kWave) pw_rollout_kernel(const KParams P, cons
     wave_lds_sync();
 
     const float k = P.contact_margin, cf = P.contact_force, dt = P.dt, damp = P.damp, mass = P.mass;
+    const float near_margin = 88.5f * k;
 
     for (int t = 0; t < T; ++t) {
         const size_t row = (size_t)t * BN + ln.g;  // flattened [t, env, agent]
@@ -1009,20 +1018,35 @@ __global__ void __launch_bounds__(kWave) pw_rollout_kernel(const KParams P, cons
             ux *= my_sens; uy *= my_sens;
             if (my_fscale != 1.0f) { ux = my_fscale * ux; uy = my_fscale * uy; }
             fx = ux + 0.0f; fy = uy + 0.0f;
-            // ---- U5 apply_environment_force: entities j ascending (agents, then landmarks)
+            // ---- U5 apply_environment_force: entities j ascending (agents, then landmarks).
+            // First a cheap pass marks the partners whose force can be non-zero (beyond
+            // dist_min + 88.5 k the softplus is exactly 0, see the fast path's note 1), then only
+            // those are evaluated -- in the same ascending order, so the sums keep their bits.
             const float2 *pp = S.pos + ln.base;
+            const float2 *lm = S.lm + ln.e_local * L;
+            uint64_t near_a = 0, near_l = 0;
             for (int j = 0; j < N; ++j) {
-                if (j == ln.a) continue;
+                const float2 q = pp[j];
+                const float dx = px - q.x, dy = py - q.y;
+                if (j != ln.a && !provably_far(dx * dx + dy * dy, my_size + P.agent_size[j], near_margin))
+                    near_a |= 1ull << j;
+            }
+            if (P.landmark_collide) {
+                for (int l = 0; l < L; ++l) {
+                    const float2 q = lm[l];
+                    const float dx = px - q.x, dy = py - q.y;
+                    if (!provably_far(dx * dx + dy * dy, my_size + P.landmark_size, near_margin)) near_l |= 1ull << l;
+                }
+            }
+            for (uint64_t m = near_a; m; m &= m - 1) {
+                const int j = __builtin_ctzll(m);
                 const float2 q = pp[j];
                 // dist_min = size_a + size_b is commutative, so either pair order gives the same bits
                 collision_force(px, py, q.x, q.y, my_size + P.agent_size[j], k, cf, fx, fy);
             }
-            if (P.landmark_collide) {
-                const float2 *lm = S.lm + ln.e_local * L;
-                for (int l = 0; l < L; ++l) {
-                    const float2 q = lm[l];
-                    collision_force(px, py, q.x, q.y, my_size + P.landmark_size, k, cf, fx, fy);
-                }
+            for (uint64_t m = near_l; m; m &= m - 1) {
+                const float2 q = lm[__builtin_ctzll(m)];
+                collision_force(px, py, q.x, q.y, my_size + P.landmark_size, k, cf, fx, fy);
             }
             // ---- U6 integrate_state
             vx = vx * damp; vy = vy * damp;
