@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, 'csrc', 'pworld.hip')
 OUT = os.path.join(HERE, 'libpworld.so')
-DEPS = [SRC, os.path.join(ROOT, 'include', 'pworld.h'), os.path.join(ROOT, 'include', 'pworld_math.h')]
+DEPS = [os.path.join(HERE, 'csrc', f) for f in sorted(os.listdir(os.path.join(HERE, 'csrc')))] + \
+       [os.path.join(ROOT, 'include', 'pworld.h'), os.path.join(ROOT, 'include', 'pworld_math.h')]
 
 # -ffp-contract=off + correctly rounded div/sqrt: the kernels must reproduce the float32
 # oracle bit for bit (HIP's device default is fp-contract=fast).

@@ -1,0 +1,302 @@
+// pw_common.hpp -- part of libpworld.so (one translation unit: csrc/pworld.hip includes it).
+// Error plumbing, kernel parameter blocks, lane mapping, the shared device functions (collision force, observation, reward/masks, reset).
+#pragma once
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define PW_HIP_CHECK(expr)                                                             \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return fail(PW_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+    } while (0)
+
+constexpr int kWave = 64;
+
+// Every workgroup is ONE wave, and a wave's LDS instructions execute in issue order, so the
+// only thing a write -> cross-lane read hand-off through LDS needs is (a) that the compiler
+// keeps the program order of the accesses and (b) that the data has landed before it is
+// consumed.  Unlike __syncthreads() this does NOT drain vmcnt: the step's global stores
+// (16 B x 4 per lane of observations) stay in flight across steps.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Everything a kernel needs, passed by value in the kernarg segment.
+struct KParams {
+    int B, N, L, A, D;
+    int epw;          // envs per wave
+    int max_episode_len, auto_reset, force_discrete, landmark_collide;
+    uint64_t seed, env_id_base;
+    float dt, damp, contact_force, contact_margin, mass, landmark_size;
+    float *pos_x, *pos_y, *vel_x, *vel_y, *lm_x, *lm_y;
+    int32_t *ep_step;
+    uint32_t *ep_count;
+    float agent_size[PW_MAX_AGENTS];
+    float agent_sens[PW_MAX_AGENTS];      // accel if set else default_sensitivity (_set_action)
+    float agent_fscale[PW_MAX_AGENTS];    // 1, or mass*accel with the fork knob (apply_action_force)
+    float agent_max_speed[PW_MAX_AGENTS]; // < 0: None
+};
+
+// Per-lane view of "its" env inside the wave.
+struct Lane {
+    int e_local, a, base;  // env slot in wave, agent index, first lane of the env
+    int env;               // local env index
+    size_t g;              // env * N + a
+    bool valid;
+};
+
+__device__ __forceinline__ Lane make_lane(const KParams &P)
+{
+    Lane ln;
+    const int lane = threadIdx.x;
+    ln.e_local = lane / P.N;
+    ln.a = lane - ln.e_local * P.N;
+    ln.base = ln.e_local * P.N;
+    ln.env = blockIdx.x * P.epw + ln.e_local;
+    ln.valid = ln.e_local < P.epw && ln.env < P.B;
+    if (!ln.valid) {  // idle lanes alias env slot 0 for reads; they never write
+        ln.e_local = 0; ln.a = 0; ln.base = 0; ln.env = 0;
+    }
+    ln.g = (size_t)ln.env * P.N + ln.a;
+    return ln;
+}
+
+// Correctly rounded sqrtf for the hot loops.  The compiler's expansion of sqrtf spends half of its
+// ~22 instructions on scaling subnormal-range inputs and on the 0 / inf / NaN pass-through.  For
+// x in [2^-90, 2^90) neither is needed: v_sqrt_f32 is within 1 ulp, and two fused residual tests
+// pick between {s-1ulp, s, s+1ulp} -- the same correction step the compiler emits.  Anything
+// outside that range (never reached from finite, non-coincident states) takes the general sqrtf.
+__device__ __forceinline__ float sqrt_rn_fast(float x)
+{
+    if (__builtin_expect(!(x >= 8.077935669463161e-28f && x < 1.2379400392853803e+27f), 0)) return sqrtf(x);
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x);
+    const float r_up = __builtin_fmaf(-s_up, s, x);
+    s = r_dn <= 0.0f ? s_dn : s;
+    s = r_up > 0.0f ? s_up : s;
+    return s;
+}
+
+// pw_softplus with the exp argument known to be <= 0: same operations as include/pworld_math.h
+// (so the same bits), but branch-free: the polynomial runs on a clamped argument and the
+// exact-zero cut / NaN pass-through are selects.
+__device__ __forceinline__ float softplus_branchless(float x)
+{
+    const float ax = x < 0.0f ? -x : x;
+    const float m = x > 0.0f ? x : 0.0f;
+    const float t0 = -ax;                       // <= 0, or NaN
+    const float tc = t0 > -87.0f ? t0 : -86.0f;  // keep the exponent arithmetic in range when cut
+    float t = tc * 1.44269504088896341f;
+    float n = floorf(t + 0.5f);
+    float r = tc - n * 0.693359375f;
+    r = r - n * -2.12194440054690583e-4f;
+    float p = 1.98412698412698413e-4f;
+    p = p * r + 1.38888888888888894e-3f;
+    p = p * r + 8.33333333333333322e-3f;
+    p = p * r + 4.16666666666666644e-2f;
+    p = p * r + 1.66666666666666657e-1f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    const int32_t e = (int32_t)n + 127;
+    float ex = p * __uint_as_float((uint32_t)e << 23);
+    ex = t0 > -87.0f ? ex : (t0 != t0 ? t0 : 0.0f);  // pw_exp: x <= -87 -> +0, NaN -> NaN
+    return m + pw_log1p01(ex);
+}
+
+// get_collision_force seen from entity i against entity j: force on i.
+// delta = p_i - p_j; dist = sqrt(sum(delta^2)); pen = logaddexp(0, -(dist - dist_min)/k) * k;
+// force = contact_force * delta / dist * pen.  (The force on the pair's second entity is
+// the exact negation, which is what this evaluates to from that entity's side.)
+template <bool FAST = false>
+__device__ __forceinline__ void collision_force(float px, float py, float qx, float qy, float dist_min,
+                                                float k, float cf, float &fx, float &fy)
+{
+    const float dx = px - qx, dy = py - qy;
+    const float d2 = dx * dx + dy * dy;
+    const float dist = FAST ? sqrt_rn_fast(d2) : sqrtf(d2);
+    const float xarg = -(dist - dist_min) / k;
+    const float pen = (FAST ? softplus_branchless(xarg) : pw_softplus(xarg)) * k;
+    const float Fx = cf * dx / dist * pen;
+    const float Fy = cf * dy / dist * pen;
+    fx = Fx + fx;
+    fy = Fy + fy;
+}
+
+// True only if the pair force is exactly +-0: d2 >= (dist_min + margin)^2 (1 + 1e-6) with margin = 88.5 k
+// puts the softplus argument below -88.4 < -87, pw_exp's exact-zero cut; float rounding in this test is
+// ~1e-7 relative against a slack of 1.4 k.  NaN and +inf are never "far" (they must propagate).
+__device__ __forceinline__ bool provably_far(float d2, float dist_min, float margin)
+{
+    const float r = dist_min + margin;
+    return d2 >= r * r * 1.000001f && d2 <= 3.402823466e+38f;
+}
+
+__device__ __forceinline__ float tag_bound(float x)
+{
+    if (x < 0.9f) return 0.0f;
+    if (x < 1.0f) return (x - 0.9f) * 10.0f;
+    const float b = pw_exp(2.0f * x - 2.0f);
+    return b < 10.0f ? b : 10.0f;
+}
+
+// scenario.observation for lane's agent -> row o[0..D).  LDS holds the current
+// positions (and velocities for simple_tag) of the wave's envs.
+template <int SCEN, int OBS>
+__device__ __forceinline__ void write_obs(const KParams &P, const Lane &ln, float *__restrict__ o,
+                                          float px, float py, float vx, float vy,
+                                          const float2 *s_pos, const float2 *s_vel, const float2 *s_lm)
+{
+    const int N = P.N, L = P.L;
+    const float2 *lm = s_lm + ln.e_local * L;
+    if (SCEN == PW_SIMPLE_SPREAD && OBS == PW_OBS_LOCAL && (L & 1) == 0) {
+        // D = 4 + 2L is a multiple of 4: 16-byte row stores (experiments/scenarios.py:6-20 layout)
+        float4 *o4 = reinterpret_cast<float4 *>(o);
+        o4[0] = make_float4(vx, vy, px, py);
+        for (int c = 0; c < L / 2; ++c) {
+            const float2 l0 = lm[2 * c], l1 = lm[2 * c + 1];
+            o4[1 + c] = make_float4(l0.x - px, l0.y - py, l1.x - px, l1.y - py);
+        }
+        return;
+    }
+    // every observation component is an (x, y) pair and D is even: 8-byte stores, half the store count
+    float2 *o2 = reinterpret_cast<float2 *>(o);
+    int k = 0;
+    o2[k++] = make_float2(vx, vy);
+    o2[k++] = make_float2(px, py);
+    for (int l = 0; l < L; ++l) {
+        const float2 q = lm[l];
+        o2[k++] = make_float2(q.x - px, q.y - py);
+    }
+    if (SCEN == PW_SIMPLE_TAG || OBS == PW_OBS_FULL) {
+        const float2 *pp = s_pos + ln.base;
+        for (int j = 0; j < N; ++j) {
+            if (j == ln.a) continue;
+            const float2 q = pp[j];
+            o2[k++] = make_float2(q.x - px, q.y - py);
+        }
+        if (SCEN == PW_SIMPLE_TAG) {
+            const float2 *vv = s_vel + ln.base;
+            for (int j = P.A; j < N; ++j) {  // velocities of the OTHER good agents
+                if (j == ln.a) continue;
+                o2[k++] = vv[j];
+            }
+        } else {
+            for (int j = 0; j < N - 1; ++j) o2[k++] = make_float2(0.0f, 0.0f);  // comm of silent agents
+        }
+    }
+    while (2 * k < P.D) o2[k++] = make_float2(0.0f, 0.0f);
+}
+
+// scenario.reward + is_collision mask for the lane's agent from the positions in LDS.
+// s_red: EPW*L floats of wave-private scratch (per-landmark min distance).
+template <int SCEN>
+__device__ __forceinline__ float reward_and_mask(const KParams &P, const Lane &ln, float px, float py,
+                                                 float my_size, const float2 *s_pos, const float2 *s_lm,
+                                                 float *s_red, uint64_t &mask_out)
+{
+    const int N = P.N, L = P.L;
+    const float2 *pp = s_pos + ln.base;
+    uint64_t m = 0;
+    for (int j = 0; j < N; ++j) {
+        const float2 q = pp[j];
+        const float dx = q.x - px, dy = q.y - py;
+        const float d = sqrtf(dx * dx + dy * dy);
+        if (d < P.agent_size[j] + my_size) m |= 1ull << j;
+    }
+    mask_out = m;
+    float r = 0.0f;
+    if (SCEN == PW_SIMPLE_SPREAD) {
+        // shared term: -sum_l min_a |p_a - p_l|.  Lane a owns landmarks a, a+N, ...; sqrt is
+        // monotone and correctly rounded, so min over distances == sqrt(min over squares).
+        const float2 *lm = s_lm + ln.e_local * L;
+        float own = 0.0f;
+        for (int l = ln.a; l < L; l += N) {
+            const float2 q = lm[l];
+            float best = 0.0f;
+            for (int a = 0; a < N; ++a) {
+                const float2 p = pp[a];
+                const float dx = p.x - q.x, dy = p.y - q.y;
+                const float d2 = dx * dx + dy * dy;
+                best = (a == 0 || d2 < best) ? d2 : best;
+            }
+            own = sqrtf(best);
+            if (L > N && ln.valid) s_red[ln.e_local * L + l] = own;
+        }
+        if (L > N) {
+            wave_lds_sync();
+            for (int l = 0; l < L; ++l) r -= s_red[ln.e_local * L + l];
+        } else {
+            // per-env ordered reduction over the env's lanes by wave shuffle (ds_bpermute)
+            for (int l = 0; l < L; ++l) r -= __shfl(own, ln.base + l, kWave);
+        }
+        for (int a = 0; a < N; ++a)
+            if ((m >> a) & 1) r -= 1.0f;  // includes a == agent, as upstream
+    } else {
+        const int A = P.A;
+        if (ln.a >= A) {
+            for (int a = 0; a < A; ++a)
+                if ((m >> a) & 1) r -= 10.0f;
+            r -= tag_bound(fabsf(px));
+            r -= tag_bound(fabsf(py));
+        }
+        // adversaries: +10 per colliding (good, adversary) pair; bit a of good lane g's mask
+        const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
+        float radv = 0.0f;
+        for (int g = A; g < N; ++g) {
+            const uint64_t mg = ((uint64_t)(uint32_t)__shfl((int)mhi, ln.base + g, kWave) << 32) |
+                                (uint32_t)__shfl((int)mlo, ln.base + g, kWave);
+            for (int a = 0; a < A; ++a)
+                if ((mg >> a) & 1) radv += 10.0f;
+        }
+        if (ln.a < A) r = radv;
+    }
+    return r;
+}
+
+__device__ __forceinline__ void reset_lane(const KParams &P, const Lane &ln, uint32_t episode, int SCEN,
+                                           float &px, float &py, float2 *s_lm)
+{
+    const uint64_t env_id = P.env_id_base + (uint64_t)ln.env;
+    pw_reset_xy(P.seed, env_id, episode, (uint32_t)ln.a, -1.0f, 1.0f, &px, &py);
+    const float lo = SCEN == PW_SIMPLE_TAG ? -0.9f : -1.0f;
+    for (int l = ln.a; l < P.L; l += P.N) {
+        float x, y;
+        pw_reset_xy(P.seed, env_id, episode, (uint32_t)(P.N + l), lo, -lo, &x, &y);
+        s_lm[ln.e_local * P.L + l] = make_float2(x, y);
+    }
+}
+
+// LDS carve-up of one (single-wave) workgroup
+struct Smem {
+    float2 *pos, *vel, *lm;
+    float *red;
+};
+__device__ __forceinline__ Smem carve(const KParams &P, unsigned char *raw)
+{
+    Smem s;
+    const int nl = P.epw * P.N, ll = P.epw * P.L;
+    s.pos = reinterpret_cast<float2 *>(raw);
+    s.vel = s.pos + nl;
+    s.lm = s.vel + nl;
+    s.red = reinterpret_cast<float *>(s.lm + ll);
+    return s;
+}
+size_t smem_bytes(const KParams &P)
+{
+    return (size_t)P.epw * (2 * P.N + P.L) * sizeof(float2) + (size_t)P.epw * P.L * sizeof(float);
+}
+
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace

@@ -1,0 +1,173 @@
+// pw_kernels_policy.hpp -- part of libpworld.so (one translation unit: csrc/pworld.hip includes it).
+// Policy forward (BiLSTM recurrence, head + Gumbel sampling) and episode bookkeeping.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Policy forward (rls/model/ac_network_multi_gumbel.py:24-67) pieces that MIOpen serves badly:
+// its RNN path issues ~45 tiny kernels for a length-6 sequence (260-400 us per batched step at
+// B = 4096, 500x the environment step).  The two dense input GEMMs stay in rocBLAS (they are real
+// GEMMs: [B*N, 64] x [64, 256]); the recurrence and the output head + Gumbel sampling are fused here.
+//
+// pw_bilstm_kernel: lane = (env, direction, hidden unit j), 32 lanes per sequence.  A lane keeps the
+// four W_hh rows of its unit (i, f, g, o gates; 128 weights) in VGPRs for the whole kernel, so a
+// recurrence step is 128 FMAs + 5 activations per lane; h is exchanged through wave-private LDS
+// (one write, eight broadcast ds_read_b128).  G holds x*W_ih^T + b_ih + b_hh for every timestep.
+// ------------------------------------------------------------------------------------------
+// v_exp_f32 / v_rcp_f32 (1 ulp): the policy net is ordinary float32 inference, not part of the
+// bit-exact environment contract; tests compare against PyTorch's float32 LSTM with a 2e-5 bound.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    const float e = __expf(-2.0f * fabsf(x));  // in (0, 1]: no overflow
+    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    return copysignf(t, x);
+}
+
+__global__ void __launch_bounds__(256) pw_bilstm_kernel(const float *__restrict__ G, const float *__restrict__ w_fw,
+                                                        const float *__restrict__ w_bw, const int B, const int N,
+                                                        const int relu_out, float *__restrict__ H)
+{
+    // W_hh of both directions staged once per workgroup (32 KB), laid out [dir][gate][k/4][unit] as
+    // float4 so that the 32 lanes of a sequence read consecutive 16-B slots (conflict-free); the lanes
+    // then keep their 128 weights in VGPRs.  Global weight traffic: 32 KB per workgroup instead of
+    // 512 B per lane (4x less), read with fully coalesced float4 loads.
+    __shared__ float4 s_w[2 * 4 * 8 * 32];
+    __shared__ __attribute__((aligned(16))) float s_h[256];  // [8 sequences per workgroup][32]
+    for (int f = threadIdx.x; f < 2048; f += 256) {
+        const int d = f >> 10, r = f & 1023, row = r >> 3, q = r & 7, gate = row >> 5, unit = row & 31;
+        s_w[((d * 4 + gate) * 8 + q) * 32 + unit] = reinterpret_cast<const float4 *>(d ? w_bw : w_fw)[r];
+    }
+    __syncthreads();
+    const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;   // hidden unit, sequence slot in the workgroup
+    const long seq = (long)blockIdx.x * 8 + grp;              // sequence id = env * 2 + dir
+    const bool valid = seq < 2L * B;
+    const long env = valid ? seq >> 1 : 0;
+    const int dir = valid ? (int)(seq & 1) : 0;
+    float wi[32], wf[32], wg[32], wo[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 a = s_w[((dir * 4 + 0) * 8 + q) * 32 + j];
+        const float4 b = s_w[((dir * 4 + 1) * 8 + q) * 32 + j];
+        const float4 c = s_w[((dir * 4 + 2) * 8 + q) * 32 + j];
+        const float4 d = s_w[((dir * 4 + 3) * 8 + q) * 32 + j];
+        wi[4 * q] = a.x; wi[4 * q + 1] = a.y; wi[4 * q + 2] = a.z; wi[4 * q + 3] = a.w;
+        wf[4 * q] = b.x; wf[4 * q + 1] = b.y; wf[4 * q + 2] = b.z; wf[4 * q + 3] = b.w;
+        wg[4 * q] = c.x; wg[4 * q + 1] = c.y; wg[4 * q + 2] = c.z; wg[4 * q + 3] = c.w;
+        wo[4 * q] = d.x; wo[4 * q + 1] = d.y; wo[4 * q + 2] = d.z; wo[4 * q + 3] = d.w;
+    }
+    float h = 0.0f, c = 0.0f;
+    float *hs = s_h + grp * 32;
+    const float *g0 = G + (((size_t)env * N + (dir ? N - 1 : 0)) * 2 + dir) * 128;
+    float ni = g0[j], nf = g0[32 + j], ng = g0[64 + j], no = g0[96 + j];
+    for (int s = 0; s < N; ++s) {
+        const int t = dir ? N - 1 - s : s;
+        float ai = ni, af = nf, ag = ng, ao = no;
+        if (s + 1 < N) {  // prefetch the next timestep's pre-activations under this step's FMAs
+            const float *g = G + (((size_t)env * N + (dir ? t - 1 : t + 1)) * 2 + dir) * 128;
+            ni = g[j]; nf = g[32 + j]; ng = g[64 + j]; no = g[96 + j];
+        }
+        hs[j] = h;
+        wave_lds_sync();  // a sequence's 32 lanes sit in one wave
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 hv = reinterpret_cast<const float4 *>(hs)[q];
+            ai = __builtin_fmaf(wi[4 * q], hv.x, ai); af = __builtin_fmaf(wf[4 * q], hv.x, af);
+            ag = __builtin_fmaf(wg[4 * q], hv.x, ag); ao = __builtin_fmaf(wo[4 * q], hv.x, ao);
+            ai = __builtin_fmaf(wi[4 * q + 1], hv.y, ai); af = __builtin_fmaf(wf[4 * q + 1], hv.y, af);
+            ag = __builtin_fmaf(wg[4 * q + 1], hv.y, ag); ao = __builtin_fmaf(wo[4 * q + 1], hv.y, ao);
+            ai = __builtin_fmaf(wi[4 * q + 2], hv.z, ai); af = __builtin_fmaf(wf[4 * q + 2], hv.z, af);
+            ag = __builtin_fmaf(wg[4 * q + 2], hv.z, ag); ao = __builtin_fmaf(wo[4 * q + 2], hv.z, ao);
+            ai = __builtin_fmaf(wi[4 * q + 3], hv.w, ai); af = __builtin_fmaf(wf[4 * q + 3], hv.w, af);
+            ag = __builtin_fmaf(wg[4 * q + 3], hv.w, ag); ao = __builtin_fmaf(wo[4 * q + 3], hv.w, ao);
+        }
+        wave_lds_sync();  // all reads of h done before the next step overwrites it
+        c = fast_sigmoid(af) * c + fast_sigmoid(ai) * fast_tanh(ag);
+        h = fast_sigmoid(ao) * fast_tanh(c);
+        if (valid) H[((size_t)env * N + t) * 64 + dir * 32 + j] = relu_out ? fmaxf(h, 0.0f) : h;
+    }
+}
+
+// Output head: logits = H * W2^T + b2 (64 -> 5) for one (env, agent) row per lane, then the hard
+// Gumbel-softmax sample of ddpg_gumbel_fix.py:109-116 as argmax(logits + g), g = -log(-log(u)),
+// u from Philox4x32-10 keyed (seed; step, row) -- the action stays an int32 index in HBM.
+__global__ void __launch_bounds__(256) pw_actor_head_kernel(const float *__restrict__ H, const float *__restrict__ w2,
+                                                            const float *__restrict__ b2, const long rows,
+                                                            const uint64_t seed, uint64_t step,
+                                                            const int64_t *__restrict__ step_dev,
+                                                            float *__restrict__ logits, int32_t *__restrict__ act)
+{
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    if (step_dev) step = (uint64_t)*step_dev;
+    float acc[5];
+#pragma unroll
+    for (int o = 0; o < 5; ++o) acc[o] = b2[o];
+    const float4 *h4 = reinterpret_cast<const float4 *>(H + (size_t)r * 64);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float4 hv = h4[q];
+#pragma unroll
+        for (int o = 0; o < 5; ++o) {  // w2 indices are uniform: scalar loads
+            acc[o] = __builtin_fmaf(w2[o * 64 + 4 * q], hv.x, acc[o]);
+            acc[o] = __builtin_fmaf(w2[o * 64 + 4 * q + 1], hv.y, acc[o]);
+            acc[o] = __builtin_fmaf(w2[o * 64 + 4 * q + 2], hv.z, acc[o]);
+            acc[o] = __builtin_fmaf(w2[o * 64 + 4 * q + 3], hv.w, acc[o]);
+        }
+    }
+    if (logits) {
+#pragma unroll
+        for (int o = 0; o < 5; ++o) logits[(size_t)r * 5 + o] = acc[o];
+    }
+    if (act) {
+        uint32_t u[8];
+        pw_philox4x32_10((uint32_t)r, (uint32_t)((uint64_t)r >> 32), (uint32_t)step, (uint32_t)(step >> 32),
+                         (uint32_t)seed, (uint32_t)(seed >> 32), u);
+        pw_philox4x32_10((uint32_t)r, (uint32_t)((uint64_t)r >> 32) | 0x80000000u, (uint32_t)step, (uint32_t)(step >> 32),
+                         (uint32_t)seed, (uint32_t)(seed >> 32), u + 4);
+        int best = 0;
+        float bv = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 5; ++o) {
+            const float uo = ((float)(u[o] >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
+            const float v = acc[o] - __logf(-__logf(uo));
+            if (o == 0 || v > bv) { bv = v; best = o; }
+        }
+        act[r] = best;
+    }
+}
+
+// Episode bookkeeping of the rollout loop (experiments/run.py:55-65, vectorised): return += shared
+// reward; on terminal the return is added to (sum, count) and cleared.  ONE workgroup with a
+// fixed-order tree reduction, so the statistics are bit-reproducible (no float atomics).
+__global__ void __launch_bounds__(1024) pw_episode_stats_kernel(const float *rew_shared, const uint8_t *terminal,
+                                                                const int B, float *episode_return,
+                                                                double *finished_sum, int64_t *finished_count)
+{
+    __shared__ double s_sum[1024];
+    __shared__ int s_cnt[1024];
+    double acc = 0.0;
+    int cnt = 0;
+    for (int e = threadIdx.x; e < B; e += 1024) {
+        const float r = episode_return[e] + rew_shared[e];
+        if (terminal[e]) { acc += (double)r; cnt += 1; episode_return[e] = 0.0f; }
+        else episode_return[e] = r;
+    }
+    s_sum[threadIdx.x] = acc;
+    s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + w];
+            s_cnt[threadIdx.x] += s_cnt[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *finished_sum += s_sum[0];
+        *finished_count += s_cnt[0];
+    }
+}
+
+}  // namespace

@@ -1,0 +1,155 @@
+// pw_kernels_replay.hpp -- part of libpworld.so (one translation unit: csrc/pworld.hip includes it).
+// Device replay ring, transition packing and the fused multi-GPU exchange launch.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// device replay ring (rls/replay_buffer.py ReplayBuffer.add / _encode_sample)
+// ------------------------------------------------------------------------------------------
+// hipGraph support: a captured launch freezes by-value arguments, so the two values that change from
+// step to step (ring position, Philox step) can also be read from device memory and advanced by a
+// one-thread kernel that is part of the same graph.
+__global__ void pw_counter_add_kernel(int64_t *counter, const int64_t delta, const int64_t modulo)
+{
+    int64_t v = *counter + delta;
+    if (modulo > 0) v %= modulo;
+    *counter = v;
+}
+
+__global__ void pw_replay_add_kernel(const pw_replay_store st, int64_t start, const int64_t *start_dev, const int B,
+                                     const float *obs, const int32_t *act_idx, const float *rew_shared,
+                                     const float *next_obs, const float *final_obs, const uint8_t *terminal,
+                                     const float *done)
+{
+    const int ND = st.num_agents * st.obs_dim, N = st.num_agents;
+    const size_t total = (size_t)B * ND;
+    if (start_dev) start = *start_dev;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / ND, c = i - e * ND;
+        const size_t slot = (size_t)((start + (int64_t)e) % st.capacity);
+        st.obs[slot * ND + c] = obs[i];
+        const bool fin = final_obs && terminal && terminal[e];
+        st.next_obs[slot * ND + c] = fin ? final_obs[i] : next_obs[i];
+        if (c < (size_t)N) st.act[slot * N + c] = (uint8_t)act_idx[e * N + c];
+        if (c == 0) {
+            st.rew[slot] = rew_shared[e];
+            st.done[slot] = done ? done[e] : 0.0f;
+        }
+    }
+}
+
+__global__ void pw_replay_gather_kernel(const pw_replay_store st, const int64_t *idx, const int b,
+                                        float *out_obs, float *out_act, float *out_rew, float *out_next_obs,
+                                        float *out_done)
+{
+    const int ND = st.num_agents * st.obs_dim, N = st.num_agents;
+    const size_t total = (size_t)b * ND;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / ND, c = i - e * ND;
+        const size_t slot = (size_t)idx[e];
+        if (out_obs) out_obs[i] = st.obs[slot * ND + c];
+        if (out_next_obs) out_next_obs[i] = st.next_obs[slot * ND + c];
+        if (out_act && c < (size_t)N * 5) {  // ND >= 5N always (obs_dim >= 6)
+            const size_t ag = c / 5, kk = c - ag * 5;
+            out_act[e * N * 5 + c] = st.act[slot * N + ag] == kk ? 1.0f : 0.0f;
+        }
+        if (c == 0) {
+            if (out_rew) out_rew[e] = st.rew[slot];
+            if (out_done) out_done[e] = st.done[slot];
+        }
+    }
+}
+
+// Transition rows for the multi-GPU exchange: [obs ND | next_obs ND | act N | rew | done], f32.
+// Row r is transition (t, e) = (sel_t[r], sel_e[r]) of a rollout chunk, t >= 1: the observation the
+// policy acted on is obs[t-1], the stored next observation is the PRE-reset one (run.py:52 vs :60).
+__global__ void pw_pack_transitions_kernel(const pw_step_io io, const int B, const int N, const int D,
+                                           const int32_t *sel_t, const int32_t *sel_e, const int R, float *rows)
+{
+    const int ND = N * D, W = 2 * ND + N + 2;
+    const size_t total = (size_t)R * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / W), c = (int)(i - (size_t)r * W);
+        const int t = sel_t[r], e = sel_e[r];
+        const size_t te = (size_t)t * B + e;
+        float v;
+        if (c < ND) {
+            v = io.obs[((size_t)(t - 1) * B + e) * ND + c];
+        } else if (c < 2 * ND) {
+            const bool fin = io.final_obs && io.terminal && io.terminal[te];
+            v = (fin ? io.final_obs : io.obs)[te * ND + (c - ND)];
+        } else if (c < 2 * ND + N) {
+            v = (float)io.act_idx[te * N + (c - 2 * ND)];
+        } else if (c == 2 * ND + N) {
+            v = io.rew_shared[te];
+        } else {
+            v = 0.0f;  // done: upstream done_callback is None
+        }
+        rows[i] = v;
+    }
+}
+
+__global__ void pw_replay_add_packed_kernel(const pw_replay_store st, const int64_t start, const int R,
+                                            const float *rows)
+{
+    const int N = st.num_agents, ND = N * st.obs_dim, W = 2 * ND + N + 2;
+    const size_t total = (size_t)R * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / W), c = (int)(i - (size_t)r * W);
+        const size_t slot = (size_t)((start + r) % st.capacity);
+        const float v = rows[i];
+        if (c < ND) st.obs[slot * ND + c] = v;
+        else if (c < 2 * ND) st.next_obs[slot * ND + (c - ND)] = v;
+        else if (c < 2 * ND + N) st.act[slot * N + (c - 2 * ND)] = (uint8_t)v;
+        else if (c == 2 * ND + N) st.rew[slot] = v;
+        else st.done[slot] = v;
+    }
+}
+
+// One launch per exchange: blocks [0, nb_in) append the rows received by the PREVIOUS collective to the
+// ring, blocks [nb_in, ...) pack this chunk's sampled transitions for the NEXT one (two tiny dependent
+// launches would cost more in launch gaps than in work).
+__global__ void pw_exchange_kernel(const pw_replay_store st, const int64_t start, const int R_in, const float *rows_in,
+                                   const int nb_in, const pw_step_io io, const int B, const int N, const int D,
+                                   const int32_t *sel_t, const int32_t *sel_e, const int R_out, float *rows_out)
+{
+    const int ND = N * D, W = 2 * ND + N + 2;
+    if ((int)blockIdx.x < nb_in) {
+        const size_t total = (size_t)R_in * W;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)nb_in * blockDim.x) {
+            const int r = (int)(i / W), c = (int)(i - (size_t)r * W);
+            const size_t slot = (size_t)((start + r) % st.capacity);
+            const float v = rows_in[i];
+            if (c < ND) st.obs[slot * ND + c] = v;
+            else if (c < 2 * ND) st.next_obs[slot * ND + (c - ND)] = v;
+            else if (c < 2 * ND + N) st.act[slot * N + (c - 2 * ND)] = (uint8_t)v;
+            else if (c == 2 * ND + N) st.rew[slot] = v;
+            else st.done[slot] = v;
+        }
+        return;
+    }
+    const int nb_out = gridDim.x - nb_in;
+    const size_t total = (size_t)R_out * W;
+    for (size_t i = (size_t)(blockIdx.x - nb_in) * blockDim.x + threadIdx.x; i < total; i += (size_t)nb_out * blockDim.x) {
+        const int r = (int)(i / W), c = (int)(i - (size_t)r * W);
+        const int t = sel_t[r], e = sel_e[r];
+        const size_t te = (size_t)t * B + e;
+        float v;
+        if (c < ND) {
+            v = io.obs[((size_t)(t - 1) * B + e) * ND + c];
+        } else if (c < 2 * ND) {
+            const bool fin = io.final_obs && io.terminal && io.terminal[te];
+            v = (fin ? io.final_obs : io.obs)[te * ND + (c - ND)];
+        } else if (c < 2 * ND + N) {
+            v = (float)io.act_idx[te * N + (c - 2 * ND)];
+        } else if (c == 2 * ND + N) {
+            v = io.rew_shared[te];
+        } else {
+            v = 0.0f;
+        }
+        rows_out[i] = v;
+    }
+}
+
+}  // namespace
