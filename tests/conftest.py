@@ -27,3 +27,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _native_libraries_up_to_date():
+    """Rebuild libpworld.so / the oracle library if a source is newer than the binary (a no-op otherwise).
+    The product itself never builds or falls back: without the .so, ``_lib.load()`` raises."""
+    import shutil
+    from multiagent_rl_amd import build_native
+    if shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc'):
+        build_native.build()
+    from oracle import c_oracle
+    c_oracle.build()
+    yield
