@@ -1,0 +1,240 @@
+// pw_kernels_tag.hpp -- part of libpworld.so (one translation unit: csrc/pworld.hip includes it).
+// simple_tag (predator-prey) streaming kernel: the "asymmetric collision path" of BASELINE.json configs[2].
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// simple_tag in the streaming style of pw_spread_stream_kernel: one wave per EPW envs, state in
+// registers + LDS across T steps, every store unconditional (idle lanes shadow lane 0), exact
+// far-pair skip, sqrt-free collision masks.  What is different from simple_spread:
+//   * two agent classes (adversary: a < A, good: a >= A) with their own size / accel / max_speed, so
+//     dist_min and the exact d2 thresholds are 2x2 tables indexed by (class_i, class_j);
+//   * landmarks collide (immovable, size 0.2): agent-landmark pairs join the near set, after the agents,
+//     which is upstream's entity order;
+//   * integrate_state clamps |v| to max_speed;
+//   * rewards: good agents -10 per colliding adversary and the boundary penalty; adversaries +10 per
+//     colliding (good, adversary) pair (read from the good lanes' masks through LDS);
+//   * observation rows [vel, pos, landmark - pos, other - pos, velocities of the OTHER good agents],
+//     zero-padded to the adversaries' width D (8-byte stores: every component is an (x, y) pair).
+// Requires each role to be homogeneous (the canonical scenario); otherwise the generic kernel runs.
+// ------------------------------------------------------------------------------------------
+struct TagParams {
+    int B, N, L, A, D, epw, max_episode_len, auto_reset;
+    uint64_t seed, env_id_base;
+    float dt, damp, contact_force, contact_margin, mass;
+    float sens[2], fscale[2], max_speed[2];
+    float dist_min[2][2], coll_thr2[2][2], near_thr2[2][2];  // [class_i][class_j]
+    float dist_min_lm[2], near_thr2_lm[2];                   // agent class vs landmark
+    float *pos_x, *pos_y, *vel_x, *vel_y, *lm_x, *lm_y;
+    int32_t *ep_step;
+    uint32_t *ep_count;
+    const int32_t *act;
+    float *obs, *final_obs, *rew, *rew_shared;
+    uint8_t *done, *terminal;
+};
+
+__device__ __forceinline__ bool bits_near(float d2, float near_thr2)
+{
+    // far <=> near_thr2 <= d2 < +inf on the raw bits (d2 is a sum of squares, never -0); NaN/inf stay near
+    const uint32_t lo = __float_as_uint(near_thr2);
+    return __float_as_uint(d2) - lo >= 0x7F800000u - lo;
+}
+
+template <int NT, int AT, int LT>
+__device__ __forceinline__ void tag_write_obs(float *__restrict__ o, const int N, const int A, const int L,
+                                              const int D, const int a, const float2 *lm, const float2 *pp,
+                                              const float2 *vv, float px, float py, float vx, float vy)
+{
+    float2 *o2 = reinterpret_cast<float2 *>(o);
+    int k = 0;
+    o2[k++] = make_float2(vx, vy);
+    o2[k++] = make_float2(px, py);
+#pragma unroll(LT > 0 ? LT : 1)
+    for (int l = 0; l < (LT ? LT : L); ++l) {
+        const float2 q = lm[l];
+        o2[k++] = make_float2(q.x - px, q.y - py);
+    }
+    for (int j = 0; j < (NT ? NT : N); ++j) {
+        if (j == a) continue;
+        const float2 q = pp[j];
+        o2[k++] = make_float2(q.x - px, q.y - py);
+    }
+    for (int j = (AT >= 0 ? AT : A); j < (NT ? NT : N); ++j) {
+        if (j == a) continue;
+        o2[k++] = vv[j];
+    }
+    while (2 * k < D) o2[k++] = make_float2(0.0f, 0.0f);
+}
+
+// NT / AT / LT: compile-time N / A / L (0 / -1 / 0 = runtime)
+template <int NT, int AT, int LT, bool UNIT_MASS>
+__global__ void __launch_bounds__(kWave) pw_tag_stream_kernel(const TagParams P, const int T)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int N = NT ? NT : P.N, A = AT >= 0 ? AT : P.A, L = LT ? LT : P.L, D = P.D;
+    float2 *s_pos = reinterpret_cast<float2 *>(smem_raw);   // [64]
+    float2 *s_vel = s_pos + kWave;                           // [64]
+    uint32_t *s_mlo = reinterpret_cast<uint32_t *>(s_vel + kWave);  // [64] collision mask, low / high words
+    uint32_t *s_mhi = s_mlo + kWave;
+    float *s_rew = reinterpret_cast<float *>(s_mhi + kWave);  // [64]
+    float2 *s_lm = reinterpret_cast<float2 *>(s_rew + kWave); // [epw * L]
+
+    int e_local = (int)threadIdx.x / N;
+    int a = (int)threadIdx.x - e_local * N;
+    int env = blockIdx.x * P.epw + e_local;
+    if (e_local >= P.epw || env >= P.B) {  // idle lane: shadow lane 0
+        e_local = 0; a = 0; env = blockIdx.x * P.epw;
+    }
+    const int base = e_local * N, me = base + a;
+    const int cls = a >= A ? 1 : 0;
+    const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
+    const size_t BN = (size_t)P.B * N;
+    const float2 *pp = s_pos + base, *vv = s_vel + base;
+    float2 *lmv = s_lm + e_local * L;
+    const uint64_t env_id = P.env_id_base + (uint64_t)env;
+    const uint64_t adv_bits = A >= 64 ? ~0ull : ((1ull << A) - 1ull);
+
+    const float my_sens = P.sens[cls], my_fscale = P.fscale[cls], my_maxspeed = P.max_speed[cls];
+    const float dmin_adv = P.dist_min[cls][0], dmin_good = P.dist_min[cls][1], dmin_lm = P.dist_min_lm[cls];
+    const float cthr_adv = P.coll_thr2[cls][0], cthr_good = P.coll_thr2[cls][1];
+    const float nthr_adv = P.near_thr2[cls][0], nthr_good = P.near_thr2[cls][1], nthr_lm = P.near_thr2_lm[cls];
+
+    float px = P.pos_x[g], py = P.pos_y[g], vx = P.vel_x[g], vy = P.vel_y[g];
+    int ep_step = P.ep_step[env];
+    uint32_t ep_count = P.ep_count[env];
+    for (int l = a; l < L; l += N) lmv[l] = make_float2(P.lm_x[(size_t)env * L + l], P.lm_y[(size_t)env * L + l]);
+    s_pos[me] = make_float2(px, py);
+    s_vel[me] = make_float2(vx, vy);
+    wave_lds_sync();
+
+    // collision mask of the current state + near sets of the next force evaluation
+    uint64_t coll = 0, near_a = 0, near_l = 0;
+    auto partner_pass = [&]() {
+        coll = 0; near_a = 0; near_l = 0;
+#pragma unroll(NT > 0 ? NT : 1)
+        for (int j = 0; j < (NT ? NT : N); ++j) {
+            const float2 q = pp[j];
+            const float dx = q.x - px, dy = q.y - py;
+            const float d2 = dx * dx + dy * dy;
+            const bool jg = j >= A;
+            if (d2 < (jg ? cthr_good : cthr_adv)) coll |= 1ull << j;
+            if (bits_near(d2, jg ? nthr_good : nthr_adv)) near_a |= 1ull << j;
+        }
+        near_a &= ~(1ull << a);
+#pragma unroll(LT > 0 ? LT : 1)
+        for (int l = 0; l < (LT ? LT : L); ++l) {
+            const float2 q = lmv[l];
+            const float dx = q.x - px, dy = q.y - py;
+            if (bits_near(dx * dx + dy * dy, nthr_lm)) near_l |= 1ull << l;
+        }
+    };
+    partner_pass();
+
+    const float k = P.contact_margin, cf = P.contact_force, dt = P.dt, damp = P.damp, mass = P.mass;
+    int act_next = P.act[g];
+    constexpr int kStoresPerStep = (NT > 0 && AT >= 0 && LT > 0) ? 4 + (4 + 2 * LT + 2 * (NT - 1) + 2 * (NT - AT)) / 2 : 0;
+    constexpr int kVm = kStoresPerStep < 63 ? kStoresPerStep : 63;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    for (int t = 0; t < T; ++t) {
+        const size_t tBN = (size_t)t * BN;
+        const int ai = act_next;
+        {
+            const int tn = t + 1 < T ? t + 1 : t;
+            act_next = P.act[(size_t)tn * BN + g];
+        }
+        float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
+        float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
+        ux *= my_sens; uy *= my_sens;
+        if (my_fscale != 1.0f) { ux = my_fscale * ux; uy = my_fscale * uy; }
+        float fx = ux + 0.0f, fy = uy + 0.0f;
+        // ---- U5: near agents (ascending j), then near landmarks (ascending l): upstream's entity order
+        for (uint64_t m = near_a; m; m &= m - 1) {
+            const int j = __builtin_ctzll(m);
+            const float2 q = pp[j];
+            collision_force<true>(px, py, q.x, q.y, j >= A ? dmin_good : dmin_adv, k, cf, fx, fy);
+        }
+        for (uint64_t m = near_l; m; m &= m - 1) {
+            const float2 q = lmv[__builtin_ctzll(m)];
+            collision_force<true>(px, py, q.x, q.y, dmin_lm, k, cf, fx, fy);
+        }
+        // ---- U6 with the max_speed clamp
+        vx = vx * damp; vy = vy * damp;
+        vx = vx + div_mass<UNIT_MASS>(fx, mass) * dt;
+        vy = vy + div_mass<UNIT_MASS>(fy, mass) * dt;
+        if (my_maxspeed >= 0.0f) {
+            const float speed = sqrtf(vx * vx + vy * vy);
+            if (speed > my_maxspeed) {
+                vx = vx / speed * my_maxspeed;
+                vy = vy / speed * my_maxspeed;
+            }
+        }
+        px = px + vx * dt;
+        py = py + vy * dt;
+        wave_lds_sync();
+        s_pos[me] = make_float2(px, py);
+        s_vel[me] = make_float2(vx, vy);
+        wave_lds_sync();
+        partner_pass();
+
+        // ---- simple_tag.reward
+        s_mlo[me] = (uint32_t)coll;
+        s_mhi[me] = (uint32_t)(coll >> 32);
+        wave_lds_sync();
+        float r = 0.0f;
+        if (cls) {
+            for (int q = 0; q < A; ++q)
+                if ((coll >> q) & 1) r -= 10.0f;
+            r -= tag_bound(fabsf(px));
+            r -= tag_bound(fabsf(py));
+        } else {
+            for (int gj = A; gj < N; ++gj) {  // +10 per colliding (good, adversary) pair: exact small integers
+                const uint64_t mg = ((uint64_t)s_mhi[base + gj] << 32) | s_mlo[base + gj];
+                r += 10.0f * (float)__builtin_popcountll(mg & adv_bits);
+            }
+        }
+        s_rew[me] = r;
+        wave_lds_sync();
+        float acc = 0.0f;
+        for (int i = 0; i < N; ++i) acc += s_rew[base + i];
+        P.rew[tBN + g] = r;
+        P.done[tBN + g] = 0;
+        P.rew_shared[(size_t)t * P.B + env] = acc;
+        ep_step += 1;
+        const bool term = P.max_episode_len > 0 && ep_step >= P.max_episode_len;
+        P.terminal[(size_t)t * P.B + env] = term ? 1 : 0;
+        if (term && P.auto_reset) {
+            if (P.final_obs)
+                tag_write_obs<NT, AT, LT>(P.final_obs + (tBN + g) * D, N, A, L, D, a, lmv, pp, vv, px, py, vx, vy);
+            wave_lds_sync();
+            ep_count += 1;
+            ep_step = 0;
+            pw_reset_xy(P.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
+            vx = 0.f; vy = 0.f;
+            for (int l = a; l < L; l += N) {
+                float x, y;
+                pw_reset_xy(P.seed, env_id, ep_count, (uint32_t)(N + l), -0.9f, 0.9f, &x, &y);
+                lmv[l] = make_float2(x, y);
+            }
+            s_pos[me] = make_float2(px, py);
+            s_vel[me] = make_float2(0.f, 0.f);
+        }
+        wave_lds_sync();
+        if (P.auto_reset && __any(term)) partner_pass();
+        tag_write_obs<NT, AT, LT>(P.obs + (tBN + g) * D, N, A, L, D, a, lmv, pp, vv, px, py, vx, vy);
+        if (kStoresPerStep > 0) __builtin_amdgcn_s_waitcnt((kVm & 0xF) | 0x0F70 | ((kVm >> 4) << 14));
+    }
+
+    P.pos_x[g] = px; P.pos_y[g] = py;
+    P.vel_x[g] = vx; P.vel_y[g] = vy;
+    for (int l = a; l < L; l += N) {
+        const float2 q = lmv[l];
+        P.lm_x[(size_t)env * L + l] = q.x;
+        P.lm_y[(size_t)env * L + l] = q.y;
+    }
+    P.ep_step[env] = ep_step;
+    P.ep_count[env] = ep_count;
+}
+
+}  // namespace

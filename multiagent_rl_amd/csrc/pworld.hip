@@ -32,6 +32,7 @@
 
 #include "pw_common.hpp"
 #include "pw_kernels_spread.hpp"
+#include "pw_kernels_tag.hpp"
 #include "pw_kernels_generic.hpp"
 #include "pw_kernels_replay.hpp"
 #include "pw_kernels_policy.hpp"
@@ -43,6 +44,8 @@ struct pw_handle {
     bool bound;
     bool fast;      // pw_spread_fast_kernel applies
     FastConsts fc;
+    bool tag_fast;  // pw_tag_stream_kernel applies
+    TagParams tp;   // its constant part (pointers are filled per launch)
 };
 
 namespace {
@@ -61,6 +64,73 @@ int dispatch(const pw_handle *h, F &&f)
     if (h->cfg.scenario == PW_SIMPLE_TAG) return f(std::integral_constant<int, PW_SIMPLE_TAG>(), std::integral_constant<int, PW_OBS_LOCAL>());
     if (h->cfg.obs_mode == PW_OBS_FULL) return f(std::integral_constant<int, PW_SIMPLE_SPREAD>(), std::integral_constant<int, PW_OBS_FULL>());
     return f(std::integral_constant<int, PW_SIMPLE_SPREAD>(), std::integral_constant<int, PW_OBS_LOCAL>());
+}
+
+// coll_thr2 = min{y : sqrtf(y) >= dist_min}: then sqrtf(d2) < dist_min <=> d2 < coll_thr2 (0 if unusable)
+float exact_coll_thr2(float dmin)
+{
+    if (!(dmin > 0.0f) || !std::isfinite(dmin)) return 0.0f;
+    float y = dmin * dmin;
+    while (sqrtf(y) >= dmin) y = std::nextafterf(y, 0.0f);
+    while (!(sqrtf(y) >= dmin)) y = std::nextafterf(y, INFINITY);
+    return y;
+}
+
+// beyond sqrt(result) the softplus argument is <= -87.5 < -87 (pw_exp's exact-zero cut); 0 if unusable
+float exact_near_thr2(float dmin, float contact_margin)
+{
+    const double near_r = (double)dmin + 88.5 * (double)contact_margin;
+    float n2 = (float)(near_r * near_r * (1.0 + 1e-6));
+    n2 = std::nextafterf(n2, INFINITY);
+    const float x_at = -(sqrtf(n2) - dmin) / contact_margin;
+    if (!(x_at <= -87.5f) || !std::isfinite(n2) || !(n2 > 0.0f)) return 0.0f;
+    return n2;
+}
+
+// Decide whether pw_tag_stream_kernel applies (both roles homogeneous) and derive its tables.
+void setup_tag_path(pw_handle *h)
+{
+    const pw_config &c = h->cfg;
+    const KParams &kp = h->kp;
+    h->tag_fast = false;
+    if (std::getenv("PWORLD_FORCE_GENERIC")) return;
+    if (c.scenario != PW_SIMPLE_TAG || !c.landmark_collide || kp.N < 1) return;
+    const int A = kp.A, N = kp.N;
+    const int rep[2] = {A > 0 ? 0 : 0, A < N ? A : 0};  // representative agent of each class
+    for (int i = 0; i < N; ++i) {
+        const int r = rep[i >= A ? 1 : 0];
+        if (kp.agent_size[i] != kp.agent_size[r] || kp.agent_sens[i] != kp.agent_sens[r] ||
+            kp.agent_fscale[i] != kp.agent_fscale[r] || kp.agent_max_speed[i] != kp.agent_max_speed[r])
+            return;
+    }
+    TagParams &t = h->tp;
+    std::memset(&t, 0, sizeof(t));
+    t.B = kp.B; t.N = N; t.L = kp.L; t.A = A; t.D = kp.D; t.epw = kp.epw;
+    t.max_episode_len = kp.max_episode_len; t.auto_reset = kp.auto_reset;
+    t.seed = kp.seed; t.env_id_base = kp.env_id_base;
+    t.dt = kp.dt; t.damp = kp.damp; t.contact_force = kp.contact_force; t.contact_margin = kp.contact_margin;
+    t.mass = kp.mass;
+    float size[2];
+    for (int cl = 0; cl < 2; ++cl) {
+        size[cl] = kp.agent_size[rep[cl]];
+        t.sens[cl] = kp.agent_sens[rep[cl]];
+        t.fscale[cl] = kp.agent_fscale[rep[cl]];
+        t.max_speed[cl] = kp.agent_max_speed[rep[cl]];
+    }
+    for (int ci = 0; ci < 2; ++ci) {
+        for (int cj = 0; cj < 2; ++cj) {
+            const volatile float dmin = size[ci] + size[cj];
+            t.dist_min[ci][cj] = dmin;
+            t.coll_thr2[ci][cj] = exact_coll_thr2(dmin);
+            t.near_thr2[ci][cj] = exact_near_thr2(dmin, kp.contact_margin);
+            if (t.coll_thr2[ci][cj] == 0.0f || t.near_thr2[ci][cj] == 0.0f) return;
+        }
+        const volatile float dl = size[ci] + kp.landmark_size;
+        t.dist_min_lm[ci] = dl;
+        t.near_thr2_lm[ci] = exact_near_thr2(dl, kp.contact_margin);
+        if (t.near_thr2_lm[ci] == 0.0f) return;
+    }
+    h->tag_fast = true;
 }
 
 // Decide whether pw_spread_fast_kernel applies and derive its exact thresholds on the host.
@@ -84,19 +154,9 @@ void setup_fast_path(pw_handle *h)
     const volatile float dmin = fc.size + fc.size;  // float add, as the kernels do
     fc.dist_min = dmin;
     if (!(dmin > 0.0f) || !std::isfinite(dmin)) return;
-    // coll_thr2 = min{y : sqrtf(y) >= dist_min}: then sqrtf(d2) < dist_min <=> d2 < coll_thr2
-    float y = dmin * dmin;
-    while (sqrtf(y) >= dmin) y = std::nextafterf(y, 0.0f);
-    while (!(sqrtf(y) >= dmin)) y = std::nextafterf(y, INFINITY);
-    fc.coll_thr2 = y;
-    // beyond near_r the softplus argument is <= -88 < -87 (pw_exp's exact-zero cut), with margin
-    const double near_r = (double)dmin + 88.5 * (double)kp.contact_margin;
-    float n2 = (float)(near_r * near_r * (1.0 + 1e-6));
-    n2 = std::nextafterf(n2, INFINITY);
-    const float dist_at = sqrtf(n2);
-    const float x_at = -(dist_at - dmin) / kp.contact_margin;
-    if (!(x_at <= -87.5f) || !std::isfinite(n2)) return;
-    fc.near_thr2 = n2;
+    fc.coll_thr2 = exact_coll_thr2(dmin);
+    fc.near_thr2 = exact_near_thr2(dmin, kp.contact_margin);
+    if (fc.coll_thr2 == 0.0f || fc.near_thr2 == 0.0f) return;
     h->fast = true;
 }
 
@@ -121,6 +181,28 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
     const KParams &kp = h->kp;
     const dim3 grid((kp.B + kp.epw - 1) / kp.epw), block(kWave);
     const size_t shmem = smem_bytes(kp);
+    if (h->tag_fast && io->act_idx && io->obs && io->rew && io->rew_shared && io->done && io->terminal && !io->coll &&
+        (size_t)kp.B * kp.N * kp.D * sizeof(float) < (1ull << 31) && !std::getenv("PWORLD_NO_STREAM")) {
+        TagParams A = h->tp;
+        A.pos_x = kp.pos_x; A.pos_y = kp.pos_y; A.vel_x = kp.vel_x; A.vel_y = kp.vel_y;
+        A.lm_x = kp.lm_x; A.lm_y = kp.lm_y; A.ep_step = kp.ep_step; A.ep_count = kp.ep_count;
+        A.act = io->act_idx; A.obs = io->obs; A.final_obs = io->final_obs; A.rew = io->rew;
+        A.rew_shared = io->rew_shared; A.done = io->done; A.terminal = io->terminal;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const size_t shm = 2 * kWave * sizeof(float2) + 3 * kWave * sizeof(float) + (size_t)kp.epw * kp.L * sizeof(float2);
+        const bool um = kp.mass == 1.0f;
+#define PW_TAG_LAUNCH(n, a, l)                                                                              \
+    do {                                                                                                    \
+        if (um) hipLaunchKernelGGL((pw_tag_stream_kernel<n, a, l, true>), grid, block, shm, st, A, T);      \
+        else hipLaunchKernelGGL((pw_tag_stream_kernel<n, a, l, false>), grid, block, shm, st, A, T);        \
+    } while (0)
+        if (kp.N == 6 && kp.A == 4 && kp.L == 2) PW_TAG_LAUNCH(6, 4, 2);        // BASELINE configs[2]
+        else if (kp.N == 4 && kp.A == 3 && kp.L == 2) PW_TAG_LAUNCH(4, 3, 2);   // canonical upstream roster
+        else PW_TAG_LAUNCH(0, -1, 0);
+#undef PW_TAG_LAUNCH
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
     if (h->fast && io->act_idx && io->obs && io->rew && io->rew_shared && io->done && io->terminal && !io->coll &&
         (size_t)kp.B * kp.N * kp.D * sizeof(float) < (1ull << 31) && !std::getenv("PWORLD_NO_STREAM")) {
         StreamParams A;
@@ -313,6 +395,7 @@ int pw_create(const pw_config *cfg, pw_handle **out)
         kp.agent_max_speed[i] = cfg->agent_max_speed[i];
     }
     setup_fast_path(h);
+    setup_tag_path(h);
     const size_t BN = (size_t)kp.B * kp.N, BL = (size_t)kp.B * kp.L;
     pw_state_layout &lo = h->layout;
     size_t off = 0;

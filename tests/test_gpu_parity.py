@@ -75,6 +75,9 @@ CASES = [
     dict(scenario='simple_spread', num_agents=3, num_landmarks=0, num_envs=9),    # empty landmark set
     dict(scenario='simple_tag', num_agents=4, num_adversaries=3, num_envs=500),   # canonical 3+1
     dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192),  # configs[2] (C3) full size
+    dict(scenario='simple_tag', num_agents=5, num_adversaries=2, num_landmarks=3, num_envs=301),  # runtime-N variant
+    dict(scenario='simple_tag', num_agents=3, num_adversaries=3, num_envs=70),    # no good agents
+    dict(scenario='simple_tag', num_agents=3, num_adversaries=0, num_envs=70),    # no adversaries
 ]
 
 
@@ -85,7 +88,7 @@ def kernel_path(request, monkeypatch):
     'stream'  pw_spread_stream_kernel (PWORLD_NO_DUO),
     'fast'    pw_spread_fast_kernel   (PWORLD_NO_STREAM, or when coll is requested),
     'generic' pw_rollout_kernel       (PWORLD_FORCE_GENERIC, read by pw_create).
-    Other scenarios always take the generic kernel."""
+    simple_tag has two: pw_tag_stream_kernel ('duo'/'stream' params) and the generic kernel ('fast'/'generic')."""
     monkeypatch.delenv('PWORLD_FORCE_GENERIC', raising=False)
     monkeypatch.delenv('PWORLD_NO_STREAM', raising=False)
     monkeypatch.delenv('PWORLD_NO_DUO', raising=False)
@@ -146,7 +149,9 @@ def test_single_step_from_injected_states(case, kernel_path):
     dict(scenario='simple_spread', num_agents=6, num_envs=257),
     dict(scenario='simple_spread', num_agents=3, num_envs=100, obs_mode='full'),
     dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=123),
-], ids=['spread6', 'spread3full', 'tag4+2'])
+    dict(scenario='simple_tag', num_agents=4, num_adversaries=3, num_envs=77),
+    dict(scenario='simple_tag', num_agents=7, num_adversaries=3, num_landmarks=1, num_envs=50),
+], ids=['spread6', 'spread3full', 'tag4+2', 'tag3+1', 'tag3+4'])
 def test_rollout_with_auto_reset_matches_oracle_bitwise(case, kernel_path):
     T, ep_len = 58, 25
     env, cfg = _mk(max_episode_len=ep_len, auto_reset=True, seed=99, env_id_base=1 << 33,
