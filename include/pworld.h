@@ -211,6 +211,11 @@ int pw_episode_stats(const float *rew_shared, const uint8_t *terminal, int32_t B
  * pw_actor_head: logits [rows,5] = H*W2^T + b2 (optional output) and act[rows] = argmax(logits + g),
  *   g = -log(-log(u)) Gumbel noise from Philox4x32-10 keyed (seed; step, row): the hard one-hot of
  *   F.gumbel_softmax(hard=True) kept as an int32 index on the device. */
+/* Y [rows,out_dim] = act(X [rows,in_dim] * W^T + b), W [out_dim,in_dim] row-major, in_dim <= 64, out_dim a
+ * multiple of 64, act = ReLU if relu.  ActorNetwork.dense1 + F.relu, and the LSTM input projection
+ * x * [W_ih; W_ih_reverse]^T + (b_ih + b_hh) that pw_bilstm_forward consumes. */
+int pw_dense(const float *X, const float *W, const float *b, int64_t rows, int32_t in_dim, int32_t out_dim,
+             int32_t relu, float *Y, void *stream);
 int pw_bilstm_forward(const float *G, const float *w_hh_fw, const float *w_hh_bw, int32_t B, int32_t N,
                       int32_t relu_out, float *H, void *stream);
 int pw_actor_head(const float *H, const float *w2, const float *b2, int64_t rows, uint64_t seed, uint64_t step,

@@ -77,6 +77,8 @@ SIGNATURES = {
     'pw_replay_add_packed': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     'pw_exchange': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.c_int32, C.c_void_p, C.POINTER(PwStepIO), C.c_int32,
                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pw_dense': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                          C.c_void_p]),
     'pw_bilstm_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p]),
     'pw_actor_head': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p,

@@ -89,6 +89,43 @@ __global__ void __launch_bounds__(256) pw_bilstm_kernel(const float *__restrict_
     }
 }
 
+// Dense layers with a tiny reduction dimension (K <= 64): Y = act(X * W^T + b), W [out, K] row-major.
+// Used for dense1 (D -> 64, ReLU) and for the LSTM input projection of both directions (64 -> 256).
+// At these shapes a library GEMM is launch- and tile-quantisation-bound (12 + 4.5 us and 18 us at
+// B*N = 24576 rows).  Weight-stationary mapping instead: lane = one output unit (its K weights and bias
+// stay in VGPRs for the whole kernel), a wave covers 64 outputs and walks over rows whose inputs are
+// wave-uniform and arrive through the scalar path (s_load), and each row's 64 outputs leave as one
+// coalesced 256-B store.
+template <int KT, bool RELU>
+__global__ void __launch_bounds__(256) pw_dense_kernel(const float *__restrict__ X, const float *__restrict__ W,
+                                                       const float *__restrict__ bvec, const long rows, const int K,
+                                                       const int out_dim, const int rows_per_wave,
+                                                       float *__restrict__ Y)
+{
+    constexpr int KM = KT > 0 ? KT : 64;
+    const int Kd = KT > 0 ? KT : K;
+    const int chunks = out_dim >> 6;
+    const long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int chunk = (int)(wave % chunks);
+    const long rg = wave / chunks;
+    const int o = chunk * 64 + (threadIdx.x & 63);
+    float w[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) w[k] = k < Kd ? W[(size_t)o * Kd + k] : 0.0f;
+    const float bias = bvec[o];
+    const long r0 = rg * rows_per_wave;
+    const long r1 = r0 + rows_per_wave < rows ? r0 + rows_per_wave : rows;
+#pragma unroll 2
+    for (long r = r0; r < r1; ++r) {
+        const float *xr = X + (size_t)r * Kd;  // wave-uniform address: scalar loads
+        float acc = bias;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (KT > 0 || k < Kd) acc = __builtin_fmaf(w[k], xr[k], acc);
+        Y[(size_t)r * out_dim + o] = RELU ? fmaxf(acc, 0.0f) : acc;
+    }
+}
+
 // Output head: logits = H * W2^T + b2 (64 -> 5) for one (env, agent) row per lane, then the hard
 // Gumbel-softmax sample of ddpg_gumbel_fix.py:109-116 as argmax(logits + g), g = -log(-log(u)),
 // u from Philox4x32-10 keyed (seed; step, row) -- the action stays an int32 index in HBM.

@@ -378,6 +378,10 @@ int pw_create(const pw_config *cfg, pw_handle **out)
     kp.A = cfg->scenario == PW_SIMPLE_TAG ? cfg->num_adversaries : 0;
     kp.D = obs_dim_of(*cfg);
     kp.epw = kWave / kp.N;
+    if (const char *e = std::getenv("PWORLD_EPW")) {  // experiments: fewer envs per wave (more, shorter waves)
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= kp.epw) kp.epw = v;
+    }
     kp.max_episode_len = cfg->max_episode_len;
     kp.auto_reset = cfg->auto_reset;
     kp.force_discrete = cfg->force_discrete_action;
@@ -642,6 +646,38 @@ int pw_episode_stats(const float *rew_shared, const uint8_t *terminal, int32_t B
     if (B < 1) return fail(PW_EINVAL, "bad sizes");
     hipLaunchKernelGGL(pw_episode_stats_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), rew_shared,
                        terminal, B, episode_return, finished_sum, finished_count);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_dense(const float *X, const float *W, const float *b, int64_t rows, int32_t in_dim, int32_t out_dim,
+             int32_t relu, float *Y, void *stream)
+{
+    if (!X || !W || !b || !Y) return fail(PW_EINVAL, "null argument");
+    if (rows < 1 || in_dim < 1 || in_dim > 64) return fail(PW_EINVAL, "in_dim must be in [1, 64]");
+    if (out_dim < 64 || (out_dim & 63)) return fail(PW_EINVAL, "out_dim must be a positive multiple of 64");
+    const int chunks = out_dim / 64;
+    // ~2048 waves (two per SIMD) when there are enough rows, at least 8 rows per wave
+    long rpw = (rows * chunks + 2047) / 2048;
+    if (rpw < 8) rpw = 8;
+    const long waves = ((rows + rpw - 1) / rpw) * chunks;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define PW_DENSE_LAUNCH(k)                                                                                          \
+    do {                                                                                                            \
+        if (relu) hipLaunchKernelGGL((pw_dense_kernel<k, true>), grid, block, 0, st, X, W, b, (long)rows, in_dim,   \
+                                     out_dim, (int)rpw, Y);                                                         \
+        else hipLaunchKernelGGL((pw_dense_kernel<k, false>), grid, block, 0, st, X, W, b, (long)rows, in_dim,       \
+                                out_dim, (int)rpw, Y);                                                              \
+    } while (0)
+    switch (in_dim) {
+    case 10: PW_DENSE_LAUNCH(10); break;
+    case 16: PW_DENSE_LAUNCH(16); break;
+    case 22: PW_DENSE_LAUNCH(22); break;
+    case 64: PW_DENSE_LAUNCH(64); break;
+    default: PW_DENSE_LAUNCH(0);
+    }
+#undef PW_DENSE_LAUNCH
     PW_HIP_CHECK(hipGetLastError());
     return PW_OK;
 }
