@@ -311,3 +311,23 @@ def test_hipgraph_rollout_equals_eager_rollout():
     for a, b in zip(rings[0][:4], rings[1][:4]):
         assert torch.equal(a, b)
     assert rings[0][4] == rings[1][4] and torch.equal(rings[0][5], rings[1][5])
+
+
+def test_pw_dense_matches_torch():
+    """pw_dense (weight-stationary skinny dense layer) vs torch fp32 for templated and runtime K, 64..256 outputs."""
+    import ctypes as C
+    from multiagent_rl_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(3)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for rows, K, out, relu in [(1, 16, 64, 1), (1000, 16, 64, 1), (777, 10, 64, 1), (513, 13, 128, 0),
+                               (300, 64, 256, 0), (4099, 22, 64, 1)]:
+        x, w, b = torch.randn(rows, K).cuda(), torch.randn(out, K).cuda() * 0.3, torch.randn(out).cuda()
+        y = torch.full((rows, out), float('nan'), device='cuda')
+        assert lib.pw_dense(p(x), p(w), p(b), rows, K, out, relu, p(y), stream) == 0
+        want = x.double() @ w.double().t() + b.double()
+        want = torch.relu(want) if relu else want
+        np.testing.assert_allclose(y.cpu().numpy(), want.float().cpu().numpy(), rtol=0, atol=2e-5)
+    assert lib.pw_dense(p(x), p(w), p(b), 10, 65, 64, 1, p(y), stream) == -1      # in_dim > 64
+    assert lib.pw_dense(p(x), p(w), p(b), 10, 16, 96, 1, p(y), stream) == -1      # out_dim not a multiple of 64
