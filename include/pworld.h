@@ -56,7 +56,8 @@ extern "C" {
 #define PW_MAX_AGENTS 64
 #define PW_MAX_LANDMARKS 64
 
-enum pw_scenario { PW_SIMPLE_SPREAD = 0, PW_SIMPLE_TAG = 1 };
+enum pw_scenario { PW_SIMPLE_SPREAD = 0, PW_SIMPLE_TAG = 1, PW_SIMPLE_REFERENCE = 2 };
+#define PW_DIM_C 10 /* simple_reference: world.dim_c communication symbols */
 enum pw_obs_mode { PW_OBS_LOCAL = 0, PW_OBS_FULL = 1 };
 enum pw_error {
     PW_OK = 0,
@@ -94,6 +95,7 @@ typedef struct pw_config {
 typedef struct pw_state_layout {
     size_t pos_x, pos_y, vel_x, vel_y, lm_x, lm_y, ep_step, ep_count; /* byte offsets */
     size_t total_bytes;
+    size_t comm, goal; /* simple_reference only: state.c [B*N*PW_DIM_C] f32, goal_b index [B*N] i32 */
 } pw_state_layout;
 
 /* Buffers of one step (T = 1) or of a T-step rollout (leading dimension T).
@@ -109,14 +111,18 @@ typedef struct pw_step_io {
     uint8_t *done;          /* [T,B,N] always 0 */
     uint8_t *terminal;      /* [T,B] */
     uint64_t *coll;         /* [T,B,N] */
+    const int32_t *act_comm; /* [T,B,N] communication symbol 0..PW_DIM_C-1; simple_reference with act_idx.
+                                There act_vec is [T,B,N,5+PW_DIM_C]: the concatenated MultiDiscrete action of
+                                experiments/run.py:39-41 (movement one-hot | communication vector) */
 } pw_step_io;
 
 int pw_version(void);
 const char *pw_last_error(void);
 
 /* Canonical upstream constants for a scenario: simple_spread (N agents, L = N
- * landmarks) or simple_tag (num_adversaries + good, L = 2). Replaces
- * Scenario.make_world() + World.__init__(). */
+ * landmarks), simple_tag (num_adversaries + good, L = 2) or simple_reference (2 speaking agents, L = 3;
+ * obs = [p_vel, landmark - pos, goal_b colour, other agent's c], D = 21). Replaces Scenario.make_world() +
+ * World.__init__(). */
 int pw_config_default(pw_config *cfg, int scenario, int num_envs, int num_agents,
                       int num_landmarks /* <0: scenario default */, int num_adversaries);
 
@@ -136,6 +142,11 @@ int pw_set_state(pw_handle *h, const float *pos, const float *vel, const float *
                  const int32_t *ep_step, const uint32_t *ep_count, void *stream);
 int pw_get_state(pw_handle *h, float *pos, float *vel, float *lm,
                  int32_t *ep_step, uint32_t *ep_count, void *stream);
+
+/* simple_reference only: the communication state (agent.state.c, [B,N,PW_DIM_C] f32) and each agent's goal
+ * landmark index (goal_b, [B,N] i32).  Either pointer may be NULL. */
+int pw_set_comm_state(pw_handle *h, const float *comm, const int32_t *goal, void *stream);
+int pw_get_comm_state(pw_handle *h, float *comm, int32_t *goal, void *stream);
 
 /* MultiAgentEnv.reset(): env_mask [B] u8 device or NULL (= all). Masked-in envs get
  * ep_count += 1, ep_step = 0, Philox initial state; obs (may be NULL) is written for ALL envs. */

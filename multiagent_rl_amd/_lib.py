@@ -12,9 +12,10 @@ LIB_PATH = os.path.join(HERE, 'libpworld.so')
 
 PW_MAX_AGENTS = 64
 PW_MAX_LANDMARKS = 64
-PW_SIMPLE_SPREAD, PW_SIMPLE_TAG = 0, 1
+PW_SIMPLE_SPREAD, PW_SIMPLE_TAG, PW_SIMPLE_REFERENCE = 0, 1, 2
+PW_DIM_C = 10
 PW_OBS_LOCAL, PW_OBS_FULL = 0, 1
-SCENARIOS = {'simple_spread': PW_SIMPLE_SPREAD, 'simple_tag': PW_SIMPLE_TAG}
+SCENARIOS = {'simple_spread': PW_SIMPLE_SPREAD, 'simple_tag': PW_SIMPLE_TAG, 'simple_reference': PW_SIMPLE_REFERENCE}
 
 
 class PwConfig(C.Structure):
@@ -36,12 +37,12 @@ class PwConfig(C.Structure):
 
 class PwStateLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
-                ('pos_x', 'pos_y', 'vel_x', 'vel_y', 'lm_x', 'lm_y', 'ep_step', 'ep_count', 'total_bytes')]
+                ('pos_x', 'pos_y', 'vel_x', 'vel_y', 'lm_x', 'lm_y', 'ep_step', 'ep_count', 'total_bytes', 'comm', 'goal')]
 
 
 class PwStepIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ('act_idx', 'act_vec', 'obs', 'final_obs', 'rew', 'rew_shared', 'done', 'terminal', 'coll')]
+                ('act_idx', 'act_vec', 'obs', 'final_obs', 'rew', 'rew_shared', 'done', 'terminal', 'coll', 'act_comm')]
 
 
 class PwReplayStore(C.Structure):
@@ -64,6 +65,8 @@ SIGNATURES = {
     'pw_bind_state': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pw_set_state': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
     'pw_get_state': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_void_p]),
+    'pw_set_comm_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pw_get_comm_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pw_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pw_observe': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'pw_reward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

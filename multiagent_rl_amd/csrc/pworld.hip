@@ -33,6 +33,7 @@
 #include "pw_common.hpp"
 #include "pw_kernels_spread.hpp"
 #include "pw_kernels_tag.hpp"
+#include "pw_kernels_reference.hpp"
 #include "pw_kernels_generic.hpp"
 #include "pw_kernels_replay.hpp"
 #include "pw_kernels_policy.hpp"
@@ -46,6 +47,8 @@ struct pw_handle {
     FastConsts fc;
     bool tag_fast;  // pw_tag_stream_kernel applies
     TagParams tp;   // its constant part (pointers are filled per launch)
+    float *comm;    // simple_reference planes inside the bound state block
+    int32_t *goal;
 };
 
 namespace {
@@ -54,8 +57,22 @@ int obs_dim_of(const pw_config &c)
 {
     const int N = c.num_agents, L = c.num_landmarks;
     if (c.scenario == PW_SIMPLE_SPREAD) return c.obs_mode == PW_OBS_FULL ? 4 + 2 * L + 4 * (N - 1) : 4 + 2 * L;
+    if (c.scenario == PW_SIMPLE_REFERENCE) return 2 + 2 * L + 3 + PW_DIM_C * (N - 1);
     const int G = N - c.num_adversaries;
     return 4 + 2 * L + 2 * (N - 1) + 2 * (c.num_adversaries > 0 ? G : G - 1);
+}
+
+RefParams ref_params(const pw_handle *h)
+{
+    const KParams &kp = h->kp;
+    RefParams R;
+    std::memset(&R, 0, sizeof(R));
+    R.B = kp.B; R.L = kp.L; R.D = kp.D; R.max_episode_len = kp.max_episode_len; R.auto_reset = kp.auto_reset;
+    R.force_discrete = kp.force_discrete; R.seed = kp.seed; R.env_id_base = kp.env_id_base;
+    R.dt = kp.dt; R.damp = kp.damp; R.mass = kp.mass; R.sens = kp.agent_sens[0];
+    R.pos_x = kp.pos_x; R.pos_y = kp.pos_y; R.vel_x = kp.vel_x; R.vel_y = kp.vel_y; R.lm_x = kp.lm_x; R.lm_y = kp.lm_y;
+    R.comm = h->comm; R.goal = h->goal; R.ep_step = kp.ep_step; R.ep_count = kp.ep_count;
+    return R;
 }
 
 template <typename F>
@@ -174,11 +191,20 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
     if (T < 1) return fail(PW_EINVAL, "num_steps must be >= 1");
     if ((io->act_idx == nullptr) == (io->act_vec == nullptr))
         return fail(PW_EINVAL, "exactly one of act_idx / act_vec must be given");
+    if (io->act_comm && h->cfg.scenario != PW_SIMPLE_REFERENCE)
+        return fail(PW_EINVAL, "act_comm only applies to simple_reference (the other scenarios' agents are silent)");
     if (io->obs && (reinterpret_cast<uintptr_t>(io->obs) & 15))
         return fail(PW_EINVAL, "obs must be 16-byte aligned");
     if (io->final_obs && (reinterpret_cast<uintptr_t>(io->final_obs) & 15))
         return fail(PW_EINVAL, "final_obs must be 16-byte aligned");
     const KParams &kp = h->kp;
+    if (h->cfg.scenario == PW_SIMPLE_REFERENCE) {
+        if (io->act_idx && !io->act_comm) return fail(PW_EINVAL, "simple_reference needs act_comm next to act_idx");
+        hipLaunchKernelGGL(pw_reference_rollout_kernel, dim3((kp.B + 31) / 32), dim3(kWave), 0,
+                           static_cast<hipStream_t>(stream), ref_params(h), *io, io->act_comm, T);
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
     const dim3 grid((kp.B + kp.epw - 1) / kp.epw), block(kWave);
     const size_t shmem = smem_bytes(kp);
     if (h->tag_fast && io->act_idx && io->obs && io->rew && io->rew_shared && io->done && io->terminal && !io->coll &&
@@ -286,6 +312,13 @@ int launch_aux(pw_handle *h, int mode, const uint8_t *env_mask, float *obs, floa
     if (int rc = check_ready(h)) return rc;
     if (obs && (reinterpret_cast<uintptr_t>(obs) & 15)) return fail(PW_EINVAL, "obs must be 16-byte aligned");
     const KParams &kp = h->kp;
+    if (h->cfg.scenario == PW_SIMPLE_REFERENCE) {
+        if (coll) return fail(PW_EINVAL, "simple_reference has no collisions");
+        hipLaunchKernelGGL(pw_reference_aux_kernel, dim3((kp.B + 31) / 32), dim3(kWave), 0,
+                           static_cast<hipStream_t>(stream), ref_params(h), mode, env_mask, obs, rew);
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
     const dim3 grid((kp.B + kp.epw - 1) / kp.epw), block(kWave);
     const size_t shmem = smem_bytes(kp);
     return dispatch(h, [&](auto scen, auto om) {
@@ -347,6 +380,17 @@ int pw_config_default(pw_config *cfg, int scenario, int num_envs, int num_agents
             cfg->agent_accel[i] = adv ? 3.0f : 4.0f;
             cfg->agent_max_speed[i] = adv ? 1.0f : 1.3f;
         }
+    } else if (scenario == PW_SIMPLE_REFERENCE) {
+        cfg->num_agents = 2;  // upstream simple_reference.make_world: two agents, three landmarks
+        cfg->num_landmarks = num_landmarks < 0 ? 3 : num_landmarks;
+        cfg->num_adversaries = 0;
+        cfg->landmark_collide = 0;
+        cfg->landmark_size = 0.05f;
+        for (int i = 0; i < 2; ++i) {
+            cfg->agent_size[i] = 0.05f;
+            cfg->agent_accel[i] = -1.0f;
+            cfg->agent_max_speed[i] = -1.0f;
+        }
     } else {
         return fail(PW_EINVAL, "unknown scenario");
     }
@@ -357,7 +401,10 @@ int pw_create(const pw_config *cfg, pw_handle **out)
 {
     if (!cfg || !out) return fail(PW_EINVAL, "null argument");
     if (cfg->struct_size != sizeof(pw_config)) return fail(PW_EINVAL, "pw_config.struct_size mismatch (ABI)");
-    if (cfg->scenario != PW_SIMPLE_SPREAD && cfg->scenario != PW_SIMPLE_TAG) return fail(PW_EINVAL, "unknown scenario");
+    if (cfg->scenario != PW_SIMPLE_SPREAD && cfg->scenario != PW_SIMPLE_TAG && cfg->scenario != PW_SIMPLE_REFERENCE)
+        return fail(PW_EINVAL, "unknown scenario");
+    if (cfg->scenario == PW_SIMPLE_REFERENCE && (cfg->num_agents != 2 || cfg->num_landmarks < 1 || cfg->num_landmarks > 3))
+        return fail(PW_EINVAL, "simple_reference is two agents and 1..3 landmarks");
     if (cfg->num_envs < 1) return fail(PW_EINVAL, "num_envs must be >= 1");
     if (cfg->num_agents < 1 || cfg->num_agents > PW_MAX_AGENTS) return fail(PW_EINVAL, "num_agents out of range [1, 64]");
     if (cfg->num_landmarks < 0 || cfg->num_landmarks > PW_MAX_LANDMARKS) return fail(PW_EINVAL, "num_landmarks out of range [0, 64]");
@@ -411,6 +458,11 @@ int pw_create(const pw_config *cfg, pw_handle **out)
     lo.lm_y = off; off = align_up(off + BL * 4, 256);
     lo.ep_step = off; off = align_up(off + (size_t)kp.B * 4, 256);
     lo.ep_count = off; off = align_up(off + (size_t)kp.B * 4, 256);
+    lo.comm = lo.goal = 0;
+    if (cfg->scenario == PW_SIMPLE_REFERENCE) {
+        lo.comm = off; off = align_up(off + BN * PW_DIM_C * 4, 256);
+        lo.goal = off; off = align_up(off + BN * 4, 256);
+    }
     lo.total_bytes = off;
     *out = h;
     return PW_OK;
@@ -458,6 +510,8 @@ int pw_bind_state(pw_handle *h, void *block)
     kp.lm_y = reinterpret_cast<float *>(b + h->layout.lm_y);
     kp.ep_step = reinterpret_cast<int32_t *>(b + h->layout.ep_step);
     kp.ep_count = reinterpret_cast<uint32_t *>(b + h->layout.ep_count);
+    h->comm = reinterpret_cast<float *>(b + h->layout.comm);
+    h->goal = reinterpret_cast<int32_t *>(b + h->layout.goal);
     h->bound = true;
     return PW_OK;
 }
@@ -483,6 +537,29 @@ int pw_get_state(pw_handle *h, float *pos, float *vel, float *lm, int32_t *ep_st
     if (n < (size_t)kp.B) n = kp.B;
     hipLaunchKernelGGL(pw_gather_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), kp, pos, vel, lm, ep_step, ep_count);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_set_comm_state(pw_handle *h, const float *comm, const int32_t *goal, void *stream)
+{
+    if (int rc = check_ready(h)) return rc;
+    if (h->cfg.scenario != PW_SIMPLE_REFERENCE) return fail(PW_EINVAL, "this scenario has no communication state");
+    const size_t n = (size_t)h->kp.B * 2 * PW_DIM_C;
+    hipLaunchKernelGGL(pw_reference_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), ref_params(h), 1, const_cast<float *>(comm),
+                       const_cast<int32_t *>(goal));
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_get_comm_state(pw_handle *h, float *comm, int32_t *goal, void *stream)
+{
+    if (int rc = check_ready(h)) return rc;
+    if (h->cfg.scenario != PW_SIMPLE_REFERENCE) return fail(PW_EINVAL, "this scenario has no communication state");
+    const size_t n = (size_t)h->kp.B * 2 * PW_DIM_C;
+    hipLaunchKernelGGL(pw_reference_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), ref_params(h), 0, comm, goal);
     PW_HIP_CHECK(hipGetLastError());
     return PW_OK;
 }

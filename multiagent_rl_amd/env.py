@@ -34,6 +34,23 @@ class Discrete(object):
         return 'Discrete(%d)' % self.n
 
 
+class MultiDiscrete(object):
+    """multiagent.multi_discrete.MultiDiscrete stand-in: ``.low`` / ``.high`` arrays.  main.py:52-54 reads
+    ``space.high + 1`` as the per-head action sizes; run.py:39-41 concatenates the heads' one-hots."""
+
+    def __init__(self, array_of_param_array):
+        self.low = np.array([x[0] for x in array_of_param_array])
+        self.high = np.array([x[1] for x in array_of_param_array])
+        self.num_discrete_space = self.low.shape[0]
+        self.shape = (self.num_discrete_space,)
+
+    def sample(self):
+        return [int(np.random.randint(lo, hi + 1)) for lo, hi in zip(self.low, self.high)]
+
+    def __repr__(self):
+        return 'MultiDiscrete' + str(self.num_discrete_space)
+
+
 class Box(object):
     def __init__(self, shape, dtype=np.float32):
         self.shape = tuple(shape)
@@ -64,7 +81,9 @@ def make_config(scenario_name, num_envs, num_agents=None, num_landmarks=None, nu
     if scenario_name not in _lib.SCENARIOS:
         raise ValueError('unsupported scenario: %r (supported: %s)' % (scenario_name, sorted(_lib.SCENARIOS)))
     scen = _lib.SCENARIOS[scenario_name]
-    if scen == _lib.PW_SIMPLE_TAG:
+    if scen == _lib.PW_SIMPLE_REFERENCE:
+        adv, n = 0, 2
+    elif scen == _lib.PW_SIMPLE_TAG:
         adv = 3 if num_adversaries is None else int(num_adversaries)
         if num_good is None:
             num_good = 1 if num_agents is None else int(num_agents) - adv
@@ -115,7 +134,10 @@ class BatchedParticleEnv(object):
         self.obs_dim = self.lib.pw_obs_dim(h)
         self.want_coll = want_coll
         self.observation_space = [Box((self.obs_dim,)) for _ in range(self.n)]
-        self.action_space = [Discrete(5) for _ in range(self.n)]
+        # simple_reference agents move AND speak: MultiDiscrete [5 movement | dim_c symbols]
+        self.dim_c = _lib.PW_DIM_C if self.cfg.scenario == _lib.PW_SIMPLE_REFERENCE else 0
+        self.action_space = [MultiDiscrete([[0, 4], [0, self.dim_c - 1]]) if self.dim_c else Discrete(5)
+                             for _ in range(self.n)]
         with torch.cuda.device(self.device):
             self._state = torch.zeros(self.lib.pw_state_bytes(h), dtype=torch.uint8, device=self.device)
         check(self.lib.pw_bind_state(h, _ptr(self._state)))
@@ -143,9 +165,14 @@ class BatchedParticleEnv(object):
         return t.to(device=self.device, dtype=dtype).contiguous()
 
     # -- state access (upstream entity.state.p_pos / p_vel)
-    def set_state(self, pos, vel=None, landmarks=None, ep_step=None, ep_count=None):
-        """pos/vel [B,N,2], landmarks [B,L,2]; None leaves that part unchanged (vel: zeros)."""
+    def set_state(self, pos, vel=None, landmarks=None, ep_step=None, ep_count=None, comm=None, goal=None):
+        """pos/vel [B,N,2], landmarks [B,L,2]; None leaves that part unchanged (vel: zeros).
+        simple_reference: comm [B,N,10] (agent.state.c) and goal [B,N] (landmark index of goal_b)."""
         B, N, L = self.num_envs, self.n, self.num_landmarks
+        if comm is not None or goal is not None:
+            cm, gl = self._dev(comm, torch.float32), self._dev(goal, torch.int32)
+            assert (cm is None or cm.shape == (B, N, self.dim_c)) and (gl is None or gl.shape == (B, N))
+            check(self.lib.pw_set_comm_state(self._h, _ptr(cm), _ptr(gl), self._stream()))
         pos = self._dev(pos, torch.float32)
         vel = torch.zeros(B, N, 2, device=self.device) if vel is None else self._dev(vel, torch.float32)
         lm = self._dev(landmarks, torch.float32)
@@ -165,6 +192,10 @@ class BatchedParticleEnv(object):
                    ep_count=torch.empty(B, dtype=torch.int32, device=self.device))
         check(self.lib.pw_get_state(self._h, _ptr(out['pos']), _ptr(out['vel']), _ptr(out['landmarks']),
                                     _ptr(out['ep_step']), _ptr(out['ep_count']), self._stream()))
+        if self.dim_c:
+            out['comm'] = self._f32(B, N, self.dim_c)
+            out['goal'] = torch.empty(B, N, dtype=torch.int32, device=self.device)
+            check(self.lib.pw_get_comm_state(self._h, _ptr(out['comm']), _ptr(out['goal']), self._stream()))
         return out
 
     # -- MultiAgentEnv.reset
@@ -206,8 +237,13 @@ class BatchedParticleEnv(object):
         actions = torch.as_tensor(actions)
         if actions.is_floating_point():
             a = actions.to(device=self.device, dtype=torch.float32).contiguous()
-            assert a.shape == lead + (5,), 'float actions must be [..., B, N, 5]'
+            assert a.shape == lead + (5 + self.dim_c,), 'float actions must be [..., B, N, %d]' % (5 + self.dim_c)
             io.act_vec = a.data_ptr()
+        elif self.dim_c:  # simple_reference: [..., B, N, 2] = (movement index, communication symbol)
+            assert actions.shape == lead + (2,), 'index actions must be [..., B, N, 2] (move, symbol)'
+            a = actions.to(device=self.device, dtype=torch.int32)
+            a = (a[..., 0].contiguous(), a[..., 1].contiguous())
+            io.act_idx, io.act_comm = a[0].data_ptr(), a[1].data_ptr()
         else:
             a = actions.to(device=self.device, dtype=torch.int32).contiguous()
             assert a.shape == lead, 'index actions must be [..., B, N]'
@@ -268,7 +304,7 @@ class MultiAgentEnv(object):
                  discrete_action=True, device=None, **kw):
         if scenario_name == 'simple_tag':
             kw.setdefault('num_agents', n)
-        else:
+        elif scenario_name == 'simple_spread':
             kw['num_agents'] = n
         self.batched = BatchedParticleEnv(scenario_name, 1, device=device, local_observation=local_observation,
                                           auto_reset=False, want_coll=benchmark, force_discrete_action=False,
@@ -286,7 +322,8 @@ class MultiAgentEnv(object):
             dims = [D] * self.n
         self._dims = dims
         self.observation_space = [Box((d,)) for d in dims]
-        self.action_space = [Discrete(5) for _ in range(self.n)]
+        self.action_space = list(self.batched.action_space)
+        self._act_width = 5 + self.batched.dim_c
         self.benchmark = benchmark
         self.discrete_action_space = discrete_action
         self.discrete_action_input = False
@@ -300,12 +337,21 @@ class MultiAgentEnv(object):
 
     def _reset_world(self):
         N, L = self.n, self._L
+        goal = None
+        if self.scenario_name == 'simple_reference':
+            # upstream reset_world: goal_b = np.random.choice(world.landmarks) for agent 0, then agent 1,
+            # BEFORE any position is drawn (same global stream)
+            idx = list(range(L))
+            goal = np.array([[np.random.choice(idx), np.random.choice(idx)]], dtype=np.int32)
         lo = 0.9 if self.scenario_name == 'simple_tag' else 1.0
         pos = np.stack([np.random.uniform(-1, +1, 2) for _ in range(N)]) if N else np.zeros((0, 2))
         lm = np.stack([np.random.uniform(-lo, +lo, 2) for _ in range(L)]) if L else np.zeros((0, 2))
         z = torch.zeros(1, dtype=torch.int32)
+        kw = {}
+        if goal is not None:
+            kw = dict(goal=torch.from_numpy(goal), comm=torch.zeros(1, N, self.batched.dim_c))
         self.batched.set_state(torch.from_numpy(pos[None].astype(np.float32)), None,
-                               torch.from_numpy(lm[None].astype(np.float32)), ep_step=z, ep_count=z)
+                               torch.from_numpy(lm[None].astype(np.float32)), ep_step=z, ep_count=z, **kw)
 
     def _rows(self, obs):
         obs = obs[0].cpu().numpy().astype(np.float64)
@@ -316,7 +362,7 @@ class MultiAgentEnv(object):
         return self._rows(self.batched.observe())
 
     def step(self, action_n):
-        a = np.stack([np.asarray(x, dtype=np.float32).reshape(5) for x in action_n])[None]
+        a = np.stack([np.asarray(x, dtype=np.float32).reshape(self._act_width) for x in action_n])[None]
         self._sync_force_discrete()
         obs, rew, done, info = self.batched.step(torch.from_numpy(a))
         rew_n = list(rew[0].cpu().numpy().astype(np.float64))  # np.float64 scalars, as upstream's reward()

@@ -34,19 +34,28 @@ class TimeDistributed(nn.Module):
 
 
 class ActorNetwork(nn.Module):
-    """Linear(D, 64) -> ReLU -> BiLSTM(64 -> 2x32) over the AGENT axis -> ReLU -> Linear(64, 5)."""
+    """Linear(D, 64) -> ReLU -> BiLSTM(64 -> 2x32) over the AGENT axis -> ReLU -> Linear(64, 5).
+    ``out_dim`` may be a list of two sizes (MultiDiscrete scenarios, main.py:52-54): then there are two
+    heads, ``dense2_1`` / ``dense2_2``, and ``forward`` returns the list of their logits."""
 
     def __init__(self, input_dim, out_dim):
         super().__init__()
         self.out_dim = out_dim
         self.dense1 = TimeDistributed(nn.Linear(input_dim, 64))
         self.bilstm = nn.LSTM(64, 32, num_layers=1, batch_first=True, bidirectional=True)
-        self.dense2 = TimeDistributed(nn.Linear(64, out_dim))
+        if type(out_dim) is list:
+            self.dense2_1 = TimeDistributed(nn.Linear(64, out_dim[0]))
+            self.dense2_2 = TimeDistributed(nn.Linear(64, out_dim[1]))
+        else:
+            self.dense2 = TimeDistributed(nn.Linear(64, out_dim))
 
     def forward(self, obs):
         hid = F.relu(self.dense1(obs))
         hid, _ = self.bilstm(hid, None)
-        return self.dense2(F.relu(hid))
+        hid = F.relu(hid)
+        if type(self.out_dim) is list:
+            return [self.dense2_1(hid), self.dense2_2(hid)]
+        return self.dense2(hid)
 
 
 class GumbelPolicy(object):
@@ -60,11 +69,16 @@ class GumbelPolicy(object):
     def logits(self, obs):
         return self.actor(obs)
 
+    def _sample(self, logits):
+        gumbels = -torch.empty_like(logits).exponential_(generator=self.generator).log()
+        return (logits + gumbels).argmax(dim=-1).to(torch.int32)
+
     @torch.no_grad()
     def __call__(self, obs):
         logits = self.actor(obs)
-        gumbels = -torch.empty_like(logits).exponential_(generator=self.generator).log()
-        return (logits + gumbels).argmax(dim=-1).to(torch.int32)
+        if isinstance(logits, (list, tuple)):  # MultiDiscrete: [B,N,2] = (movement index, communication symbol)
+            return torch.stack([self._sample(x) for x in logits], dim=-1)
+        return self._sample(logits)
 
 
 class FusedActor(object):

@@ -45,8 +45,8 @@ def run_test(env, actor, critic, Trainer, scenario_name=None, action_type='Discr
 def _loop(env, actor, critic, Trainer, scenario_name, action_type, cnt, arglist, memory, out_dir, log,
           evaluate, per_agent_transition):
     cfg = _default_arglist if arglist is None else arglist
-    if action_type != 'Discrete':
-        raise NotImplementedError('MultiDiscrete scenarios (communication actions) are outside the hot path')
+    if action_type not in ('Discrete', 'MultiDiscrete'):
+        raise ValueError('action_type must be Discrete or MultiDiscrete, got %r' % (action_type,))
     log('observation shape: ', env.observation_space)
     log('action shape: ', env.action_space)
     if memory is None:
@@ -65,8 +65,12 @@ def _loop(env, actor, critic, Trainer, scenario_name, action_type, cnt, arglist,
     t_start = time.time()
     log('Starting iterations...')
     while True:
-        action_n = learner.get_exploration_action(obs_n)[0]
-        action_n_env = [np.array(row) for row in action_n.tolist()]
+        if action_type == 'Discrete':
+            action_n = learner.get_exploration_action(obs_n)[0]
+            action_n_env = [np.array(row) for row in action_n.tolist()]
+        else:  # MultiDiscrete (run.py:39-41): one array per head; each agent's action is their concatenation
+            action_n = learner.get_exploration_action(obs_n)
+            action_n_env = [np.concatenate([u, c], axis=-1) for u, c in zip(action_n[0][0], action_n[1][0])]
         new_obs_n, rew_n, done_n, info_n = env.step(action_n_env)
         episode_step += 1
         done = all(done_n)
@@ -121,6 +125,8 @@ class BatchedRollout(object):
     Per step: ``actions = policy(obs)`` -> ``env.step(actions)`` (one fused launch) ->
     ``memory.add_batch(...)`` with the reference's transition tuple (obs, action, shared reward,
     next obs BEFORE reset, done) -- the same bookkeeping as run.py:44-65, vectorised over B.
+    (The device replay ring stores single-head action indices; MultiDiscrete rollouts run with
+    ``memory=None`` or their own sink.)
     Episode returns are accumulated on the device; nothing is read back inside ``collect``.
     """
 

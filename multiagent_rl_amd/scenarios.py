@@ -8,7 +8,7 @@ kernels.  ``make_batched_env`` is the [B x N] tensor form of the same env.
 """
 from .env import BatchedParticleEnv, MultiAgentEnv
 
-SUPPORTED = ('simple_spread', 'simple_tag')
+SUPPORTED = ('simple_spread', 'simple_tag', 'simple_reference')
 
 
 def make_env(scenario_name, n=None, local_observation=True, benchmark=False, discrete_action=True, **kw):
@@ -32,7 +32,7 @@ def make_batched_env(scenario_name, num_envs, n=None, local_observation=True, **
     if scenario_name == 'simple_tag':
         if n is not None:
             kw.setdefault('num_agents', n)
-    else:
+    elif scenario_name == 'simple_spread':
         kw['num_agents'] = n
     kw.setdefault('force_discrete_action', True)
     return BatchedParticleEnv(scenario_name, num_envs, local_observation=local_observation, **kw)

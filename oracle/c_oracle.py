@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, 'libpworld_oracle.so')
 
 PO_MAX_AGENTS = 64
-SIMPLE_SPREAD, SIMPLE_TAG = 0, 1
+SIMPLE_SPREAD, SIMPLE_TAG, SIMPLE_REFERENCE = 0, 1, 2
+DIM_C = 10
 OBS_LOCAL, OBS_FULL = 0, 1
 
 
@@ -88,6 +89,14 @@ def make_config(scenario='simple_spread', num_agents=3, num_landmarks=None, num_
             c.agent_size[i] = 0.075 if adv else 0.05
             c.agent_accel[i] = 3.0 if adv else 4.0
             c.agent_max_speed[i] = 1.0 if adv else 1.3
+    elif scenario == 'simple_reference':
+        c.scenario = SIMPLE_REFERENCE
+        N, L = 2, 3
+        c.landmark_collide = 0
+        c.landmark_size = 0.05
+        c.num_adversaries = 0
+        for i in range(N):
+            c.agent_size[i], c.agent_accel[i], c.agent_max_speed[i] = 0.05, -1.0, -1.0
     else:
         raise ValueError(scenario)
     c.num_agents, c.num_landmarks = N, L
@@ -173,6 +182,61 @@ class COracle(object):
             _p(ai, C.c_int32), _p(av, self.ct),
             _p(out['obs'], self.ct), _p(out['final_obs'], self.ct), _p(out['rew'], self.ct),
             _p(out['done'], C.c_uint8), _p(out['terminal'], C.c_uint8), _p(out['coll'], C.c_uint64))
+        assert rc == 0
+        return out
+
+
+class CRefOracle(object):
+    """simple_reference worlds (comm channel + goals) advanced by the C restatement."""
+
+    def __init__(self, cfg, B, dtype=np.float32):
+        assert cfg.scenario == SIMPLE_REFERENCE
+        self.cfg, self.B = cfg, B
+        self.dtype = np.dtype(dtype)
+        self.sfx = '_f32' if self.dtype == np.float32 else '_f64'
+        self.ct = C.c_float if self.dtype == np.float32 else C.c_double
+        self.N, self.L = cfg.num_agents, cfg.num_landmarks
+        self.D = obs_dim(cfg)
+        self.pos = np.zeros((B, self.N, 2), self.dtype)
+        self.vel = np.zeros((B, self.N, 2), self.dtype)
+        self.lm = np.zeros((B, self.L, 2), self.dtype)
+        self.comm = np.zeros((B, self.N, DIM_C), self.dtype)
+        self.goal = np.zeros((B, self.N), np.int32)
+        self.ep_step = np.zeros(B, np.int32)
+        self.ep_count = np.zeros(B, np.uint32)
+
+    def _state(self):
+        return (_p(self.pos, self.ct), _p(self.vel, self.ct), _p(self.lm, self.ct), _p(self.comm, self.ct),
+                _p(self.goal, C.c_int32))
+
+    def set_state(self, pos, vel, lm, comm, goal):
+        self.pos[...], self.vel[...], self.lm[...], self.comm[...], self.goal[...] = pos, vel, lm, comm, goal
+
+    def reset(self):
+        obs = np.zeros((self.B, self.N, self.D), self.dtype)
+        rc = getattr(lib(), 'po_ref_reset' + self.sfx)(C.byref(self.cfg), self.B, *self._state(),
+                                                       _p(self.ep_step, C.c_int32), _p(self.ep_count, C.c_uint32),
+                                                       _p(obs, self.ct))
+        assert rc == 0
+        return obs
+
+    def observe(self):
+        obs = np.zeros((self.B, self.N, self.D), self.dtype)
+        getattr(lib(), 'po_ref_observe' + self.sfx)(C.byref(self.cfg), self.B, *self._state(), _p(obs, self.ct))
+        return obs
+
+    def step(self, act_idx=None, act_comm=None, act_vec=None):
+        B, N, D = self.B, self.N, self.D
+        out = dict(obs=np.zeros((B, N, D), self.dtype), final_obs=np.zeros((B, N, D), self.dtype),
+                   rew=np.zeros((B, N), self.dtype), done=np.zeros((B, N), np.uint8), terminal=np.zeros(B, np.uint8))
+        ai = None if act_idx is None else np.ascontiguousarray(act_idx, np.int32).reshape(B, N)
+        ac = None if act_comm is None else np.ascontiguousarray(act_comm, np.int32).reshape(B, N)
+        av = None if act_vec is None else np.ascontiguousarray(act_vec, self.dtype).reshape(B, N, 5 + DIM_C)
+        rc = getattr(lib(), 'po_ref_step' + self.sfx)(
+            C.byref(self.cfg), B, *self._state(), _p(self.ep_step, C.c_int32), _p(self.ep_count, C.c_uint32),
+            _p(ai, C.c_int32), _p(ac, C.c_int32), _p(av, self.ct), _p(out['obs'], self.ct),
+            _p(out['final_obs'], self.ct), _p(out['rew'], self.ct), _p(out['done'], C.c_uint8),
+            _p(out['terminal'], C.c_uint8))
         assert rc == 0
         return out
 

@@ -435,6 +435,74 @@ class SimpleTag(object):
     observation_local = observation_full  # the reference patches no local obs for simple_tag
 
 
+class SimpleReference(object):
+    """Canonical simple_reference (main.py:24 lists it): two agents that move AND
+    speak; each must get the OTHER agent to the landmark only it knows (goal_b).  dim_c = 10, nobody
+    collides.  The observation is the one the reference patches in (experiments/scenarios.py:23-42), which is
+    also upstream's: [p_vel] + landmark_rel + [goal_b.color] + other agents' comm."""
+
+    name = 'simple_reference'
+    LANDMARK_COLORS = [(0.75, 0.25, 0.25), (0.25, 0.75, 0.25), (0.25, 0.25, 0.75)]
+
+    def make_world(self):
+        world = World()
+        world.dim_c = 10
+        world.collaborative = True
+        world.agents = [Agent() for _ in range(2)]
+        for i, agent in enumerate(world.agents):
+            agent.name = 'agent %d' % i
+            agent.collide = False
+        world.landmarks = [Landmark() for _ in range(3)]
+        for i, landmark in enumerate(world.landmarks):
+            landmark.name = 'landmark %d' % i
+            landmark.collide = False
+            landmark.movable = False
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for agent in world.agents:
+            agent.goal_a = None
+            agent.goal_b = None
+        # draw order on the global NumPy stream: two choices, then agents, then landmarks
+        world.agents[0].goal_a = world.agents[1]
+        world.agents[0].goal_b = np.random.choice(world.landmarks)
+        world.agents[1].goal_a = world.agents[0]
+        world.agents[1].goal_b = np.random.choice(world.landmarks)
+        for agent in world.agents:
+            agent.color = np.array([0.25, 0.25, 0.25])
+        for landmark, col in zip(world.landmarks, self.LANDMARK_COLORS):
+            landmark.color = np.array(col)
+        world.agents[0].goal_a.color = world.agents[0].goal_b.color
+        world.agents[1].goal_a.color = world.agents[1].goal_b.color
+        for agent in world.agents:
+            agent.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            agent.state.p_vel = np.zeros(world.dim_p)
+            agent.state.c = np.zeros(world.dim_c)
+        for landmark in world.landmarks:
+            landmark.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            landmark.state.p_vel = np.zeros(world.dim_p)
+
+    def reward(self, agent, world):
+        if agent.goal_a is None or agent.goal_b is None:
+            return 0.0
+        dist2 = np.sum(np.square(agent.goal_a.state.p_pos - agent.goal_b.state.p_pos))
+        return -dist2
+
+    def benchmark_data(self, agent, world):
+        return self.reward(agent, world)
+
+    def observation_full(self, agent, world):
+        goal_color = [np.zeros(world.dim_color), np.zeros(world.dim_color)]
+        if agent.goal_b is not None:
+            goal_color[1] = agent.goal_b.color
+        entity_pos = [e.state.p_pos - agent.state.p_pos for e in world.landmarks]
+        comm = [other.state.c for other in world.agents if other is not agent]
+        return np.concatenate([agent.state.p_vel] + entity_pos + [goal_color[1]] + comm)
+
+    observation_local = observation_full  # experiments/scenarios.py:23-42 is the same expression
+
+
 # ----------------------------------------------------------------------------
 # environment (U1, U2)
 # ----------------------------------------------------------------------------
@@ -447,6 +515,20 @@ class _Discrete(object):
 
     def __repr__(self):
         return 'Discrete(%d)' % self.n
+
+
+class _MultiDiscrete(object):
+    """Stand-in for multiagent.multi_discrete.MultiDiscrete: ``.low`` / ``.high`` arrays (main.py:52-54 reads
+    ``.high + 1`` as the per-head action sizes)."""
+
+    def __init__(self, array_of_param_array):
+        self.low = np.array([x[0] for x in array_of_param_array])
+        self.high = np.array([x[1] for x in array_of_param_array])
+        self.num_discrete_space = self.low.shape[0]
+        self.shape = (self.num_discrete_space,)
+
+    def __repr__(self):
+        return 'MultiDiscrete' + str(self.num_discrete_space)
 
 
 class _Box(object):
@@ -480,7 +562,15 @@ class OracleMultiAgentEnv(object):
         self.action_space = []
         self.observation_space = []
         for agent in self.agents:
-            self.action_space.append(_Discrete(world.dim_p * 2 + 1))
+            total = []
+            if agent.movable:
+                total.append(_Discrete(world.dim_p * 2 + 1))
+            if not agent.silent:
+                total.append(_Discrete(world.dim_c))
+            if len(total) > 1:
+                self.action_space.append(_MultiDiscrete([[0, sp.n - 1] for sp in total]))
+            else:
+                self.action_space.append(total[0])
             obs_dim = len(observation_callback(agent, self.world))
             self.observation_space.append(_Box((obs_dim,)))
             agent.action.c = np.zeros(self.world.dim_c)
@@ -537,7 +627,14 @@ class OracleMultiAgentEnv(object):
     def _set_action(self, action, agent, action_space, time=None):
         agent.action.u = np.zeros(self.world.dim_p)
         agent.action.c = np.zeros(self.world.dim_c)
-        action = [action]
+        if isinstance(action_space, _MultiDiscrete):
+            act, index = [], 0
+            for size in action_space.high - action_space.low + 1:
+                act.append(action[index:(index + size)])
+                index += size
+            action = act
+        else:
+            action = [action]
         if agent.movable:
             if self.discrete_action_input:
                 agent.action.u = np.zeros(self.world.dim_p)
@@ -564,6 +661,13 @@ class OracleMultiAgentEnv(object):
                 sensitivity = agent.accel
             agent.action.u *= sensitivity
             action = action[1:]
+        if not agent.silent:
+            if self.discrete_action_input:
+                agent.action.c = np.zeros(self.world.dim_c)
+                agent.action.c[action[0]] = 1.0
+            else:
+                agent.action.c = action[0]
+            action = action[1:]
         assert len(action) == 0
 
 
@@ -575,6 +679,9 @@ def make_oracle_env(scenario_name, n=None, local_observation=True, benchmark=Fal
         world = scenario.make_world(**world_kwargs) if n is None else scenario.make_world(num_agents=n, **world_kwargs)
     elif scenario_name == 'simple_tag':
         scenario = SimpleTag()
+        world = scenario.make_world(**world_kwargs)
+    elif scenario_name == 'simple_reference':
+        scenario = SimpleReference()
         world = scenario.make_world(**world_kwargs)
     else:
         raise ValueError('unsupported scenario: %r' % (scenario_name,))

@@ -30,7 +30,8 @@
 #define PO_EXPORT __attribute__((visibility("default")))
 #define PO_MAX_AGENTS 64
 #define PO_MAX_ENTITIES 192
-enum { PO_SIMPLE_SPREAD = 0, PO_SIMPLE_TAG = 1 };
+enum { PO_SIMPLE_SPREAD = 0, PO_SIMPLE_TAG = 1, PO_SIMPLE_REFERENCE = 2 };
+#define PO_DIM_C 10 /* simple_reference: world.dim_c */
 enum { PO_OBS_LOCAL = 0, PO_OBS_FULL = 1 };
 
 typedef struct po_config {
@@ -59,6 +60,7 @@ PO_EXPORT int po_obs_dim(const po_config *c)
     const int N = c->num_agents, L = c->num_landmarks;
     if (c->scenario == PO_SIMPLE_SPREAD)
         return c->obs_mode == PO_OBS_FULL ? 4 + 2 * L + 4 * (N - 1) : 4 + 2 * L;
+    if (c->scenario == PO_SIMPLE_REFERENCE) return 2 + 2 * L + 3 + PO_DIM_C * (N - 1);
     /* simple_tag: adversary rows are the widest (see all G good velocities) */
     const int G = N - c->num_adversaries;
     return 4 + 2 * L + 2 * (N - 1) + 2 * (c->num_adversaries > 0 ? G : G - 1);
@@ -138,6 +140,17 @@ PO_EXPORT void po_philox_xy(uint64_t seed, uint64_t env_id, uint32_t episode, ui
     *x = span * u0 + lo;
     *y = span * u1 + lo;
 }
+
+/* simple_reference: goal_b landmark of an agent = third Philox word of the agent's reset draw, mod L */
+PO_EXPORT int32_t po_philox_goal(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t entity, int32_t L)
+{
+    uint32_t ctr[4] = {entity, episode, (uint32_t)env_id, (uint32_t)(env_id >> 32)};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
+    po_philox4x32_10(ctr, key, r);
+    return (int32_t)(r[2] % (uint32_t)L);
+}
+
+static const float PO_LM_COLOR[3][3] = {{0.75f, 0.25f, 0.25f}, {0.25f, 0.75f, 0.25f}, {0.25f, 0.25f, 0.75f}};
 
 #define PO_CAT_(a, b) a##b
 #define PO_CAT(a, b) PO_CAT_(a, b)

@@ -9,6 +9,7 @@ third-party package, so these fixtures pin the BOUNDARY, not the arithmetic:
                       ReplayBuffer) with the CPU oracle env + a recording stub Trainer: the exact
                       call sequence, container types/shapes/dtypes, per-episode rewards, history keys.
   run_test_trace.json experiments.run.run_test the same way (load_models first, test_history_*.pkl with the memory).
+  run_multidiscrete_trace.json  experiments.run.run on simple_reference: the MultiDiscrete branch (run.py:39-41).
   replay_buffer.json  rls.replay_buffer.ReplayBuffer: ring semantics, make_index under random.seed,
                       encode shapes (NumPy-1 semantics; the literal call raises under NumPy >= 2).
   actor_forward.npz   rls.model.ac_network_multi_gumbel.ActorNetwork: state_dict, input, logits, and the
@@ -90,6 +91,32 @@ def make_run_test_trace():
     print('run_test_trace.json: %d events, files %s' % (len(env.trace), files))
 
 
+def make_multidiscrete_trace():
+    """experiments.run.run on simple_reference (MultiDiscrete branch, run.py:39-41)."""
+    from rls import arglist
+    from experiments.run import run
+    arglist.num_episodes, arglist.warmup_steps, arglist.update_rate, arglist.save_rate = 2, 10, 20, 2
+    arglist.max_episode_len = 25
+    np.random.seed(12345680)
+    env = RecordingEnv(po.make_oracle_env('simple_reference'))
+    env.env.force_discrete_action = True
+    np.random.seed(12345680)
+    StubTrainer.trace = env.trace
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        os.makedirs('Models')
+        try:
+            run(env, None, None, StubTrainer, 'simple_reference', 'MultiDiscrete', cnt=2)
+            hist = pickle.load(open('Models/history_simple_reference_2.pkl', 'rb'))
+        finally:
+            os.chdir(cwd)
+    out = dict(arglist=dict(num_episodes=2, warmup_steps=10, update_rate=20, save_rate=2, max_episode_len=25),
+               trace=env.trace, reward_episodes=[float(x) for x in hist['reward_episodes']])
+    json.dump(out, open(os.path.join(HERE, 'run_multidiscrete_trace.json'), 'w'), indent=0)
+    print('run_multidiscrete_trace.json: %d events' % len(env.trace))
+
+
 def make_replay():
     from rls.replay_buffer import ReplayBuffer
     rb = ReplayBuffer(5)
@@ -145,5 +172,6 @@ def make_actor():
 if __name__ == '__main__':
     make_run_trace()
     make_run_test_trace()
+    make_multidiscrete_trace()
     make_replay()
     make_actor()

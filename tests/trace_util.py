@@ -67,6 +67,7 @@ class StubTrainer(object):
 
     def __init__(self, actor, critic, memory, action_type='Discrete'):
         self.memory = memory
+        self.action_type = action_type
         self.rng = np.random.RandomState(7)
         StubTrainer.last = self
         self.trace.append(['trainer_init', action_type])
@@ -74,6 +75,9 @@ class StubTrainer(object):
     def get_exploration_action(self, obs_n):
         self.trace.append(['act', fingerprint(obs_n)])
         n = len(obs_n)
+        if self.action_type == 'MultiDiscrete':  # one array per head, as ddpg_gumbel_fix.py:101-105 returns
+            return [np.eye(5, dtype=np.float32)[self.rng.randint(0, 5, n)][None],
+                    np.eye(10, dtype=np.float32)[self.rng.randint(0, 10, n)][None]]
         return np.eye(5, dtype=np.float32)[self.rng.randint(0, 5, n)][None]
 
     def optimize(self):
