@@ -67,6 +67,9 @@ CASES = [
     dict(scenario='simple_spread', num_agents=12, num_envs=333),
     dict(scenario='simple_spread', num_agents=24, num_envs=65),
     dict(scenario='simple_spread', num_agents=48, num_envs=33),
+    dict(scenario='simple_spread', num_agents=12, num_envs=4096),           # configs[4] (C5) full size
+    dict(scenario='simple_spread', num_agents=24, num_envs=4096),
+    dict(scenario='simple_spread', num_agents=48, num_envs=4096),
     dict(scenario='simple_spread', num_agents=64, num_envs=5),              # maximum N
     dict(scenario='simple_spread', num_agents=1, num_envs=130),
     dict(scenario='simple_spread', num_agents=4, num_envs=200, obs_mode='full'),
