@@ -232,6 +232,11 @@ int pw_bilstm_forward(const float *G, const float *w_hh_fw, const float *w_hh_bw
 int pw_actor_head(const float *H, const float *w2, const float *b2, int64_t rows, uint64_t seed, uint64_t step,
                   const int64_t *step_dev /* device, or NULL */, float *logits, int32_t *act, void *stream);
 
+/* Test hook: y[i] = f(x[i]) with the DEVICE implementation of one math primitive, so its bits can be compared
+ * with a CPU implementation of pworld_math.h.  fn: 0 the kernels' fast correctly-rounded sqrt, 1 their
+ * branch-free softplus, 2 pw_softplus, 3 pw_exp, 4 sqrtf, 5 x / aux (IEEE division). */
+int pw_debug_math(int32_t fn, const float *x, float aux, float *y, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

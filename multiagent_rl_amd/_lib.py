@@ -87,6 +87,7 @@ SIGNATURES = {
     'pw_actor_head': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     'pw_episode_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pw_debug_math': (C.c_int, [C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     'pw_replay_gather': (C.c_int, [C.POINTER(PwReplayStore), C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_void_p]),
 }
 

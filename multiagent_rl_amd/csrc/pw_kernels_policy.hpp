@@ -175,6 +175,26 @@ __global__ void __launch_bounds__(256) pw_actor_head_kernel(const float *__restr
     }
 }
 
+// Test hook: evaluate one device math primitive element-wise so that tests can compare the exact bits
+// against the CPU contract (include/pworld_math.h, restated in oracle/pworld_oracle.c) over millions of
+// inputs.  fn: 0 sqrt_rn_fast, 1 softplus_branchless, 2 pw_softplus, 3 pw_exp, 4 sqrtf, 5 x / aux (IEEE)
+__global__ void pw_debug_math_kernel(const int fn, const float *x, const float aux, float *y, const long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float r;
+    switch (fn) {
+    case 0: r = sqrt_rn_fast(v); break;
+    case 1: r = softplus_branchless(v); break;
+    case 2: r = pw_softplus(v); break;
+    case 3: r = pw_exp(v); break;
+    case 4: r = sqrtf(v); break;
+    default: r = v / aux; break;
+    }
+    y[i] = r;
+}
+
 // Episode bookkeeping of the rollout loop (experiments/run.py:55-65, vectorised): return += shared
 // reward; on terminal the return is added to (sum, count) and cleared.  ONE workgroup with a
 // fixed-order tree reduction, so the statistics are bit-reproducible (no float atomics).

@@ -241,6 +241,13 @@ class CRefOracle(object):
         return out
 
 
+def math_v(fn, x, aux=1.0):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().po_math_v(C.c_int(fn), _p(x, C.c_float), C.c_float(aux), _p(y, C.c_float), C.c_long(x.size))
+    return y
+
+
 def philox4x32_10(counter, key):
     ctr = (C.c_uint32 * 4)(*counter)
     k = (C.c_uint32 * 2)(*key)

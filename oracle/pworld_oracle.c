@@ -114,6 +114,16 @@ PO_EXPORT float po_softplus_det_f32(float x)
     return m + po_log1p_det_f32(po_exp_det_f32(-ax));
 }
 
+/* vectorised forms for the device-math bit tests: fn 0/4 sqrtf, 1/2 softplus, 3 exp, 5 x / aux */
+PO_EXPORT void po_math_v(int fn, const float *x, float aux, float *y, long n)
+{
+    for (long i = 0; i < n; ++i) {
+        const float v = x[i];
+        y[i] = (fn == 0 || fn == 4) ? sqrtf(v) : (fn == 1 || fn == 2) ? po_softplus_det_f32(v)
+               : fn == 3 ? po_exp_det_f32(v) : v / aux;
+    }
+}
+
 /* ---- Philox4x32-10 (Salmon et al. 2011), reset RNG of the batched env ---- */
 PO_EXPORT void po_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 {
