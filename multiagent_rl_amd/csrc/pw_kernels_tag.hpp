@@ -237,4 +237,226 @@ __global__ void __launch_bounds__(kWave) pw_tag_stream_kernel(const TagParams P,
     P.ep_count[env] = ep_count;
 }
 
+// ------------------------------------------------------------------------------------------
+// Two-wave (duo) form of the simple_tag kernel, same split as pw_spread_duo_kernel: wave P does the
+// physics (action, near-pair forces against agents then landmarks, integrate + max_speed clamp, publish
+// {pos, vel} into the 3-slot LDS ring, near sets of the next step), wave O one step behind does the
+// collision masks, rewards, shared reward, terminal, observation rows and every store.  Each wave keeps
+// its own copy of the landmarks (both draw them from Philox at a reset), so the only cross-wave traffic is
+// the ring.  Used while the grid is small enough to be latency bound.
+// ------------------------------------------------------------------------------------------
+template <int NT, int AT, int LT, bool UNIT_MASS>
+__global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P, const int T)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int N = NT ? NT : P.N, A = AT >= 0 ? AT : P.A, L = LT ? LT : P.L, D = P.D;
+    float4 *s_ring = reinterpret_cast<float4 *>(smem_raw);                 // [3][64] {px, py, vx, vy}
+    uint32_t *s_mlo = reinterpret_cast<uint32_t *>(s_ring + 3 * kWave);    // [64] (wave O)
+    uint32_t *s_mhi = s_mlo + kWave;
+    float *s_rew = reinterpret_cast<float *>(s_mhi + kWave);               // [64] (wave O)
+    float2 *s_lm_p = reinterpret_cast<float2 *>(s_rew + kWave);            // [epw * L] wave P's landmarks
+    float2 *s_lm_o = s_lm_p + P.epw * L;                                   // [epw * L] wave O's landmarks
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = (int)threadIdx.x & 63;
+    int e_local = lane / N;
+    int a = lane - e_local * N;
+    int env = blockIdx.x * P.epw + e_local;
+    if (e_local >= P.epw || env >= P.B) {  // idle lane: shadow lane 0
+        e_local = 0; a = 0; env = blockIdx.x * P.epw;
+    }
+    const int base = e_local * N, me = base + a;
+    const int cls = a >= A ? 1 : 0;
+    const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
+    const size_t BN = (size_t)P.B * N;
+    const uint64_t env_id = P.env_id_base + (uint64_t)env;
+    int ep_step = P.ep_step[env];
+    uint32_t ep_count = P.ep_count[env];
+    int cur = 0;
+
+    if (wave == 0) {
+        // ================================ wave P: physics ================================
+        float2 *lmv = s_lm_p + e_local * L;
+        const float my_sens = P.sens[cls], my_fscale = P.fscale[cls], my_maxspeed = P.max_speed[cls];
+        const float dmin_adv = P.dist_min[cls][0], dmin_good = P.dist_min[cls][1], dmin_lm = P.dist_min_lm[cls];
+        const float nthr_adv = P.near_thr2[cls][0], nthr_good = P.near_thr2[cls][1], nthr_lm = P.near_thr2_lm[cls];
+        float px = P.pos_x[g], py = P.pos_y[g], vx = P.vel_x[g], vy = P.vel_y[g];
+        for (int l = a; l < L; l += N) lmv[l] = make_float2(P.lm_x[(size_t)env * L + l], P.lm_y[(size_t)env * L + l]);
+        s_ring[me] = make_float4(px, py, vx, vy);
+        wave_lds_sync();
+        uint64_t near_a = 0, near_l = 0;
+        auto near_pass = [&](const float4 *slot) {
+            near_a = 0; near_l = 0;
+#pragma unroll(NT > 0 ? NT : 1)
+            for (int j = 0; j < (NT ? NT : N); ++j) {
+                const float2 q = *reinterpret_cast<const float2 *>(slot + j);
+                const float dx = q.x - px, dy = q.y - py;
+                if (bits_near(dx * dx + dy * dy, j >= A ? nthr_good : nthr_adv)) near_a |= 1ull << j;
+            }
+            near_a &= ~(1ull << a);
+#pragma unroll(LT > 0 ? LT : 1)
+            for (int l = 0; l < (LT ? LT : L); ++l) {
+                const float2 q = lmv[l];
+                const float dx = q.x - px, dy = q.y - py;
+                if (bits_near(dx * dx + dy * dy, nthr_lm)) near_l |= 1ull << l;
+            }
+        };
+        near_pass(s_ring + base);
+        const float k = P.contact_margin, cf = P.contact_force, dt = P.dt, damp = P.damp, mass = P.mass;
+        int act_next = P.act[g];
+        for (int t = 0; t < T; ++t) {
+            const int ai = act_next;
+            {
+                const int tn = t + 1 < T ? t + 1 : t;
+                act_next = P.act[(size_t)tn * BN + g];
+            }
+            float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
+            float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
+            ux *= my_sens; uy *= my_sens;
+            if (my_fscale != 1.0f) { ux = my_fscale * ux; uy = my_fscale * uy; }
+            float fx = ux + 0.0f, fy = uy + 0.0f;
+            const float4 *pp = s_ring + cur * kWave + base;
+            for (uint64_t m = near_a; m; m &= m - 1) {
+                const int j = __builtin_ctzll(m);
+                const float2 q = *reinterpret_cast<const float2 *>(pp + j);
+                collision_force<true>(px, py, q.x, q.y, j >= A ? dmin_good : dmin_adv, k, cf, fx, fy);
+            }
+            for (uint64_t m = near_l; m; m &= m - 1) {
+                const float2 q = lmv[__builtin_ctzll(m)];
+                collision_force<true>(px, py, q.x, q.y, dmin_lm, k, cf, fx, fy);
+            }
+            vx = vx * damp; vy = vy * damp;
+            vx = vx + div_mass<UNIT_MASS>(fx, mass) * dt;
+            vy = vy + div_mass<UNIT_MASS>(fy, mass) * dt;
+            if (my_maxspeed >= 0.0f) {
+                const float speed = sqrtf(vx * vx + vy * vy);
+                if (speed > my_maxspeed) {
+                    vx = vx / speed * my_maxspeed;
+                    vy = vy / speed * my_maxspeed;
+                }
+            }
+            px = px + vx * dt;
+            py = py + vy * dt;
+            int nxt = cur + 1; nxt = nxt == 3 ? 0 : nxt;
+            s_ring[nxt * kWave + me] = make_float4(px, py, vx, vy);
+            ep_step += 1;
+            if (P.auto_reset && P.max_episode_len > 0 && ep_step >= P.max_episode_len) {
+                ep_count += 1;
+                ep_step = 0;
+                pw_reset_xy(P.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
+                vx = 0.f; vy = 0.f;
+                for (int l = a; l < L; l += N) {
+                    float x, y;
+                    pw_reset_xy(P.seed, env_id, ep_count, (uint32_t)(N + l), -0.9f, 0.9f, &x, &y);
+                    lmv[l] = make_float2(x, y);
+                }
+                nxt = nxt + 1; nxt = nxt == 3 ? 0 : nxt;
+                s_ring[nxt * kWave + me] = make_float4(px, py, 0.f, 0.f);
+            }
+            cur = nxt;
+            duo_barrier();
+            near_pass(s_ring + cur * kWave + base);
+        }
+        P.pos_x[g] = px; P.pos_y[g] = py;
+        P.vel_x[g] = vx; P.vel_y[g] = vy;
+        P.ep_step[env] = ep_step;
+        P.ep_count[env] = ep_count;
+    } else {
+        // ================================ wave O: outputs ================================
+        float2 *lmv = s_lm_o + e_local * L;
+        const float cthr_adv = P.coll_thr2[cls][0], cthr_good = P.coll_thr2[cls][1];
+        const uint64_t adv_bits = A >= 64 ? ~0ull : ((1ull << A) - 1ull);
+        for (int l = a; l < L; l += N) lmv[l] = make_float2(P.lm_x[(size_t)env * L + l], P.lm_y[(size_t)env * L + l]);
+        constexpr int kStoresPerStep = (NT > 0 && AT >= 0 && LT > 0) ? 4 + (4 + 2 * LT + 2 * (NT - 1) + 2 * (NT - AT)) / 2 : 0;
+        constexpr int kVm = kStoresPerStep < 63 ? kStoresPerStep : 63;
+        // observation row from a ring slot ({pos, vel} of every agent of the env) + this wave's landmarks
+        auto write_row = [&](float *o, const float4 *slot, float px, float py, float vx, float vy) {
+            float2 *o2 = reinterpret_cast<float2 *>(o);
+            int kk = 0;
+            o2[kk++] = make_float2(vx, vy);
+            o2[kk++] = make_float2(px, py);
+#pragma unroll(LT > 0 ? LT : 1)
+            for (int l = 0; l < (LT ? LT : L); ++l) {
+                const float2 q = lmv[l];
+                o2[kk++] = make_float2(q.x - px, q.y - py);
+            }
+            for (int j = 0; j < (NT ? NT : N); ++j) {
+                if (j == a) continue;
+                const float4 q = slot[j];
+                o2[kk++] = make_float2(q.x - px, q.y - py);
+            }
+            for (int j = (AT >= 0 ? AT : A); j < (NT ? NT : N); ++j) {
+                if (j == a) continue;
+                const float4 q = slot[j];
+                o2[kk++] = make_float2(q.z, q.w);
+            }
+            while (2 * kk < D) o2[kk++] = make_float2(0.0f, 0.0f);
+        };
+        for (int t = 0; t < T; ++t) {
+            const size_t tBN = (size_t)t * BN;
+            duo_barrier();
+            int nxt = cur + 1; nxt = nxt == 3 ? 0 : nxt;
+            const float4 *slot = s_ring + nxt * kWave + base;
+            const float4 mine = slot[a];
+            float px = mine.x, py = mine.y, vx = mine.z, vy = mine.w;
+            uint64_t coll = 0;
+#pragma unroll(NT > 0 ? NT : 1)
+            for (int j = 0; j < (NT ? NT : N); ++j) {
+                const float4 q = slot[j];
+                const float dx = q.x - px, dy = q.y - py;
+                if (dx * dx + dy * dy < (j >= A ? cthr_good : cthr_adv)) coll |= 1ull << j;
+            }
+            s_mlo[me] = (uint32_t)coll;
+            s_mhi[me] = (uint32_t)(coll >> 32);
+            wave_lds_sync();
+            float r = 0.0f;
+            if (cls) {
+                for (int q = 0; q < A; ++q)
+                    if ((coll >> q) & 1) r -= 10.0f;
+                r -= tag_bound(fabsf(px));
+                r -= tag_bound(fabsf(py));
+            } else {
+                for (int gj = A; gj < N; ++gj) {
+                    const uint64_t mg = ((uint64_t)s_mhi[base + gj] << 32) | s_mlo[base + gj];
+                    r += 10.0f * (float)__builtin_popcountll(mg & adv_bits);
+                }
+            }
+            s_rew[me] = r;
+            wave_lds_sync();
+            float acc = 0.0f;
+            for (int i = 0; i < N; ++i) acc += s_rew[base + i];
+            P.rew[tBN + g] = r;
+            P.done[tBN + g] = 0;
+            P.rew_shared[(size_t)t * P.B + env] = acc;
+            ep_step += 1;
+            const bool term = P.max_episode_len > 0 && ep_step >= P.max_episode_len;
+            P.terminal[(size_t)t * P.B + env] = term ? 1 : 0;
+            if (term && P.auto_reset) {
+                if (P.final_obs) write_row(P.final_obs + (tBN + g) * D, slot, px, py, vx, vy);
+                wave_lds_sync();
+                ep_count += 1;
+                ep_step = 0;
+                for (int l = a; l < L; l += N) {
+                    float x, y;
+                    pw_reset_xy(P.seed, env_id, ep_count, (uint32_t)(N + l), -0.9f, 0.9f, &x, &y);
+                    lmv[l] = make_float2(x, y);
+                }
+                nxt = nxt + 1; nxt = nxt == 3 ? 0 : nxt;
+                slot = s_ring + nxt * kWave + base;  // post-reset state published by P
+                const float4 fresh = slot[a];
+                px = fresh.x; py = fresh.y; vx = fresh.z; vy = fresh.w;
+            }
+            cur = nxt;
+            wave_lds_sync();
+            write_row(P.obs + (tBN + g) * D, slot, px, py, vx, vy);
+            if (kStoresPerStep > 0) __builtin_amdgcn_s_waitcnt((kVm & 0xF) | 0x0F70 | ((kVm >> 4) << 14));
+        }
+        for (int l = a; l < L; l += N) {
+            const float2 q = lmv[l];
+            P.lm_x[(size_t)env * L + l] = q.x;
+            P.lm_y[(size_t)env * L + l] = q.y;
+        }
+    }
+}
+
 }  // namespace

@@ -217,9 +217,16 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         hipStream_t st = static_cast<hipStream_t>(stream);
         const size_t shm = 2 * kWave * sizeof(float2) + 3 * kWave * sizeof(float) + (size_t)kp.epw * kp.L * sizeof(float2);
         const bool um = kp.mass == 1.0f;
+        // measured: +3.5 % at B = 8192 (820 workgroups), -3 % at B = 65536: only worth it on small grids
+        const bool duo = (grid.x <= 1024 && !std::getenv("PWORLD_NO_DUO")) || std::getenv("PWORLD_FORCE_DUO");
+        const size_t shm2 = 3 * kWave * sizeof(float4) + 3 * kWave * sizeof(float) + 2 * (size_t)kp.epw * kp.L * sizeof(float2);
+        const dim3 block2(2 * kWave);
 #define PW_TAG_LAUNCH(n, a, l)                                                                              \
     do {                                                                                                    \
-        if (um) hipLaunchKernelGGL((pw_tag_stream_kernel<n, a, l, true>), grid, block, shm, st, A, T);      \
+        if (duo) {                                                                                          \
+            if (um) hipLaunchKernelGGL((pw_tag_duo_kernel<n, a, l, true>), grid, block2, shm2, st, A, T);   \
+            else hipLaunchKernelGGL((pw_tag_duo_kernel<n, a, l, false>), grid, block2, shm2, st, A, T);     \
+        } else if (um) hipLaunchKernelGGL((pw_tag_stream_kernel<n, a, l, true>), grid, block, shm, st, A, T); \
         else hipLaunchKernelGGL((pw_tag_stream_kernel<n, a, l, false>), grid, block, shm, st, A, T);        \
     } while (0)
         if (kp.N == 6 && kp.A == 4 && kp.L == 2) PW_TAG_LAUNCH(6, 4, 2);        // BASELINE configs[2]

@@ -91,7 +91,8 @@ def kernel_path(request, monkeypatch):
     'stream'  pw_spread_stream_kernel (PWORLD_NO_DUO),
     'fast'    pw_spread_fast_kernel   (PWORLD_NO_STREAM, or when coll is requested),
     'generic' pw_rollout_kernel       (PWORLD_FORCE_GENERIC, read by pw_create).
-    simple_tag has two: pw_tag_stream_kernel ('duo'/'stream' params) and the generic kernel ('fast'/'generic')."""
+    simple_tag has three: pw_tag_duo_kernel ('duo'), pw_tag_stream_kernel ('stream') and the generic kernel
+    ('fast'/'generic')."""
     monkeypatch.delenv('PWORLD_FORCE_GENERIC', raising=False)
     monkeypatch.delenv('PWORLD_NO_STREAM', raising=False)
     monkeypatch.delenv('PWORLD_NO_DUO', raising=False)
