@@ -301,3 +301,14 @@ def test_c_oracle_auto_reset_and_terminal():
     cfg2 = co.make_config('simple_spread', 3, max_episode_len=5, auto_reset=True, seed=7, env_id_base=2)
     o2 = co.COracle(cfg2, 2, np.float32)
     assert np.array_equal(o2.reset(), first[2:])
+
+
+def test_oracle_self_regression_vectors():
+    """tests/golden/oracle_vectors.npz (made by make_oracle_vectors.py from this oracle) has not drifted."""
+    import os
+    from tests.golden.make_oracle_vectors import CASES, trajectory
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'oracle_vectors.npz'))
+    for i, (name, kw, seed) in enumerate(CASES):
+        tr = trajectory(name, kw, seed)
+        for k, v in tr.items():
+            np.testing.assert_allclose(v, g['%d/%s' % (i, k)], rtol=0, atol=1e-12, err_msg='%s %s' % (name, k))
