@@ -239,6 +239,36 @@ def main():
         pass
 
     finite = bool(torch.isfinite(outs['obs'][-1]).all().item()) and (K < 25 or bool(outs['terminal'][24].all().item()))
+    steps_per_launch_f = K / len(chunks)
+
+    # Reported next to the headline ("report policy-in-the-loop separately"): the same env with the
+    # reference's actor architecture in the loop -- policy forward + Gumbel sampling + pw_step + replay append +
+    # episode bookkeeping per step, captured in one hipGraph.  N = 1 only; never part of `value`.
+    policy_line = None
+    if world == 1 and rank == 0 and args.scenario == 'simple_spread' and not os.environ.get('PW_BENCH_NO_POLICY'):
+        try:
+            from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+            from multiagent_rl_amd.replay_buffer import ReplayBuffer
+            from multiagent_rl_amd.rollout import BatchedRollout
+            del outs, acts, plans
+            torch.cuda.empty_cache()
+            torch.manual_seed(12345678)
+            penv = BatchedParticleEnv('simple_spread', B, num_agents=N, max_episode_len=25, auto_reset=True,
+                                      seed=12345678)
+            ro = BatchedRollout(penv, FusedActor(ActorNetwork(penv.obs_dim, 5).to(dev).eval(), seed=12345678),
+                                ReplayBuffer(1e6, N, penv.obs_dim))
+            ro.capture(2)
+            ro.collect(50)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            ro.collect(500)
+            torch.cuda.synchronize()
+            tp = time.perf_counter() - tp
+            policy_line = dict(value=B * 500 / tp, unit='env-steps/s', us_per_step=tp / 500 * 1e6, steps=500,
+                               policy='FusedActor (reference ActorNetwork: Linear-BiLSTM-Linear, random init) + Gumbel sampling',
+                               loop='policy + pw_step + device replay append + episode stats in one hipGraph')
+        except Exception as e:  # the headline must not depend on this extra
+            policy_line = dict(error=repr(e)[:200])
 
     if rank == 0:
         value = world * B * K / elapsed
@@ -264,6 +294,7 @@ def main():
         }
         if world == 1:
             line['cpu_baseline'] = cpu_line
+            line['policy_in_loop'] = policy_line
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
