@@ -42,6 +42,17 @@ def main():
     summ = collections.OrderedDict(tag=a.tag, kernel=k['Name'], calls=int(k['Calls']),
                                    avg_ns=float(k['AverageNs']), min_ns=float(k['MinNs']),
                                    max_ns=float(k['MaxNs']), pct_of_gpu_time=float(k['Percentage']))
+    # per-dispatch trace: the timed launches are the LAST ceil(steps / chunk) dispatches of the kernel
+    kt = glob.glob(os.path.join(a.stats, '**', '*_kernel_trace.csv'), recursive=True)
+    if kt and a.bench:
+        line = [l for l in open(a.bench).read().splitlines() if l.startswith('{')][-1]
+        b = json.loads(line)
+        n_timed = max(1, round(b['steps'] * b['config']['global_batch'] / b['n_gpus'] / b['roofline']['env_steps_per_launch']))
+        durs = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+                      for r in csv.DictReader(open(kt[0])) if a.kernel in r['Kernel_Name'])
+        timed = [d for _, d in durs][-n_timed:]
+        summ['timed_launches'] = len(timed)
+        summ['timed_avg_ns'] = sum(timed) / len(timed)
     if a.fetch and a.write:
         fk, nf = pmc_mean(a.fetch, 'FETCH_SIZE', a.kernel)
         wk, nw = pmc_mean(a.write, 'WRITE_SIZE', a.kernel)
@@ -54,7 +65,7 @@ def main():
         b = json.loads(line)
         summ['bench'] = b
         summ['hip_event_launch_ms'] = b['roofline']['launch_ms']
-        summ['rocprof_vs_hip_event'] = summ['avg_ns'] * 1e-6 / b['roofline']['launch_ms']
+        summ['rocprof_vs_hip_event'] = summ.get('timed_avg_ns', summ['avg_ns']) * 1e-6 / b['roofline']['launch_ms']
     json.dump(summ, open(os.path.join(a.out, '%s_summary.json' % a.tag), 'w'), indent=1)
     print(json.dumps(summ, indent=1)[:1500])
 
