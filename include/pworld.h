@@ -227,6 +227,15 @@ int pw_episode_stats(const float *rew_shared, const uint8_t *terminal, int32_t B
  * x * [W_ih; W_ih_reverse]^T + (b_ih + b_hh) that pw_bilstm_forward consumes. */
 int pw_dense(const float *X, const float *W, const float *b, int64_t rows, int32_t in_dim, int32_t out_dim,
              int32_t relu, float *Y, void *stream);
+/* G [rows,256] = relu(X [rows,in_dim] * W1^T + b1) * Wih^T + bih in one launch on the matrix cores
+ * (v_mfma_f32_32x32x2_f32, exact float32): dense1 + F.relu + the input projections of both LSTM directions.
+ * The weights are consumed in MFMA fragment order: pw_actor_front_pack writes that image (w1 [64,in_dim],
+ * w_ih [256,64] = [W_ih; W_ih_reverse] row-major -> frag[pw_actor_front_pack_floats(in_dim)]) once per weight
+ * update; b_ih [256] = b_ih + b_hh per direction. */
+size_t pw_actor_front_pack_floats(int32_t in_dim);
+int pw_actor_front_pack(const float *w1, const float *w_ih, int32_t in_dim, float *frag, void *stream);
+int pw_actor_front(const float *X, const float *frag, const float *b1, const float *b_ih, int64_t rows, int32_t in_dim,
+                   float *G, void *stream);
 int pw_bilstm_forward(const float *G, const float *w_hh_fw, const float *w_hh_bw, int32_t B, int32_t N,
                       int32_t relu_out, float *H, void *stream);
 int pw_actor_head(const float *H, const float *w2, const float *b2, int64_t rows, uint64_t seed, uint64_t step,

@@ -126,6 +126,141 @@ __global__ void __launch_bounds__(256) pw_dense_kernel(const float *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused actor front end on the matrix cores: G = relu(X * W1^T + b1) * Wih^T + bih in ONE launch
+// (ActorNetwork.dense1 + F.relu + the input projections of both LSTM directions), exact float32
+// (v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain).
+//
+// Everything is computed TRANSPOSED so that the hidden activations never leave registers:
+//   stage 1   X1^T [64 hidden x 32 rows] = W1 [64 x D] * X^T [D x 32]      (2 tiles, D/2 k-steps)
+//   stage 2   G^T  [256 units x 32 rows] = Wih [256 x 64] * X1^T [64 x 32] (8 tiles, 32 k-steps each)
+// A 32x32 accumulator tile has its column (here: the data row) on the lane and its rows (hidden unit)
+// in the 16 registers, which is exactly the B-operand layout of the next MFMA when that MFMA sums over
+// the tile's ROW index: register `reg` of lane half h holds hidden unit hloc(reg) + 4h, so one MFMA
+// k-step consumes the pair {hloc(reg), hloc(reg) + 4} and the A operand (weights) is simply fetched in
+// that k order.  Weights are pre-swizzled into LDS in fragment order once per workgroup; the output tile
+// is transposed through a 33-float-stride LDS patch so that G leaves as 128-byte row segments.
+// One wave owns 32 data rows; a workgroup of 4 waves shares the 64 KB + 4 KB of weight fragments.
+// ------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// fragment order of the stage-2 weights: [8 n][2 m][4 rq][64 lane] float4, element e of lane ln =
+// Wih[n*32 + (ln & 31)][m*32 + 8*rq + 4*(ln >> 5) + e]; stage 1: [2 m][S1][64 lane], lane ln of step s =
+// W1[m*32 + (ln & 31)][2s + (ln >> 5)] (0 past in_dim), S1 = the k-step count rounded up to a multiple of 4 (the
+// kernel is instantiated per S1 / 4 so that stage 1 is straight-line code; a zero k-step adds +0 to the
+// accumulators, which never hold -0).  pw_actor_front_pack writes both once per weight update.
+__global__ void pw_actor_front_pack_kernel(const float *__restrict__ w1, const float *__restrict__ wih, const int D,
+                                           float *__restrict__ frag)
+{
+    const int S1 = ((D + 7) >> 3) * 4;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < 8 * 2 * 4 * 64) {
+        const int ln = f & 63, rq = (f >> 6) & 3, m = (f >> 8) & 1, n = f >> 9;
+        const int u = n * 32 + (ln & 31), h = m * 32 + 8 * rq + 4 * (ln >> 5);
+        reinterpret_cast<float4 *>(frag)[f] = *reinterpret_cast<const float4 *>(wih + (size_t)u * 64 + h);
+    }
+    if (f < 2 * S1 * 64) {
+        const int ln = f & 63, sidx = (f >> 6) % S1, m = (f >> 6) / S1;
+        const int k = 2 * sidx + (ln >> 5);
+        frag[8 * 2 * 4 * 64 * 4 + f] = k < D ? w1[(size_t)(m * 32 + (ln & 31)) * D + k] : 0.0f;
+    }
+}
+
+template <int S1C>
+__global__ void __launch_bounds__(256) pw_actor_front_kernel(const float *__restrict__ X, const float *__restrict__ frag,
+                                                             const float *__restrict__ b1, const float *__restrict__ bih,
+                                                             const long rows, const int D, float *__restrict__ G)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int S1 = 4 * S1C;                                      // stage-1 k-steps (K = 2 each), zero padded
+    float4 *f_wih = reinterpret_cast<float4 *>(smem_raw);            // [8 n][2 m][4 rq][64 lane] float4 (e = reg & 3)
+    float *f_w1 = reinterpret_cast<float *>(f_wih + 8 * 2 * 4 * 64);  // [2 m][S1][64 lane]
+    float *s_b1 = f_w1 + 2 * S1 * 64;                                // [64]
+    float *s_bih = s_b1 + 64;                                        // [256]
+    float *s_t = s_bih + 256;                                        // [4 waves][32][33] transpose patches
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    // ---- weight fragments -> LDS (once per workgroup): a linear, fully coalesced copy of the packed image
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(frag);
+        const int n4 = 8 * 2 * 4 * 64 + (2 * S1 * 64) / 4;  // f_w1 follows f_wih contiguously, (2*S1*64) % 4 == 0
+        for (int f = tid; f < n4; f += 256) f_wih[f] = src[f];
+    }
+    if (tid < 64) s_b1[tid] = b1[tid];
+    s_bih[tid] = bih[tid];
+    __syncthreads();
+
+    const long row0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (row0 >= rows) return;
+    long myrow = row0 + col;
+    const bool row_ok = myrow < rows;
+    if (!row_ok) myrow = rows - 1;
+    // ---- stage 1: two 32x32 tiles of X1^T, bias + ReLU applied in registers
+    f32x16 acc1[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[m][r] = 0.0f;
+    const float *xr = X + (size_t)myrow * D;
+    float xb[S1];  // this lane's B operands of all k-steps, fetched before the first MFMA (loads in flight together)
+#pragma unroll
+    for (int sidx = 0; sidx < S1; ++sidx) {
+        const int k = 2 * sidx + half;
+        xb[sidx] = k < D ? xr[k] : 0.0f;                           // B[kk = half][j = col] = X[row][k]
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < S1; ++sidx) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+            acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_w1[(m * S1 + sidx) * 64 + lane], xb[sidx], acc1[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[m][r] = fmaxf(acc1[m][r] + s_b1[m * 32 + mfma_row(r, half)], 0.0f);
+
+    // ---- stage 2: eight 32x32 tiles of G^T, one at a time (acc1 stays resident as the B operands)
+    float *patch = s_t + wave * 32 * 33;
+#pragma unroll 1
+    for (int n = 0; n < 8; ++n) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const float4 a = f_wih[((n * 2 + m) * 4 + rq) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc1[m][4 * rq + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc1[m][4 * rq + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, acc1[m][4 * rq + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, acc1[m][4 * rq + 3], acc, 0, 0, 0);
+            }
+        }
+        // transpose: lane (col = data row, half) holds units mfma_row(r, half); patch[row][unit], stride 33
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[col * 33 + mfma_row(r, half)] = acc[r];
+        wave_lds_sync();
+        // each lane emits 4 float4 = 16 consecutive units of one row: rows (lane >> 1) and halves (lane & 1)
+        {
+            const int rr = lane >> 1, u0 = (lane & 1) * 16;
+            const long orow = row0 + rr;
+            if (orow < rows) {
+                float4 *dst = reinterpret_cast<float4 *>(G + (size_t)orow * 256 + n * 32 + u0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float *src = patch + rr * 33 + u0 + 4 * q;
+                    const float *bb = s_bih + n * 32 + u0 + 4 * q;
+                    dst[q] = make_float4(src[0] + bb[0], src[1] + bb[1], src[2] + bb[2], src[3] + bb[3]);
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
 // Output head: logits = H * W2^T + b2 (64 -> 5) for one (env, agent) row per lane, then the hard
 // Gumbel-softmax sample of ddpg_gumbel_fix.py:109-116 as argmax(logits + g), g = -log(-log(u)),
 // u from Philox4x32-10 keyed (seed; step, row) -- the action stays an int32 index in HBM.

@@ -775,4 +775,47 @@ int pw_debug_math(int32_t fn, const float *x, float aux, float *y, int64_t n, vo
     return PW_OK;
 }
 
+size_t pw_actor_front_pack_floats(int32_t in_dim) { return (size_t)8 * 2 * 4 * 64 * 4 + (size_t)2 * (((in_dim + 7) / 8) * 4) * 64; }
+
+int pw_actor_front_pack(const float *w1, const float *w_ih, int32_t in_dim, float *frag, void *stream)
+{
+    if (!w1 || !w_ih || !frag) return fail(PW_EINVAL, "null argument");
+    if (in_dim < 1 || in_dim > 64) return fail(PW_EINVAL, "in_dim must be in [1, 64]");
+    if ((reinterpret_cast<uintptr_t>(w_ih) | reinterpret_cast<uintptr_t>(frag)) & 15)
+        return fail(PW_EINVAL, "w_ih and frag must be 16-byte aligned");
+    hipLaunchKernelGGL(pw_actor_front_pack_kernel, dim3(16), dim3(256), 0, static_cast<hipStream_t>(stream), w1, w_ih, in_dim, frag);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_actor_front(const float *X, const float *frag, const float *b1, const float *b_ih, int64_t rows, int32_t in_dim,
+                   float *G, void *stream)
+{
+    if (!X || !frag || !b1 || !b_ih || !G) return fail(PW_EINVAL, "null argument");
+    if (rows < 1 || in_dim < 1 || in_dim > 64) return fail(PW_EINVAL, "in_dim must be in [1, 64]");
+    if ((reinterpret_cast<uintptr_t>(frag) | reinterpret_cast<uintptr_t>(G)) & 15)
+        return fail(PW_EINVAL, "frag and G must be 16-byte aligned");
+    const int S1C = (in_dim + 7) / 8, S1 = 4 * S1C;
+    const size_t shm = (size_t)8 * 2 * 4 * 64 * sizeof(float4) + (size_t)(2 * S1 * 64 + 64 + 256 + 4 * 32 * 33) * sizeof(float);
+    const long tiles = (rows + 127) / 128;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static bool attr_set[9] = {};
+#define PW_FRONT(C)                                                                                                      \
+    case C:                                                                                                              \
+        if (!attr_set[C]) { /* > 64 KB of dynamic LDS needs the opt-in */                                                \
+            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_actor_front_kernel<C>),                   \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+            attr_set[C] = true;                                                                                          \
+        }                                                                                                                \
+        hipLaunchKernelGGL(pw_actor_front_kernel<C>, dim3((unsigned)tiles), dim3(256), shm, st, X, frag, b1, b_ih,       \
+                           (long)rows, in_dim, G);                                                                       \
+        break;
+    switch (S1C) {
+        PW_FRONT(1) PW_FRONT(2) PW_FRONT(3) PW_FRONT(4) PW_FRONT(5) PW_FRONT(6) PW_FRONT(7) PW_FRONT(8)
+    }
+#undef PW_FRONT
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
 }  // extern "C"

@@ -82,20 +82,23 @@ class GumbelPolicy(object):
 
 
 class FusedActor(object):
-    """The same ActorNetwork evaluated with one rocBLAS GEMM + three launches of libpworld (``pw_dense``,
+    """The same ActorNetwork evaluated with three launches of libpworld (``pw_actor_front``,
     ``pw_bilstm_forward``, ``pw_actor_head``) instead of MIOpen's ~45-kernel RNN path.
 
-    Weights are snapshotted from ``actor`` (call ``refresh()`` after the learner updates it).  dense1 + ReLU
-    (K = D, tiny) uses a weight-stationary kernel; the input projections of both LSTM directions are one
-    [B*N, 64] x [64, 256] rocBLAS GEMM; the recurrence over the agent axis and the output head + Gumbel
-    sampling run in their own kernels; all float32.
+    Weights are snapshotted from ``actor`` (call ``refresh()`` after the learner updates it).  dense1 + ReLU and
+    the input projections of both LSTM directions are one hand-written float32 MFMA kernel (the [B*N, 64]
+    hidden activations stay in registers between the two products); the recurrence over the agent axis and the
+    output head + Gumbel sampling run in their own kernels; all float32.  ``PW_ACTOR_NO_MFMA=1`` selects the
+    three-launch form (weight-stationary dense1 + rocBLAS GEMM) for comparison.
     """
 
     def __init__(self, actor, seed=0):
         import ctypes as C
         from . import _lib
         self._C, self._lib_mod, self.lib = C, _lib, _lib.load()
+        import os
         self.actor, self.seed, self.calls = actor, int(seed), 0
+        self.use_mfma_front = not os.environ.get('PW_ACTOR_NO_MFMA')
         self.refresh()
         self._step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)  # Philox step (hipGraph mode)
         self.graph_mode = False
@@ -109,12 +112,18 @@ class FusedActor(object):
         assert dev.type == 'cuda', 'FusedActor needs the actor on the GPU (no CPU fallback)'
         f = lambda t: t.detach().to(torch.float32).contiguous()  # noqa: E731
         self.w1, self.b1 = f(lin1.weight), f(lin1.bias)                                          # [64, D]
-        self.wih_t = f(torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], 0).t())       # [64, 256]
+        self.wih = f(torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse], 0))             # [256, 64]
+        self.wih_t = f(self.wih.t())                                                            # [64, 256]
         self.bih = f(torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0,
                                 lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse], 0))         # [256]
         self.whh_f, self.whh_r = f(lstm.weight_hh_l0), f(lstm.weight_hh_l0_reverse)             # [128, 32]
         self.w2, self.b2 = f(lin2.weight), f(lin2.bias)                                         # [5, 64]
         self.device = dev
+        D = self.w1.shape[1]
+        self.frag = torch.empty(self.lib.pw_actor_front_pack_floats(D), dtype=torch.float32, device=dev)
+        cp = lambda t: self._C.c_void_p(t.data_ptr())  # noqa: E731
+        self._lib_mod.check(self.lib.pw_actor_front_pack(cp(self.w1), cp(self.wih), D, cp(self.frag),
+                                                         self._C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
     def _stream(self):
         return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -125,13 +134,18 @@ class FusedActor(object):
         B, N, D = obs.shape
         x = obs.reshape(B * N, D).to(torch.float32).contiguous()
         p = lambda t: self._C.c_void_p(t.data_ptr())  # noqa: E731
-        x1 = torch.empty(B * N, 64, dtype=torch.float32, device=self.device)
         h = torch.empty(B, N, 64, dtype=torch.float32, device=self.device)
-        # dense1 + ReLU: K = D is tiny, the weight-stationary kernel beats GEMM + ReLU launches 3x (5.5 vs 16.5 us)
-        self._lib_mod.check(self.lib.pw_dense(p(x), p(self.w1), p(self.b1), B * N, D, 64, 1, p(x1), self._stream()))
-        # input projections of both directions: a real [B*N, 64] x [64, 256] GEMM -> rocBLAS (18 us; the
-        # scalar-fed kernel needs 60 us at K = 64: one 64-float row per wave in flight is latency-bound)
-        g = torch.addmm(self.bih, x1, self.wih_t)            # [B*N, 256] = [B,N,2,128]
+        if self.use_mfma_front:
+            # dense1 + ReLU + both input projections in ONE launch on the matrix cores (exact f32 MFMA);
+            # the hidden activations never leave registers
+            g = torch.empty(B * N, 256, dtype=torch.float32, device=self.device)     # [B,N,2,128]
+            self._lib_mod.check(self.lib.pw_actor_front(p(x), p(self.frag), p(self.b1), p(self.bih), B * N, D, p(g),
+                                                        self._stream()))
+        else:
+            # the same in three launches: weight-stationary dense1 + ReLU, then a rocBLAS GEMM
+            x1 = torch.empty(B * N, 64, dtype=torch.float32, device=self.device)
+            self._lib_mod.check(self.lib.pw_dense(p(x), p(self.w1), p(self.b1), B * N, D, 64, 1, p(x1), self._stream()))
+            g = torch.addmm(self.bih, x1, self.wih_t)        # [B*N, 256] = [B,N,2,128]
         self._lib_mod.check(self.lib.pw_bilstm_forward(p(g), p(self.whh_f), p(self.whh_r), B, N, 1, p(h),
                                                        self._stream()))
         return h

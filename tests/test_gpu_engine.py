@@ -331,3 +331,39 @@ def test_pw_dense_matches_torch():
         np.testing.assert_allclose(y.cpu().numpy(), want.float().cpu().numpy(), rtol=0, atol=2e-5)
     assert lib.pw_dense(p(x), p(w), p(b), 10, 65, 64, 1, p(y), stream) == -1      # in_dim > 64
     assert lib.pw_dense(p(x), p(w), p(b), 10, 16, 96, 1, p(y), stream) == -1      # out_dim not a multiple of 64
+
+
+def test_pw_actor_front_mfma_matches_torch():
+    """G = relu(X W1^T + b1) Wih^T + bih on the matrix cores vs float64 torch, several in_dims and ragged row counts."""
+    import ctypes as C
+    from multiagent_rl_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(5)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for rows, D in [(1, 16), (31, 16), (128, 16), (24576, 16), (1000, 10), (333, 21), (129, 22), (64, 1), (200, 64)]:
+        x = (torch.randn(rows, D) * 2).cuda()
+        w1, b1 = (torch.randn(64, D) * 0.4).cuda(), torch.randn(64).cuda()
+        wih, bih = (torch.randn(256, 64) * 0.2).cuda(), torch.randn(256).cuda()
+        g = torch.full((rows, 256), float('nan'), device='cuda')
+        frag = torch.empty(lib.pw_actor_front_pack_floats(D), device='cuda')
+        assert lib.pw_actor_front_pack(p(w1), p(wih), D, p(frag), stream) == 0
+        assert lib.pw_actor_front(p(x), p(frag), p(b1), p(bih), rows, D, p(g), stream) == 0
+        want = torch.relu(x.double() @ w1.double().t() + b1.double()) @ wih.double().t() + bih.double()
+        np.testing.assert_allclose(g.cpu().numpy(), want.float().cpu().numpy(), rtol=0, atol=5e-5,
+                                   err_msg='rows=%d D=%d' % (rows, D))
+    # asymmetric-weight identity check (catches row/col swaps): W1 = [I | 0], Wih picks hidden unit (u % 64)
+    D = 16
+    x = torch.rand(70, D).cuda() + 0.5
+    w1 = torch.zeros(64, D).cuda(); w1[:D] = torch.eye(D).cuda()
+    wih = torch.zeros(256, 64).cuda(); wih[torch.arange(256), torch.arange(256) % 64] = torch.arange(1, 257).float().cuda()
+    g = torch.empty(70, 256, device='cuda')
+    z = torch.zeros(256).cuda()
+    frag = torch.empty(lib.pw_actor_front_pack_floats(D), device='cuda')
+    assert lib.pw_actor_front_pack(p(w1), p(wih), D, p(frag), stream) == 0
+    assert lib.pw_actor_front(p(x), p(frag), p(z[:64].contiguous()), p(z), 70, D, p(g), stream) == 0
+    want = torch.zeros(70, 256).cuda()
+    for u in range(256):
+        if u % 64 < D:
+            want[:, u] = x[:, u % 64] * (u + 1)
+    assert torch.equal(g, want)
