@@ -189,6 +189,15 @@ int pw_replay_add(const pw_replay_store *st, int64_t start, const int64_t *start
 int pw_counter_add(int64_t *counter, int64_t delta, int64_t modulo, void *stream);
 /* sample_index() / _encode_sample(): gather rows idx[0..b) into dense batch tensors;
  * out_act is one-hot f32 [b,N,5] exactly as the reference's trainer consumes it. */
+/* pw_replay_add + pw_episode_stats in ONE launch (the last launch of a captured rollout step).  The ring
+ * position comes from `start` or, if non-NULL, *start_dev; (position + B) % capacity is written to
+ * *next_start_dev (optional; must not alias start_dev: double-buffer the cursor) and *step_counter (optional,
+ * e.g. the policy's Philox step) is incremented.  Episode-return arithmetic is identical to pw_episode_stats. */
+int pw_replay_add_tail(const pw_replay_store *st, int64_t start, const int64_t *start_dev, int64_t *next_start_dev,
+                       int32_t B, const float *obs, const int32_t *act_idx, const float *rew_shared,
+                       const float *next_obs, const float *final_obs, const uint8_t *terminal, const float *done,
+                       float *episode_return, double *finished_sum, int64_t *finished_count, int64_t *step_counter,
+                       void *stream);
 int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b,
                      float *out_obs, float *out_act, float *out_rew, float *out_next_obs,
                      float *out_done, void *stream);
@@ -212,6 +221,12 @@ int pw_exchange(const pw_replay_store *st, int64_t start, int32_t R_in, const fl
  * *finished_count += 1, return cleared.  Deterministic (single workgroup, fixed-order reduction). */
 int pw_episode_stats(const float *rew_shared, const uint8_t *terminal, int32_t B, float *episode_return,
                      double *finished_sum, int64_t *finished_count, void *stream);
+/* pw_episode_stats that also advances up to two device-side counters (NULL to skip; value = (value + delta) %
+ * modulo, modulo 0 = no wrap) -- e.g. the replay ring cursor and the policy's Philox step of a captured
+ * rollout step, whose earlier launches have all read them by the time this one runs (stream order). */
+int pw_rollout_tail(const float *rew_shared, const uint8_t *terminal, int32_t B, float *episode_return,
+                    double *finished_sum, int64_t *finished_count, int64_t *counter0, int64_t delta0, int64_t modulo0,
+                    int64_t *counter1, int64_t delta1, int64_t modulo1, void *stream);
 
 /* ---- action producer (rls/model/ac_network_multi_gumbel.py:24-67, ddpg_gumbel_fix.py:86-116) --------
  * The actor is Linear(D,64)-ReLU-BiLSTM(64->2x32 over the AGENT axis)-ReLU-Linear(64,5).  The two input
@@ -240,6 +255,15 @@ int pw_bilstm_forward(const float *G, const float *w_hh_fw, const float *w_hh_bw
                       int32_t relu_out, float *H, void *stream);
 int pw_actor_head(const float *H, const float *w2, const float *b2, int64_t rows, uint64_t seed, uint64_t step,
                   const int64_t *step_dev /* device, or NULL */, float *logits, int32_t *act, void *stream);
+
+/* The whole actor in ONE launch: X [B,N,in_dim] observations -> act [B,N] (Gumbel-argmax index), and/or
+ * logits [B,N,5], H [B,N,64] (each optional, NULL to skip).  Same arithmetic and the same Philox keying as
+ * pw_actor_front + pw_bilstm_forward + pw_actor_head chained (identical results); G and H stay in LDS.
+ * frag = pw_actor_front_pack's image; N <= 96. */
+int pw_actor_fused(const float *X, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
+                   const float *w_hh_bw, const float *w2, const float *b2, int64_t B, int32_t N, int32_t in_dim,
+                   int32_t relu_out, uint64_t seed, uint64_t step, const int64_t *step_dev /* device, or NULL */,
+                   float *H, float *logits, int32_t *act, void *stream);
 
 /* Test hook: y[i] = f(x[i]) with the DEVICE implementation of one math primitive, so its bits can be compared
  * with a CPU implementation of pworld_math.h.  fn: 0 the kernels' fast correctly-rounded sqrt, 1 their

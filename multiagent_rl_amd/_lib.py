@@ -85,11 +85,16 @@ SIGNATURES = {
     'pw_actor_front_pack_floats': (C.c_size_t, [C.c_int32]),
     'pw_actor_front_pack': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'pw_actor_front': (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pw_actor_fused': (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64]
+                       + [C.c_void_p] * 5),
     'pw_bilstm_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p]),
     'pw_actor_head': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     'pw_episode_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pw_replay_add_tail': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 12),
+    'pw_rollout_tail': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'pw_debug_math': (C.c_int, [C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     'pw_replay_gather': (C.c_int, [C.POINTER(PwReplayStore), C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_void_p]),
 }

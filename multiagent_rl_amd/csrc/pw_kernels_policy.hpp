@@ -25,6 +25,51 @@ __device__ __forceinline__ float fast_tanh(float x)
     return copysignf(t, x);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One hidden unit's four W_hh rows, gate pairs (i, f) and (g, o) packed so that a recurrence step is 64
+// v_pk_fma_f32 (two gates per instruction, h broadcast through op_sel) instead of 128 scalar FMAs.  Each
+// gate still accumulates over k in ascending order with fused multiply-adds: the same bits either way.
+struct LstmUnitW {
+    f32x2 wif[32], wgo[32];
+};
+
+// sw: one direction's W_hh staged as [gate][k/4][unit] float4
+__device__ __forceinline__ void lstm_load_unit(const float4 *sw, const int j, LstmUnitW &w)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 a = sw[(0 * 8 + q) * 32 + j], b = sw[(1 * 8 + q) * 32 + j];
+        const float4 c = sw[(2 * 8 + q) * 32 + j], d = sw[(3 * 8 + q) * 32 + j];
+        w.wif[4 * q] = f32x2{a.x, b.x}; w.wif[4 * q + 1] = f32x2{a.y, b.y};
+        w.wif[4 * q + 2] = f32x2{a.z, b.z}; w.wif[4 * q + 3] = f32x2{a.w, b.w};
+        w.wgo[4 * q] = f32x2{c.x, d.x}; w.wgo[4 * q + 1] = f32x2{c.y, d.y};
+        w.wgo[4 * q + 2] = f32x2{c.z, d.z}; w.wgo[4 * q + 3] = f32x2{c.w, d.w};
+    }
+}
+
+// gates = pre-activations (x W_ih^T + biases) of this unit; hs = the sequence's previous h [32] in LDS
+__device__ __forceinline__ void lstm_step(const LstmUnitW &w, const float *hs, float gi, float gf, float gg, float go,
+                                          float &h, float &c)
+{
+    f32x2 aif = {gi, gf}, ago = {gg, go};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 hv = reinterpret_cast<const float4 *>(hs)[q];
+        aif = __builtin_elementwise_fma(w.wif[4 * q], f32x2{hv.x, hv.x}, aif);
+        ago = __builtin_elementwise_fma(w.wgo[4 * q], f32x2{hv.x, hv.x}, ago);
+        aif = __builtin_elementwise_fma(w.wif[4 * q + 1], f32x2{hv.y, hv.y}, aif);
+        ago = __builtin_elementwise_fma(w.wgo[4 * q + 1], f32x2{hv.y, hv.y}, ago);
+        aif = __builtin_elementwise_fma(w.wif[4 * q + 2], f32x2{hv.z, hv.z}, aif);
+        ago = __builtin_elementwise_fma(w.wgo[4 * q + 2], f32x2{hv.z, hv.z}, ago);
+        aif = __builtin_elementwise_fma(w.wif[4 * q + 3], f32x2{hv.w, hv.w}, aif);
+        ago = __builtin_elementwise_fma(w.wgo[4 * q + 3], f32x2{hv.w, hv.w}, ago);
+    }
+    wave_lds_sync();  // all reads of h done before the caller overwrites it
+    c = fast_sigmoid(aif.y) * c + fast_sigmoid(aif.x) * fast_tanh(ago.x);
+    h = fast_sigmoid(ago.y) * fast_tanh(c);
+}
+
 __global__ void __launch_bounds__(256) pw_bilstm_kernel(const float *__restrict__ G, const float *__restrict__ w_fw,
                                                         const float *__restrict__ w_bw, const int B, const int N,
                                                         const int relu_out, float *__restrict__ H)
@@ -45,46 +90,22 @@ __global__ void __launch_bounds__(256) pw_bilstm_kernel(const float *__restrict_
     const bool valid = seq < 2L * B;
     const long env = valid ? seq >> 1 : 0;
     const int dir = valid ? (int)(seq & 1) : 0;
-    float wi[32], wf[32], wg[32], wo[32];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float4 a = s_w[((dir * 4 + 0) * 8 + q) * 32 + j];
-        const float4 b = s_w[((dir * 4 + 1) * 8 + q) * 32 + j];
-        const float4 c = s_w[((dir * 4 + 2) * 8 + q) * 32 + j];
-        const float4 d = s_w[((dir * 4 + 3) * 8 + q) * 32 + j];
-        wi[4 * q] = a.x; wi[4 * q + 1] = a.y; wi[4 * q + 2] = a.z; wi[4 * q + 3] = a.w;
-        wf[4 * q] = b.x; wf[4 * q + 1] = b.y; wf[4 * q + 2] = b.z; wf[4 * q + 3] = b.w;
-        wg[4 * q] = c.x; wg[4 * q + 1] = c.y; wg[4 * q + 2] = c.z; wg[4 * q + 3] = c.w;
-        wo[4 * q] = d.x; wo[4 * q + 1] = d.y; wo[4 * q + 2] = d.z; wo[4 * q + 3] = d.w;
-    }
+    LstmUnitW w;
+    lstm_load_unit(s_w + dir * 1024, j, w);
     float h = 0.0f, c = 0.0f;
     float *hs = s_h + grp * 32;
     const float *g0 = G + (((size_t)env * N + (dir ? N - 1 : 0)) * 2 + dir) * 128;
     float ni = g0[j], nf = g0[32 + j], ng = g0[64 + j], no = g0[96 + j];
     for (int s = 0; s < N; ++s) {
         const int t = dir ? N - 1 - s : s;
-        float ai = ni, af = nf, ag = ng, ao = no;
+        const float ai = ni, af = nf, ag = ng, ao = no;
         if (s + 1 < N) {  // prefetch the next timestep's pre-activations under this step's FMAs
             const float *g = G + (((size_t)env * N + (dir ? t - 1 : t + 1)) * 2 + dir) * 128;
             ni = g[j]; nf = g[32 + j]; ng = g[64 + j]; no = g[96 + j];
         }
         hs[j] = h;
         wave_lds_sync();  // a sequence's 32 lanes sit in one wave
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 hv = reinterpret_cast<const float4 *>(hs)[q];
-            ai = __builtin_fmaf(wi[4 * q], hv.x, ai); af = __builtin_fmaf(wf[4 * q], hv.x, af);
-            ag = __builtin_fmaf(wg[4 * q], hv.x, ag); ao = __builtin_fmaf(wo[4 * q], hv.x, ao);
-            ai = __builtin_fmaf(wi[4 * q + 1], hv.y, ai); af = __builtin_fmaf(wf[4 * q + 1], hv.y, af);
-            ag = __builtin_fmaf(wg[4 * q + 1], hv.y, ag); ao = __builtin_fmaf(wo[4 * q + 1], hv.y, ao);
-            ai = __builtin_fmaf(wi[4 * q + 2], hv.z, ai); af = __builtin_fmaf(wf[4 * q + 2], hv.z, af);
-            ag = __builtin_fmaf(wg[4 * q + 2], hv.z, ag); ao = __builtin_fmaf(wo[4 * q + 2], hv.z, ao);
-            ai = __builtin_fmaf(wi[4 * q + 3], hv.w, ai); af = __builtin_fmaf(wf[4 * q + 3], hv.w, af);
-            ag = __builtin_fmaf(wg[4 * q + 3], hv.w, ag); ao = __builtin_fmaf(wo[4 * q + 3], hv.w, ao);
-        }
-        wave_lds_sync();  // all reads of h done before the next step overwrites it
-        c = fast_sigmoid(af) * c + fast_sigmoid(ai) * fast_tanh(ag);
-        h = fast_sigmoid(ao) * fast_tanh(c);
+        lstm_step(w, hs, ai, af, ag, ao, h, c);
         if (valid) H[((size_t)env * N + t) * 64 + dir * 32 + j] = relu_out ? fmaxf(h, 0.0f) : h;
     }
 }
@@ -310,6 +331,222 @@ __global__ void __launch_bounds__(256) pw_actor_head_kernel(const float *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The whole actor in ONE launch: obs [B,N,D] -> Gumbel-sampled action index [B,N] (and/or logits, H).
+// A workgroup of 8 waves owns E = min(16, 96 / N) environments (R = E*N <= 96 rows = up to three 32-row MFMA
+// tiles) and nothing but the observation rows and the outputs touches HBM:
+//   stage 1   X1^T = relu(W1 X^T + b1) on the matrix cores, kept in registers (each wave: its own row tile)
+//   per direction d (forward, reverse):
+//     fill    W_ih(d) fragments (32 KB) + W_hh(d) (16 KB) -> LDS
+//     stage 2 G(d)^T = W_ih(d) X1^T + b on the matrix cores -> LDS tile Gs [R][128] (row stride 129)
+//     LSTM    lane = (sequence, hidden unit): 8 waves x 2 sequences, the unit's 128 W_hh weights in VGPRs,
+//             N recurrence steps of 64 packed FMAs; relu(h) -> LDS tile Hs [R][64] (row stride 68)
+//   head      thread = (row, logit): 64 FMAs, Gumbel noise from Philox4x32-10 keyed (seed; step, row) exactly
+//             as pw_actor_head_kernel; argmax per row.
+// Same arithmetic, in the same order, as pw_actor_front_kernel + pw_bilstm_kernel + pw_actor_head_kernel
+// (the tests demand identical bits); what is removed is the HBM round trip of G (1 KB per row, twice), of H,
+// and two launches.  LDS: 6-16 KB stage-1 fragments + 32 + 16 + 48.4 (Gs) + 25.5 (Hs) + 7 KB small = <= 145 KB.
+// ------------------------------------------------------------------------------------------
+struct ActorFusedArgs {
+    const float *X, *frag, *b1, *bih, *whh_f, *whh_r, *w2, *b2;
+    int B, N, D, E, relu_out;
+    uint64_t seed, step;
+    const int64_t *step_dev;
+    float *H, *logits;
+    int32_t *act;
+};
+constexpr int kFusedRows = 96, kGs = 129, kHs = 68;  // kHs: 16-byte aligned rows for the head's float4 reads
+
+template <int S1C>
+__global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int S1 = 4 * S1C;
+    float4 *f_wih = reinterpret_cast<float4 *>(smem_raw);              // [4 n][2 m][4 rq][64 lane] float4, one direction
+    float4 *s_whh = f_wih + 4 * 2 * 4 * 64;                            // [4 gate][8 q][32 unit] float4, one direction
+    float *f_w1 = reinterpret_cast<float *>(s_whh + 4 * 8 * 32);       // [2 m][S1][64 lane]
+    float *s_g = f_w1 + 2 * S1 * 64;                                   // [96][129]
+    float *s_hid = s_g + kFusedRows * kGs;                             // [96][68]
+    float *s_b1 = s_hid + kFusedRows * kHs;                            // [64]
+    float *s_bih = s_b1 + 64;                                          // [256]
+    float *s_w2 = s_bih + 256;                                         // [5][64]
+    float *s_b2 = s_w2 + 320;                                          // [8]
+    float *s_hx = s_b2 + 8;                                            // [16 sequences][32]
+    float *s_lg = s_hx + 512;                                          // [96 * 5] perturbed logits
+
+    PW_STAMP_DECL;
+    PW_STAMP_START;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = A.N, E = A.E;
+    const long env0 = (long)blockIdx.x * E;
+    const int envs_here = (int)((long)A.B - env0 < (long)E ? (long)A.B - env0 : (long)E);
+    const int rows_here = envs_here * N;
+    const long row_base = env0 * N;
+
+    // one direction's weights -> LDS: W_ih fragments (32 KB) + W_hh (16 KB, re-laid as [gate][k/4][unit])
+    auto fill_dir = [&](const int dir) {
+        const float4 *src = reinterpret_cast<const float4 *>(A.frag) + dir * 2048;
+        for (int f = tid; f < 2048; f += 512) f_wih[f] = src[f];
+        const float4 *wh = reinterpret_cast<const float4 *>(dir ? A.whh_r : A.whh_f);
+        for (int f = tid; f < 1024; f += 512) {
+            const int row = f >> 3, q = f & 7, gate = row >> 5, unit = row & 31;
+            s_whh[(gate * 8 + q) * 32 + unit] = wh[f];
+        }
+    };
+    // Matrix-core job map: 3 row tiles x 4 unit tiles per direction = 12 jobs over 4 SIMDs (waves w and w + 4
+    // share one): waves 0-3 take two unit tiles of row tiles 0 / 1, waves 4-7 one unit tile of row tile 2, so
+    // every SIMD carries three jobs.  Each wave needs stage 1 of its own row tile only.
+    const int rt = wave < 4 ? wave >> 1 : 2;
+    const int n_lo = wave < 4 ? (wave & 1) * 2 : wave - 4, n_cnt = wave < 4 ? 2 : 1;
+    const bool front = rt * 32 < rows_here;  // wave-uniform
+    float xb[S1];  // this lane's stage-1 B operands, requested before the weights so that the loads overlap the fill
+    {
+        int lr = rt * 32 + col;
+        if (lr >= rows_here) lr = rows_here - 1;
+        const float *xr = A.X + (size_t)(row_base + lr) * A.D;
+#pragma unroll
+        for (int sidx = 0; sidx < S1; ++sidx) {
+            const int k = 2 * sidx + half;
+            xb[sidx] = k < A.D ? xr[k] : 0.0f;
+        }
+    }
+    {   // stage-1 fragments, the small vectors and the forward direction's weights
+        const float4 *src = reinterpret_cast<const float4 *>(A.frag + 8 * 2 * 4 * 64 * 4);
+        for (int f = tid; f < (2 * S1 * 64) / 4; f += 512) reinterpret_cast<float4 *>(f_w1)[f] = src[f];
+        if (tid < 64) s_b1[tid] = A.b1[tid];
+        if (tid < 256) s_bih[tid] = A.bih[tid];
+        if (tid < 320) s_w2[tid] = A.w2[tid];
+        if (tid < 5) s_b2[tid] = A.b2[tid];
+        fill_dir(0);
+    }
+    __syncthreads();
+    PW_STAMP(0);
+
+    // ---- stage 1
+    f32x16 acc1[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[m][r] = 0.0f;
+    if (front) {
+#pragma unroll
+        for (int sidx = 0; sidx < S1; ++sidx) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_w1[(m * S1 + sidx) * 64 + lane], xb[sidx], acc1[m], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[m][r] = fmaxf(acc1[m][r] + s_b1[m * 32 + mfma_row(r, half)], 0.0f);
+    }
+    PW_STAMP(1);
+    // ---- LSTM lane identity: 2 sequences per wave, sequence slot = local environment
+    const int j = lane & 31, sl = wave * 2 + (lane >> 5);
+    const bool seq_ok = sl < envs_here;
+    const int se = seq_ok ? sl : 0;  // idle half-waves shadow environment 0 (they write nothing)
+    float *hs = s_hx + sl * 32;
+
+#pragma unroll 1
+    for (int dir = 0; dir < 2; ++dir) {
+        if (dir == 1) {
+            fill_dir(1);
+            __syncthreads();
+        }
+        PW_STAMP(2);
+        if (front) {
+#pragma unroll 1
+            for (int nn = 0; nn < n_cnt; ++nn) {
+                const int n = n_lo + nn;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const float4 a = f_wih[((n * 2 + m) * 4 + rq) * 64 + lane];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc1[m][4 * rq + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc1[m][4 * rq + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, acc1[m][4 * rq + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, acc1[m][4 * rq + 3], acc, 0, 0, 0);
+                    }
+                }
+                float *dst = s_g + (rt * 32 + col) * kGs + n * 32;
+                const float *bb = s_bih + dir * 128 + n * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[mfma_row(r, half)] = acc[r] + bb[mfma_row(r, half)];
+            }
+        }
+        PW_STAMP(3);
+        __syncthreads();
+        PW_STAMP(4);
+        {   // recurrence over the agent axis
+            LstmUnitW w;
+            lstm_load_unit(s_whh, j, w);
+            float h = 0.0f, c = 0.0f;
+            for (int s = 0; s < N; ++s) {
+                const int t = dir ? N - 1 - s : s;
+                const float *g = s_g + (se * N + t) * kGs;
+                const float gi = g[j], gf = g[32 + j], gg = g[64 + j], go = g[96 + j];
+                hs[j] = h;
+                wave_lds_sync();
+                lstm_step(w, hs, gi, gf, gg, go, h, c);
+                if (seq_ok) s_hid[(se * N + t) * kHs + dir * 32 + j] = A.relu_out ? fmaxf(h, 0.0f) : h;
+            }
+        }
+        PW_STAMP(5);
+        __syncthreads();  // Gs / weights are overwritten by the next direction; Hs complete after the last
+        PW_STAMP(6);
+    }
+
+    // ---- head
+    if (A.H) {
+        for (int idx = tid; idx < rows_here * 64; idx += 512)
+            A.H[(size_t)row_base * 64 + idx] = s_hid[(idx >> 6) * kHs + (idx & 63)];
+    }
+    if (tid < rows_here * 5) {
+        const int r = tid / 5, o = tid - r * 5;
+        float acc = s_b2[o];
+        const float4 *hv = reinterpret_cast<const float4 *>(s_hid + r * kHs), *wv = reinterpret_cast<const float4 *>(s_w2 + o * 64);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 hq = hv[q], wq = wv[q];
+            acc = __builtin_fmaf(wq.x, hq.x, acc);
+            acc = __builtin_fmaf(wq.y, hq.y, acc);
+            acc = __builtin_fmaf(wq.z, hq.z, acc);
+            acc = __builtin_fmaf(wq.w, hq.w, acc);
+        }
+        const long grow = row_base + r;
+        if (A.logits) A.logits[(size_t)grow * 5 + o] = acc;
+        if (A.act) {
+            const uint64_t step = A.step_dev ? (uint64_t)*A.step_dev : A.step;
+            uint32_t u[4];
+            pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | (o == 4 ? 0x80000000u : 0u), (uint32_t)step,
+                             (uint32_t)(step >> 32), (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
+            const uint32_t uw = o == 4 ? u[0] : (o == 0 ? u[0] : o == 1 ? u[1] : o == 2 ? u[2] : u[3]);
+            const float uo = ((float)(uw >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
+            s_lg[tid] = acc - __logf(-__logf(uo));
+        }
+    }
+    if (A.act) {
+        __syncthreads();
+        if (tid < rows_here) {
+            int best = 0;
+            float bv = 0.0f;
+#pragma unroll
+            for (int o = 0; o < 5; ++o) {
+                const float v = s_lg[tid * 5 + o];
+                if (o == 0 || v > bv) { bv = v; best = o; }
+            }
+            A.act[row_base + tid] = best;
+        }
+    }
+    PW_STAMP(7);
+    PW_STAMP_FLUSH;
+}
+
 // Test hook: evaluate one device math primitive element-wise so that tests can compare the exact bits
 // against the CPU contract (include/pworld_math.h, restated in oracle/pworld_oracle.c) over millions of
 // inputs.  fn: 0 sqrt_rn_fast, 1 softplus_branchless, 2 pw_softplus, 3 pw_exp, 4 sqrtf, 5 x / aux (IEEE)
@@ -333,10 +570,21 @@ __global__ void pw_debug_math_kernel(const int fn, const float *x, const float a
 // Episode bookkeeping of the rollout loop (experiments/run.py:55-65, vectorised): return += shared
 // reward; on terminal the return is added to (sum, count) and cleared.  ONE workgroup with a
 // fixed-order tree reduction, so the statistics are bit-reproducible (no float atomics).
+// The same launch can advance up to two device-side counters (replay ring cursor, Philox step) once every
+// earlier kernel of the step has read them: stream order puts this launch last in a rollout step.
+struct TailCounters {
+    int64_t *c0, *c1;
+    int64_t d0, m0, d1, m1;
+};
 __global__ void __launch_bounds__(1024) pw_episode_stats_kernel(const float *rew_shared, const uint8_t *terminal,
                                                                 const int B, float *episode_return,
-                                                                double *finished_sum, int64_t *finished_count)
+                                                                double *finished_sum, int64_t *finished_count,
+                                                                const TailCounters tc)
 {
+    if (threadIdx.x == 0) {
+        if (tc.c0) { int64_t v = *tc.c0 + tc.d0; if (tc.m0 > 0) v %= tc.m0; *tc.c0 = v; }
+        if (tc.c1) { int64_t v = *tc.c1 + tc.d1; if (tc.m1 > 0) v %= tc.m1; *tc.c1 = v; }
+    }
     __shared__ double s_sum[1024];
     __shared__ int s_cnt[1024];
     double acc = 0.0;

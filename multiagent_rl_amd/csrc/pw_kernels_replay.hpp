@@ -39,6 +39,77 @@ __global__ void pw_replay_add_kernel(const pw_replay_store st, int64_t start, co
     }
 }
 
+// pw_replay_add_kernel + the step's bookkeeping in the same launch (a captured rollout step ends with this
+// kernel): one extra workgroup accumulates the episode returns (pw_episode_stats_kernel's arithmetic in the same
+// order: 1024 strided partial sums, then a binary tree), publishes the NEXT ring position into a second
+// cursor cell -- every workgroup reads `start_dev`, so it must not be overwritten here -- and advances the
+// policy's Philox step.
+struct ReplayTail {
+    float *episode_return;
+    double *finished_sum;
+    int64_t *finished_count, *next_start_dev, *step_counter;
+};
+__global__ void __launch_bounds__(256) pw_replay_add_tail_kernel(const pw_replay_store st, int64_t start,
+                                                                 const int64_t *start_dev, const int B, const float *obs,
+                                                                 const int32_t *act_idx, const float *rew_shared,
+                                                                 const float *next_obs, const float *final_obs,
+                                                                 const uint8_t *terminal, const float *done,
+                                                                 const ReplayTail tl)
+{
+    const int ND = st.num_agents * st.obs_dim, N = st.num_agents;
+    const size_t total = (size_t)B * ND;
+    if (start_dev) start = *start_dev;
+    const unsigned copy_blocks = gridDim.x - 1;  // the last workgroup does the bookkeeping, concurrently
+    if (blockIdx.x < copy_blocks) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)copy_blocks * blockDim.x) {
+            const size_t e = i / ND, c = i - e * ND;
+            const size_t slot = (size_t)((start + (int64_t)e) % st.capacity);
+            st.obs[slot * ND + c] = obs[i];
+            const bool fin = final_obs && terminal && terminal[e];
+            st.next_obs[slot * ND + c] = fin ? final_obs[i] : next_obs[i];
+            if (c < (size_t)N) st.act[slot * N + c] = (uint8_t)act_idx[e * N + c];
+            if (c == 0) {
+                st.rew[slot] = rew_shared[e];
+                st.done[slot] = done ? done[e] : 0.0f;
+            }
+        }
+        return;
+    }
+    __shared__ double s_sum[128];
+    __shared__ int s_cnt[128];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        if (tl.next_start_dev) *tl.next_start_dev = (start + B) % st.capacity;
+        if (tl.step_counter) *tl.step_counter += 1;
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};  // the partial sums of "threads" tid, tid + 256, tid + 512, tid + 768
+    int cnt[4] = {0, 0, 0, 0};
+    for (int e0 = tid; e0 < B; e0 += 1024) {  // the four partial sums advance together: 4 independent load chains
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int e = e0 + 256 * v;
+            if (e < B) {
+                const float r = tl.episode_return[e] + rew_shared[e];
+                if (terminal[e]) { acc[v] += (double)r; cnt[v] += 1; tl.episode_return[e] = 0.0f; }
+                else tl.episode_return[e] = r;
+            }
+        }
+    }
+    // tree levels 512 and 256 are thread-local: s[i] += s[i + 512] (i < 512), then s[i] += s[i + 256] (i < 256)
+    double sum = (acc[0] + acc[2]) + (acc[1] + acc[3]);
+    int c = (cnt[0] + cnt[2]) + (cnt[1] + cnt[3]);
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid >= w && tid < 2 * w) { s_sum[tid - w] = sum; s_cnt[tid - w] = c; }
+        __syncthreads();
+        if (tid < w) { sum += s_sum[tid]; c += s_cnt[tid]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *tl.finished_sum += sum;
+        *tl.finished_count += c;
+    }
+}
+
 __global__ void pw_replay_gather_kernel(const pw_replay_store st, const int64_t *idx, const int b,
                                         float *out_obs, float *out_act, float *out_rew, float *out_next_obs,
                                         float *out_done)

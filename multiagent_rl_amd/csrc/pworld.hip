@@ -627,6 +627,31 @@ int pw_replay_add(const pw_replay_store *st, int64_t start, const int64_t *start
     return PW_OK;
 }
 
+int pw_replay_add_tail(const pw_replay_store *st, int64_t start, const int64_t *start_dev, int64_t *next_start_dev,
+                       int32_t B, const float *obs, const int32_t *act_idx, const float *rew_shared,
+                       const float *next_obs, const float *final_obs, const uint8_t *terminal, const float *done,
+                       float *episode_return, double *finished_sum, int64_t *finished_count, int64_t *step_counter,
+                       void *stream)
+{
+    if (!st || !obs || !act_idx || !rew_shared || !next_obs || !terminal || !episode_return || !finished_sum ||
+        !finished_count)
+        return fail(PW_EINVAL, "null argument");
+    if (st->capacity < 1 || B < 1 || B > st->capacity || start < 0) return fail(PW_EINVAL, "bad ring arguments");
+    if (st->obs_dim < 5) return fail(PW_EINVAL, "obs_dim must be >= 5");
+    if (start_dev && next_start_dev == start_dev)
+        return fail(PW_EINVAL, "next_start_dev must not alias start_dev (every workgroup reads start_dev)");
+    const size_t total = (size_t)B * st->num_agents * st->obs_dim;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    ReplayTail tl;
+    tl.episode_return = episode_return; tl.finished_sum = finished_sum; tl.finished_count = finished_count;
+    tl.next_start_dev = next_start_dev; tl.step_counter = step_counter;
+    hipLaunchKernelGGL(pw_replay_add_tail_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       *st, start, start_dev, B, obs, act_idx, rew_shared, next_obs, final_obs, terminal, done, tl);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
 int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b, float *out_obs, float *out_act,
                      float *out_rew, float *out_next_obs, float *out_done, void *stream)
 {
@@ -722,16 +747,66 @@ int pw_actor_head(const float *H, const float *w2, const float *b2, int64_t rows
     return PW_OK;
 }
 
-int pw_episode_stats(const float *rew_shared, const uint8_t *terminal, int32_t B, float *episode_return,
-                     double *finished_sum, int64_t *finished_count, void *stream)
+int pw_actor_fused(const float *X, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
+                   const float *w_hh_bw, const float *w2, const float *b2, int64_t B, int32_t N, int32_t in_dim,
+                   int32_t relu_out, uint64_t seed, uint64_t step, const int64_t *step_dev, float *H, float *logits,
+                   int32_t *act, void *stream)
+{
+    if (!X || !frag || !b1 || !b_ih || !w_hh_fw || !w_hh_bw || !w2 || !b2 || (!H && !logits && !act))
+        return fail(PW_EINVAL, "null argument");
+    if (B < 1 || N < 1 || N > 96 || B > (int64_t)0x7fffffff) return fail(PW_EINVAL, "N must be in [1, 96]");
+    if (in_dim < 1 || in_dim > 64) return fail(PW_EINVAL, "in_dim must be in [1, 64]");
+    if ((reinterpret_cast<uintptr_t>(frag) | reinterpret_cast<uintptr_t>(w_hh_fw) | reinterpret_cast<uintptr_t>(w_hh_bw)) & 15)
+        return fail(PW_EINVAL, "frag and w_hh must be 16-byte aligned");
+    ActorFusedArgs a;
+    a.X = X; a.frag = frag; a.b1 = b1; a.bih = b_ih; a.whh_f = w_hh_fw; a.whh_r = w_hh_bw; a.w2 = w2; a.b2 = b2;
+    a.B = (int)B; a.N = N; a.D = in_dim; a.relu_out = relu_out;
+    a.E = 96 / N < 16 ? 96 / N : 16;
+    a.seed = seed; a.step = step; a.step_dev = step_dev; a.H = H; a.logits = logits; a.act = act;
+    const int S1C = (in_dim + 7) / 8, S1 = 4 * S1C;
+    const size_t shm = (size_t)(4 * 2 * 4 * 64 + 4 * 8 * 32) * sizeof(float4) +
+                       (size_t)(2 * S1 * 64 + kFusedRows * kGs + kFusedRows * kHs + 64 + 256 + 320 + 8 + 512 + 512) * sizeof(float);
+    const unsigned grid = (unsigned)((B + a.E - 1) / a.E);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static bool attr_set[9] = {};
+#define PW_FUSED(C)                                                                                                      \
+    case C:                                                                                                              \
+        if (!attr_set[C]) {                                                                                              \
+            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_actor_fused_kernel<C>),                   \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+            attr_set[C] = true;                                                                                          \
+        }                                                                                                                \
+        hipLaunchKernelGGL(pw_actor_fused_kernel<C>, dim3(grid), dim3(512), shm, st, a);                                 \
+        break;
+    switch (S1C) {
+        PW_FUSED(1) PW_FUSED(2) PW_FUSED(3) PW_FUSED(4) PW_FUSED(5) PW_FUSED(6) PW_FUSED(7) PW_FUSED(8)
+    }
+#undef PW_FUSED
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_rollout_tail(const float *rew_shared, const uint8_t *terminal, int32_t B, float *episode_return,
+                    double *finished_sum, int64_t *finished_count, int64_t *counter0, int64_t delta0, int64_t modulo0,
+                    int64_t *counter1, int64_t delta1, int64_t modulo1, void *stream)
 {
     if (!rew_shared || !terminal || !episode_return || !finished_sum || !finished_count)
         return fail(PW_EINVAL, "null argument");
     if (B < 1) return fail(PW_EINVAL, "bad sizes");
+    TailCounters tc;
+    tc.c0 = counter0; tc.d0 = delta0; tc.m0 = modulo0;
+    tc.c1 = counter1; tc.d1 = delta1; tc.m1 = modulo1;
     hipLaunchKernelGGL(pw_episode_stats_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), rew_shared,
-                       terminal, B, episode_return, finished_sum, finished_count);
+                       terminal, B, episode_return, finished_sum, finished_count, tc);
     PW_HIP_CHECK(hipGetLastError());
     return PW_OK;
+}
+
+int pw_episode_stats(const float *rew_shared, const uint8_t *terminal, int32_t B, float *episode_return,
+                     double *finished_sum, int64_t *finished_count, void *stream)
+{
+    return pw_rollout_tail(rew_shared, terminal, B, episode_return, finished_sum, finished_count, nullptr, 0, 0, nullptr, 0,
+                           0, stream);
 }
 
 int pw_dense(const float *X, const float *W, const float *b, int64_t rows, int32_t in_dim, int32_t out_dim,

@@ -82,14 +82,14 @@ class GumbelPolicy(object):
 
 
 class FusedActor(object):
-    """The same ActorNetwork evaluated with three launches of libpworld (``pw_actor_front``,
-    ``pw_bilstm_forward``, ``pw_actor_head``) instead of MIOpen's ~45-kernel RNN path.
+    """The same ActorNetwork evaluated by libpworld instead of MIOpen's ~45-kernel RNN path.
 
-    Weights are snapshotted from ``actor`` (call ``refresh()`` after the learner updates it).  dense1 + ReLU and
-    the input projections of both LSTM directions are one hand-written float32 MFMA kernel (the [B*N, 64]
-    hidden activations stay in registers between the two products); the recurrence over the agent axis and the
-    output head + Gumbel sampling run in their own kernels; all float32.  ``PW_ACTOR_NO_MFMA=1`` selects the
-    three-launch form (weight-stationary dense1 + rocBLAS GEMM) for comparison.
+    Weights are snapshotted from ``actor`` (call ``refresh()`` after the learner updates it).  Default: ONE launch
+    (``pw_actor_fused``): dense1 + ReLU and the input projections of both LSTM directions on the matrix cores
+    (exact float32 MFMA), the recurrence over the agent axis, the output head and the Gumbel-argmax sampling, with
+    every intermediate in registers / LDS.  ``PW_ACTOR_NO_FUSE=1`` selects the same arithmetic as three launches
+    (``pw_actor_front``, ``pw_bilstm_forward``, ``pw_actor_head`` -- identical results, also used when N > 96), and
+    ``PW_ACTOR_NO_MFMA=1`` additionally replaces the front end by weight-stationary dense1 + a rocBLAS GEMM.
     """
 
     def __init__(self, actor, seed=0):
@@ -99,9 +99,11 @@ class FusedActor(object):
         import os
         self.actor, self.seed, self.calls = actor, int(seed), 0
         self.use_mfma_front = not os.environ.get('PW_ACTOR_NO_MFMA')
+        self.use_fused = self.use_mfma_front and not os.environ.get('PW_ACTOR_NO_FUSE')
         self.refresh()
         self._step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)  # Philox step (hipGraph mode)
         self.graph_mode = False
+        self.defer_step_advance = False  # graph mode: the caller advances _step_dev (pw_rollout_tail)
 
     @torch.no_grad()
     def refresh(self):
@@ -129,9 +131,28 @@ class FusedActor(object):
         return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     @torch.no_grad()
+    def _fused(self, obs, want_h=False, want_logits=False, want_act=False):
+        """One launch: obs [B,N,D] -> (H [B,N,64], logits [B,N,5], act [B,N] int32), each None unless wanted."""
+        B, N, D = obs.shape
+        x = obs.reshape(B * N, D).to(torch.float32).contiguous()
+        h = torch.empty(B, N, 64, dtype=torch.float32, device=self.device) if want_h else None
+        logits = torch.empty(B, N, 5, dtype=torch.float32, device=self.device) if want_logits else None
+        act = torch.empty(B, N, dtype=torch.int32, device=self.device) if want_act else None
+        p = lambda t: None if t is None else self._C.c_void_p(t.data_ptr())  # noqa: E731
+        step_dev = p(self._step_dev) if (self.graph_mode and want_act) else None
+        self._lib_mod.check(self.lib.pw_actor_fused(p(x), p(self.frag), p(self.b1), p(self.bih), p(self.whh_f),
+                                                    p(self.whh_r), p(self.w2), p(self.b2), B, N, D, 1, self.seed,
+                                                    self.calls, step_dev, p(h), p(logits), p(act), self._stream()))
+        if step_dev is not None and not self.defer_step_advance:  # captured: the counter advances on the device
+            self._lib_mod.check(self.lib.pw_counter_add(p(self._step_dev), 1, 0, self._stream()))
+        return h, logits, act
+
+    @torch.no_grad()
     def hidden(self, obs):
         """obs [B,N,D] -> relu(BiLSTM(relu(dense1(obs)))) [B,N,64]."""
         B, N, D = obs.shape
+        if self.use_fused and N <= 96:
+            return self._fused(obs, want_h=True)[0]
         x = obs.reshape(B * N, D).to(torch.float32).contiguous()
         p = lambda t: self._C.c_void_p(t.data_ptr())  # noqa: E731
         h = torch.empty(B, N, 64, dtype=torch.float32, device=self.device)
@@ -159,16 +180,21 @@ class FusedActor(object):
         step_dev = p(self._step_dev) if (self.graph_mode and want_act) else None
         self._lib_mod.check(self.lib.pw_actor_head(p(h), p(self.w2), p(self.b2), B * N, self.seed, self.calls,
                                                    step_dev, p(logits), p(act), self._stream()))
-        if step_dev is not None:  # captured: the counter advances on the device with every replay
+        if step_dev is not None and not self.defer_step_advance:  # captured: the counter advances on the device
             self._lib_mod.check(self.lib.pw_counter_add(p(self._step_dev), 1, 0, self._stream()))
         return logits, act
 
     def logits(self, obs):
+        if self.use_fused and obs.shape[1] <= 96:
+            return self._fused(obs, want_logits=True)[1]
         return self._head(self.hidden(obs), True, False)[0]
 
     def __call__(self, obs):
         """-> Gumbel-sampled action index [B,N] int32 (one fresh Philox stream per call)."""
-        act = self._head(self.hidden(obs), False, True)[1]
+        if self.use_fused and obs.shape[1] <= 96:
+            act = self._fused(obs, want_act=True)[2]
+        else:
+            act = self._head(self.hidden(obs), False, True)[1]
         self.calls += 1
         return act
 

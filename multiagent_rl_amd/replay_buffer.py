@@ -64,7 +64,9 @@ class ReplayBuffer(object):
         st.act = self.act.data_ptr()
         st.capacity, st.num_agents, st.obs_dim = cap, N, D
         self._store = st
-        self._cursor = torch.zeros(1, dtype=torch.int64, device=dev)  # device copy of _next_idx (hipGraph mode)
+        # device copies of _next_idx (hipGraph mode): cell [0] for add_batch(device_cursor=True); add_batch_tail
+        # ping-pongs between [0] and [1] (it reads one cell in every workgroup and writes the other)
+        self._cursor = torch.zeros(2, dtype=torch.int64, device=dev)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
@@ -95,12 +97,13 @@ class ReplayBuffer(object):
         self._len = min(self._len + num_transitions, self._maxsize)
 
     def add_batch(self, obs, act_idx, rew_shared, next_obs, final_obs=None, terminal=None, done=None,
-                  device_cursor=False):
+                  device_cursor=False, advance_cursor=True):
         """B transitions of one batched step: obs/next_obs [B,N,D], act_idx [B,N] int, rew_shared [B].
         Where ``terminal[b]`` is set, next_obs is taken from ``final_obs`` (the pre-reset
         observation: the reference stores new_obs_n BEFORE env.reset(), run.py:52 vs :60).
         ``device_cursor=True`` (hipGraph capture): the ring position is read from, and advanced in,
-        device memory by the captured launches; the caller accounts for it with ``note_graph_adds``."""
+        device memory by the captured launches; the caller accounts for it with ``note_graph_adds``
+        (``advance_cursor=False``: the caller advances ``_cursor`` itself, e.g. in pw_rollout_tail)."""
         B, N, D = obs.shape
         if self._store is None:
             self._device = obs.device if obs.is_cuda and self._device is None else self._device
@@ -116,13 +119,42 @@ class ReplayBuffer(object):
             check(self._lib.pw_replay_add(C.byref(self._store), 0, _ptr(self._cursor), B, _ptr(obs), _ptr(act_idx),
                                           _ptr(rew_shared), _ptr(next_obs), _ptr(final_obs), _ptr(term), _ptr(done),
                                           self._stream()))
-            check(self._lib.pw_counter_add(_ptr(self._cursor), B, self._maxsize, self._stream()))
+            if advance_cursor:
+                check(self._lib.pw_counter_add(_ptr(self._cursor), B, self._maxsize, self._stream()))
             return
         check(self._lib.pw_replay_add(C.byref(self._store), self._next_idx, None, B, _ptr(obs), _ptr(act_idx),
                                       _ptr(rew_shared), _ptr(next_obs), _ptr(final_obs), _ptr(term), _ptr(done),
                                       self._stream()))
         self._next_idx = (self._next_idx + B) % self._maxsize
         self._len = min(self._len + B, self._maxsize)
+
+    def add_batch_tail(self, obs, act_idx, rew_shared, next_obs, final_obs, terminal, episode_return, finished_sum,
+                       finished_count, step_counter=None, parity=None):
+        """``add_batch`` + the rollout's episode-return bookkeeping (``pw_episode_stats``) in ONE launch.
+        ``parity`` None: host ring position.  ``parity`` 0/1 (hipGraph capture): the position is read from
+        ``_cursor[parity]`` and the next one written to ``_cursor[1 - parity]``; ``step_counter`` (a device
+        int64, e.g. the policy's Philox step) is incremented by the same launch; the caller accounts for the
+        adds with ``note_graph_adds``.  All tensors must already be float32 / int32 / uint8 device tensors."""
+        B, N, D = obs.shape
+        if self._store is None:
+            self._device = obs.device if self._device is None else self._device
+            self._allocate(N, D)
+        assert (N, D) == (self.num_agents, self.obs_dim) and B <= self._maxsize
+        term = terminal.view(torch.uint8)
+        for t, dt in ((obs, torch.float32), (next_obs, torch.float32), (rew_shared, torch.float32),
+                      (act_idx, torch.int32), (term, torch.uint8), (episode_return, torch.float32)):
+            assert t.is_cuda and t.dtype == dt and t.is_contiguous()
+        if parity is None:
+            start, cur, nxt = self._next_idx, None, None
+        else:
+            start, cur, nxt = 0, _ptr(self._cursor[parity:]), _ptr(self._cursor[1 - parity:])
+        check(self._lib.pw_replay_add_tail(C.byref(self._store), start, cur, nxt, B, _ptr(obs), _ptr(act_idx),
+                                           _ptr(rew_shared), _ptr(next_obs), _ptr(final_obs), _ptr(term), None,
+                                           _ptr(episode_return), _ptr(finished_sum), _ptr(finished_count),
+                                           _ptr(step_counter), self._stream()))
+        if parity is None:
+            self._next_idx = (self._next_idx + B) % self._maxsize
+            self._len = min(self._len + B, self._maxsize)
 
     # -- rls/replay_buffer.py:51-57
     def make_index(self, batch_size):

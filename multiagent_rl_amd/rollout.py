@@ -142,21 +142,40 @@ class BatchedRollout(object):
         self.finished_episodes = torch.zeros((), dtype=torch.int64, device=dev)
         self._graph = None
 
-    def _bookkeeping(self, rew_shared, terminal):
+    def _bookkeeping(self, rew_shared, terminal, counters=()):
+        """Episode returns on the device; ``counters`` = up to two (tensor, delta, modulo) device counters that the
+        same launch advances (captured steps: replay cursor, Philox step)."""
         import ctypes as C
         from ._lib import check
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        check(self.env.lib.pw_episode_stats(p(rew_shared), p(terminal), self.env.num_envs, p(self.episode_return),
-                                            p(self.finished_return_sum), p(self.finished_episodes),
-                                            self.env._stream()))
+        cs = list(counters) + [(None, 0, 0)] * (2 - len(counters))
+        args = []
+        for t, d, m in cs:
+            args += [None if t is None else p(t), int(d), int(m)]
+        check(self.env.lib.pw_rollout_tail(p(rew_shared), p(terminal), self.env.num_envs, p(self.episode_return),
+                                           p(self.finished_return_sum), p(self.finished_episodes), *args,
+                                           self.env._stream()))
+
+    def _sink(self, obs, actions, out, parity=None, step_counter=None):
+        """Replay append + episode-return bookkeeping: ONE launch when there is a device ring."""
+        if self.memory is not None and actions.dtype == torch.int32 and out.get('final_obs') is not None:
+            self.memory.add_batch_tail(obs, actions, out['rew_shared'], out['obs'], out['final_obs'], out['terminal'],
+                                       self.episode_return, self.finished_return_sum, self.finished_episodes,
+                                       step_counter=step_counter, parity=parity)
+            return
+        counters = [] if step_counter is None else [(step_counter, 1, 0)]
+        if self.memory is not None:
+            self.memory.add_batch(obs, actions, out['rew_shared'], out['obs'], out.get('final_obs'), out['terminal'],
+                                  device_cursor=parity is not None, advance_cursor=False)
+            if parity is not None:
+                counters.append((self.memory._cursor, self.env.num_envs, self.memory._maxsize))
+        self._bookkeeping(out['rew_shared'], out['terminal'], counters)
 
     def step(self):
         obs = self.obs
         actions = self.policy(obs)
         nxt, rew, done, info = self.env.step(actions)
-        if self.memory is not None:
-            self.memory.add_batch(obs, actions, info['rew_shared'], nxt, info.get('final_obs'), info['terminal'])
-        self._bookkeeping(info['rew_shared'], info['terminal'])
+        self._sink(obs, actions, dict(info, obs=nxt))
         self.obs = nxt
         self.env_steps += self.env.num_envs
         return nxt, rew, done, info
@@ -173,6 +192,9 @@ class BatchedRollout(object):
         self._obs_buf = [self.obs.clone(), torch.empty_like(self.obs)]
         if hasattr(self.policy, 'begin_graph'):
             self.policy.begin_graph()
+        defer = hasattr(self.policy, 'defer_step_advance')
+        if defer:
+            self.policy.defer_step_advance = True
         if self.memory is not None:
             if self.memory._store is None:
                 self.memory._allocate(env.n, env.obs_dim)
@@ -184,10 +206,7 @@ class BatchedRollout(object):
             out['obs'] = dst
             actions = self.policy(src)
             env.step(actions, out=out)
-            if self.memory is not None:
-                self.memory.add_batch(src, actions, out['rew_shared'], dst, out.get('final_obs'), out['terminal'],
-                                      device_cursor=True)
-            self._bookkeeping(out['rew_shared'], out['terminal'])
+            self._sink(src, actions, out, parity=i & 1, step_counter=self.policy._step_dev if defer else None)
 
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))

@@ -367,3 +367,27 @@ def test_pw_actor_front_mfma_matches_torch():
         if u % 64 < D:
             want[:, u] = x[:, u % 64] * (u + 1)
     assert torch.equal(g, want)
+
+
+def test_one_launch_actor_equals_three_launch_chain(monkeypatch):
+    """pw_actor_fused (everything in LDS) vs pw_actor_front + pw_bilstm_forward + pw_actor_head chained: the
+    hidden state, the logits and the sampled actions must be IDENTICAL (same arithmetic, same Philox keying),
+    for ragged batches (last workgroup partly filled), N that does not divide 96, and several in_dims."""
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    torch.manual_seed(9)
+    for D in (16, 10, 21, 40):
+        actor = ActorNetwork(D, 5).cuda().eval()
+        one = FusedActor(actor, seed=77)
+        monkeypatch.setenv('PW_ACTOR_NO_FUSE', '1')
+        three = FusedActor(actor, seed=77)
+        monkeypatch.delenv('PW_ACTOR_NO_FUSE')
+        assert one.use_fused and not three.use_fused
+        for B, N in [(1, 1), (1, 6), (16, 6), (17, 6), (4096, 6), (100, 3), (33, 7), (5, 48), (9, 96), (70, 2), (3, 50)]:
+            obs = (torch.randn(B, N, D) * 2).cuda()
+            assert torch.equal(one.hidden(obs), three.hidden(obs)), (D, B, N)
+            assert torch.equal(one.logits(obs), three.logits(obs)), (D, B, N)
+            a1, a3 = one(obs), three(obs)
+            assert a1.dtype == torch.int32 and torch.equal(a1, a3), (D, B, N)
+    # N > 96 falls back to the chain
+    obs = torch.randn(2, 100, 40).cuda()
+    assert torch.equal(one(obs), three(obs))
