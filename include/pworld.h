@@ -267,7 +267,8 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
 
 /* Test hook: y[i] = f(x[i]) with the DEVICE implementation of one math primitive, so its bits can be compared
  * with a CPU implementation of pworld_math.h.  fn: 0 the kernels' fast correctly-rounded sqrt, 1 their
- * branch-free softplus, 2 pw_softplus, 3 pw_exp, 4 sqrtf, 5 x / aux (IEEE division). */
+ * branch-free softplus, 2 pw_softplus, 3 pw_exp, 4 sqrtf, 5 x / aux (IEEE division), 6 / 7 the hot loops'
+ * scaling-free division chain for x / aux and aux / x, 8 their softplus, 9 aux / x (IEEE division). */
 int pw_debug_math(int32_t fn, const float *x, float aux, float *y, int64_t n, void *stream);
 
 #ifdef __cplusplus

@@ -73,9 +73,8 @@ __device__ __forceinline__ Lane make_lane(const KParams &P)
 // x in [2^-90, 2^90) neither is needed: v_sqrt_f32 is within 1 ulp, and two fused residual tests
 // pick between {s-1ulp, s, s+1ulp} -- the same correction step the compiler emits.  Anything
 // outside that range (never reached from finite, non-coincident states) takes the general sqrtf.
-__device__ __forceinline__ float sqrt_rn_fast(float x)
+__device__ __forceinline__ float sqrt_rn_core(float x)  // x in [2^-90, 2^90)
 {
-    if (__builtin_expect(!(x >= 8.077935669463161e-28f && x < 1.2379400392853803e+27f), 0)) return sqrtf(x);
     float s = __builtin_amdgcn_sqrtf(x);
     const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
     const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
@@ -84,6 +83,42 @@ __device__ __forceinline__ float sqrt_rn_fast(float x)
     s = r_dn <= 0.0f ? s_dn : s;
     s = r_up > 0.0f ? s_up : s;
     return s;
+}
+
+__device__ __forceinline__ float sqrt_rn_fast(float x)
+{
+    if (__builtin_expect(!(x >= 8.077935669463161e-28f && x < 1.2379400392853803e+27f), 0)) return sqrtf(x);
+    return sqrt_rn_core(x);
+}
+
+// IEEE float32 division without its scaling wrapper.  The compiler expands a / b into
+//   v_div_scale x2, v_rcp, y = fma(fma(-b, rcp, 1), rcp, rcp), q0 = a*y, r0 = fma(-b, q0, a), q1 = fma(r0, y, q0),
+//   r1 = fma(-b, q1, a), v_div_fmas (= fma(r1, y, q1)), v_div_fixup
+// where v_div_scale / v_div_fmas only act when an operand or the quotient is within ~2^-100 / 2^96 of the
+// float32 range limits, and v_div_fixup only on zeros, infinities and NaNs.  Away from those cases the quotient
+// IS the bare FMA chain below -- bit for bit, it is the same instruction sequence -- so callers that know their
+// operand ranges run the chain directly: 5 instructions per quotient (packed: 5 for two quotients) plus 3 per
+// distinct divisor, instead of 11-12 per division.  Required: b in [2^-45, 2^45], a in [2^-69, 2^52] in
+// magnitude (then neither the quotient nor any residual leaves the normal range), or a == +-0 where the sign
+// of the zero result does not matter to the caller.  tests: pw_debug_math fn 6 / 7 against IEEE division.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float div_refined_rcp(float b)
+{
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+}
+__device__ __forceinline__ float div_chain(float a, float b, float y)
+{
+    const float q0 = a * y;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
+    return __builtin_fmaf(__builtin_fmaf(-b, q1, a), y, q1);
+}
+__device__ __forceinline__ f32x2 div_chain2(f32x2 a, float b, float y)
+{
+    const f32x2 nb = {-b, -b}, yy = {y, y};
+    const f32x2 q0 = a * yy;
+    const f32x2 q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(nb, q0, a), yy, q0);
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(nb, q1, a), yy, q1);
 }
 
 // pw_softplus with the exp argument known to be <= 0: same operations as include/pworld_math.h
@@ -117,12 +152,77 @@ __device__ __forceinline__ float softplus_branchless(float x)
 // delta = p_i - p_j; dist = sqrt(sum(delta^2)); pen = logaddexp(0, -(dist - dist_min)/k) * k;
 // force = contact_force * delta / dist * pen.  (The force on the pair's second entity is
 // the exact negation, which is what this evaluates to from that entity's side.)
+// softplus_branchless with log1p's t / (2 + t) through div_chain: t = exp(-|x|) in [0, 1] and the divisor in
+// [2, 3] are in range unless t < 2^-23, where 2 + t rounds to 2 and the IEEE quotient is t * 0.5 exactly.
+__device__ __forceinline__ float softplus_fastdiv(float x)
+{
+    const float ax = x < 0.0f ? -x : x;
+    const float m = x > 0.0f ? x : 0.0f;
+    const float t0 = -ax;
+    const float tc = t0 > -87.0f ? t0 : -86.0f;
+    float t = tc * 1.44269504088896341f;
+    float n = floorf(t + 0.5f);
+    float r = tc - n * 0.693359375f;
+    r = r - n * -2.12194440054690583e-4f;
+    float p = 1.98412698412698413e-4f;
+    p = p * r + 1.38888888888888894e-3f;
+    p = p * r + 8.33333333333333322e-3f;
+    p = p * r + 4.16666666666666644e-2f;
+    p = p * r + 1.66666666666666657e-1f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    const int32_t e = (int32_t)n + 127;
+    float ex = p * __uint_as_float((uint32_t)e << 23);
+    ex = t0 > -87.0f ? ex : (t0 != t0 ? t0 : 0.0f);
+    // pw_log1p01(ex)
+    const float den = 2.0f + ex;
+    float sq = div_chain(ex, den, div_refined_rcp(den));
+    sq = den == 2.0f ? ex * 0.5f : sq;
+    const float z = sq * sq;
+    float q = 6.66666666666666657e-2f;
+    q = q * z + 7.69230769230769273e-2f;
+    q = q * z + 9.09090909090909116e-2f;
+    q = q * z + 1.11111111111111105e-1f;
+    q = q * z + 1.42857142857142849e-1f;
+    q = q * z + 0.2f;
+    q = q * z + 3.33333333333333315e-1f;
+    q = q * z + 1.0f;
+    return m + 2.0f * sq * q;
+}
+
+// get_collision_force seen from entity i against entity j: force on i.
+// delta = p_i - p_j; dist = sqrt(sum(delta^2)); pen = logaddexp(0, -(dist - dist_min)/k) * k;
+// force = contact_force * delta / dist * pen.  (The force on the pair's second entity is
+// the exact negation, which is what this evaluates to from that entity's side.)
+// FAST: the same IEEE results through sqrt_rn_core / div_chain when every operand is provably in their range
+// (one range test per pair); anything else -- coincident or astronomically distant entities, a coordinate
+// difference below 2^-60, an exotic contact margin, NaN / inf -- takes the general expressions.
 template <bool FAST = false>
 __device__ __forceinline__ void collision_force(float px, float py, float qx, float qy, float dist_min,
                                                 float k, float cf, float &fx, float &fy)
 {
     const float dx = px - qx, dy = py - qy;
     const float d2 = dx * dx + dy * dy;
+    if (FAST) {
+        const f32x2 a = {cf * dx, cf * dy};
+        // one range test per pair, evaluated without short-circuit branches: d2 in [2^-90, 2^90) on the raw bits
+        // (d2 is a sum of squares: never negative; NaN fails), both numerators >= 2^-60 in magnitude (they are
+        // < 2^52 because |delta| < 2^45 and contact_force <= 128), and the wave-uniform contact parameters
+        const bool uni = (k >= 9.094947017729282e-13f) & (k <= 1099511627776.0f) & (cf >= 9.5367431640625e-07f) & (cf <= 128.0f);
+        const bool c1 = (__float_as_uint(d2) - 0x12800000u) < (0x6C800000u - 0x12800000u);
+        const bool c2 = fminf(fabsf(a.x), fabsf(a.y)) >= 8.673617379884035e-19f;
+        const bool in_range = c1 & c2 & uni;
+        if (__builtin_expect(in_range, 1)) {
+            const float dist = sqrt_rn_core(d2);
+            const float xarg = div_chain(-(dist - dist_min), k, div_refined_rcp(k));
+            const float pen = softplus_fastdiv(xarg) * k;
+            const f32x2 F = div_chain2(a, dist, div_refined_rcp(dist)) * f32x2{pen, pen};
+            fx = F.x + fx;
+            fy = F.y + fy;
+            return;
+        }
+    }
     const float dist = FAST ? sqrt_rn_fast(d2) : sqrtf(d2);
     const float xarg = -(dist - dist_min) / k;
     const float pen = (FAST ? softplus_branchless(xarg) : pw_softplus(xarg)) * k;

@@ -25,8 +25,6 @@ __device__ __forceinline__ float fast_tanh(float x)
     return copysignf(t, x);
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 // One hidden unit's four W_hh rows, gate pairs (i, f) and (g, o) packed so that a recurrence step is 64
 // v_pk_fma_f32 (two gates per instruction, h broadcast through op_sel) instead of 128 scalar FMAs.  Each
 // gate still accumulates over k in ascending order with fused multiply-adds: the same bits either way.
@@ -549,7 +547,8 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
 
 // Test hook: evaluate one device math primitive element-wise so that tests can compare the exact bits
 // against the CPU contract (include/pworld_math.h, restated in oracle/pworld_oracle.c) over millions of
-// inputs.  fn: 0 sqrt_rn_fast, 1 softplus_branchless, 2 pw_softplus, 3 pw_exp, 4 sqrtf, 5 x / aux (IEEE)
+// inputs.  fn: 0 sqrt_rn_fast, 1 softplus_branchless, 2 pw_softplus, 3 pw_exp, 4 sqrtf, 5 x / aux (IEEE),
+// 6 div_chain(x, aux), 7 div_chain(aux, x) (the scaling-free division of the hot loops), 8 softplus_fastdiv
 __global__ void pw_debug_math_kernel(const int fn, const float *x, const float aux, float *y, const long n)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -562,6 +561,10 @@ __global__ void pw_debug_math_kernel(const int fn, const float *x, const float a
     case 2: r = pw_softplus(v); break;
     case 3: r = pw_exp(v); break;
     case 4: r = sqrtf(v); break;
+    case 6: r = div_chain(v, aux, div_refined_rcp(aux)); break;
+    case 7: r = div_chain(aux, v, div_refined_rcp(v)); break;
+    case 8: r = softplus_fastdiv(v); break;
+    case 9: r = aux / v; break;
     default: r = v / aux; break;
     }
     y[i] = r;

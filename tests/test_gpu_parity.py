@@ -355,3 +355,62 @@ def test_device_math_primitives_match_cpu_contract_bitwise():
     _assert_same_bits(dev(3, xs), co.math_v(3, xs), 'pw_exp')
     for k in (1e-3, 0.3, 1.0):
         _assert_same_bits(dev(5, xs, k), co.math_v(5, xs, k), 'x / %g' % k)
+
+
+def test_scaling_free_division_chain_is_ieee_division_bitwise():
+    """The hot loops divide through a bare FMA chain (pw_common.hpp div_chain) inside a guarded operand range.
+    Inside that range it must BE IEEE division: compared with the device's own a / b and with the CPU's,
+    over tens of millions of operand pairs, dense around powers of two and at the range edges; the chain's
+    softplus against the branch-free one over every exponent, NaN, inf, the exact-zero cut."""
+    import ctypes as C
+    from multiagent_rl_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(5)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def dev(fn, x, aux=1.0):
+        xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        yd = torch.empty_like(xd)
+        assert lib.pw_debug_math(fn, C.c_void_p(xd.data_ptr()), C.c_float(aux), C.c_void_p(yd.data_ptr()), xd.numel(), stream) == 0
+        return yd.cpu().numpy()
+
+    def mags(lo_exp, hi_exp, n):  # random sign, exponent uniform in [lo_exp, hi_exp), random mantissa
+        e = rng.randint(lo_exp + 127, hi_exp + 127, n).astype(np.uint32) << 23
+        m = rng.randint(0, 1 << 23, n).astype(np.uint32)
+        sg = rng.randint(0, 2, n).astype(np.uint32) << 31
+        return (sg | e | m).view(np.float32)
+
+    def near_pow2(lo_exp, hi_exp, n):  # mantissas within a few ulps of 1.0 and of 2.0 (rounding-boundary stress)
+        e = rng.randint(lo_exp + 127, hi_exp + 127, n).astype(np.uint32) << 23
+        m = np.where(rng.randint(0, 2, n) == 0, rng.randint(0, 8, n), (1 << 23) - 1 - rng.randint(0, 8, n)).astype(np.uint32)
+        return (e | m).view(np.float32)
+
+    # numerators of the three kinds the kernels produce: -(dist - dist_min) (incl. exact zero), contact_force * delta
+    num = np.concatenate([mags(-69, 52, 4_000_000), near_pow2(-69, 52, 500_000), -near_pow2(-69, 52, 500_000),
+                          rng.uniform(-0.5, 0.5, 2_000_000).astype(np.float32), np.array([0.0, -0.0], np.float32)])
+    for k in (1e-3, 1e-2, 0.3, 1.0, 2.5, 3.0, 7.62939453125e-06, 9.094947017729282e-13, 1099511627776.0,
+              0.99999994, 1.9999999, 1.0000001, 35184372088832.0 / 2, 2.842170943040401e-14 * 2):
+        k = float(np.float32(k))
+        got, want = dev(6, num, k), dev(5, num, k)
+        nz = num != 0                       # a zero numerator gives a zero of either sign (callers do not care)
+        _assert_same_bits(got[nz], want[nz], 'chain x / %g vs device IEEE' % k)
+        assert (got[~nz] == 0).all()
+        _assert_same_bits(want, co.math_v(5, num, k), 'device IEEE x / %g vs CPU' % k)
+    # divisors: dist in [2^-45, 2^45], and log1p's 2 + t in (2, 3]
+    den = np.concatenate([np.abs(mags(-45, 45, 4_000_000)), near_pow2(-45, 45, 500_000),
+                          rng.uniform(0.05, 0.6, 2_000_000).astype(np.float32), rng.uniform(2.0, 3.0, 1_000_000).astype(np.float32)])
+    for a in (100.0, -100.0, 1.0, 3.0517578125e-05, 8.673617379884035e-19, 4503599627370495.0, 0.33333334, -17.123457,
+              1.0000001, 1.9999999):
+        a = float(np.float32(a))
+        lo, hi = abs(a) / 2.0 ** 100, abs(a) * 2.0 ** 100     # keep the quotient well inside the normal range
+        d = den[(den > lo) & (den < hi)]
+        _assert_same_bits(dev(7, d, a), dev(9, d, a), 'chain %g / x vs device IEEE' % a)
+        _assert_same_bits(dev(9, d, a), (np.float32(a) / d).astype(np.float32), 'device IEEE %g / x vs CPU' % a)
+    # softplus through the chain == the branch-free softplus == the CPU contract, everywhere
+    special = np.array([0.0, -0.0, 1e-45, 1e-38, 1.0, -1.0, 87.0, -87.0, -86.999, -87.001, 88.0, -300.0, 300.0, 17.0, -17.0,
+                        15.9, 16.0, 16.1, -15.9, -16.0, -16.1, np.inf, -np.inf, np.nan], np.float32)
+    bits = rng.randint(0, 2 ** 32, 3_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    xs = np.concatenate([special, bits, rng.uniform(-100, 320, 3_000_000).astype(np.float32),
+                         rng.uniform(-20, 20, 3_000_000).astype(np.float32)])
+    _assert_same_bits(dev(8, xs), dev(1, xs), 'softplus_fastdiv vs softplus_branchless')
+    _assert_same_bits(dev(8, xs), co.math_v(1, xs), 'softplus_fastdiv vs CPU contract')
