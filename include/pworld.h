@@ -56,8 +56,9 @@ extern "C" {
 #define PW_MAX_AGENTS 64
 #define PW_MAX_LANDMARKS 64
 
-enum pw_scenario { PW_SIMPLE_SPREAD = 0, PW_SIMPLE_TAG = 1, PW_SIMPLE_REFERENCE = 2 };
-#define PW_DIM_C 10 /* simple_reference: world.dim_c communication symbols */
+enum pw_scenario { PW_SIMPLE_SPREAD = 0, PW_SIMPLE_TAG = 1, PW_SIMPLE_REFERENCE = 2, PW_SIMPLE_SPEAKER_LISTENER = 3 };
+#define PW_DIM_C 10   /* simple_reference: world.dim_c communication symbols */
+#define PW_SL_DIM_C 3 /* simple_speaker_listener: world.dim_c */
 enum pw_obs_mode { PW_OBS_LOCAL = 0, PW_OBS_FULL = 1 };
 enum pw_error {
     PW_OK = 0,
@@ -95,7 +96,8 @@ typedef struct pw_config {
 typedef struct pw_state_layout {
     size_t pos_x, pos_y, vel_x, vel_y, lm_x, lm_y, ep_step, ep_count; /* byte offsets */
     size_t total_bytes;
-    size_t comm, goal; /* simple_reference only: state.c [B*N*PW_DIM_C] f32, goal_b index [B*N] i32 */
+    size_t comm, goal; /* communication scenarios only: state.c [B*N*dim_c] f32 (dim_c = PW_DIM_C for simple_reference,
+                          PW_SL_DIM_C for simple_speaker_listener), goal_b index [B*N] i32 */
 } pw_state_layout;
 
 /* Buffers of one step (T = 1) or of a T-step rollout (leading dimension T).
@@ -113,16 +115,21 @@ typedef struct pw_step_io {
     uint64_t *coll;         /* [T,B,N] */
     const int32_t *act_comm; /* [T,B,N] communication symbol 0..PW_DIM_C-1; simple_reference with act_idx.
                                 There act_vec is [T,B,N,5+PW_DIM_C]: the concatenated MultiDiscrete action of
-                                experiments/run.py:39-41 (movement one-hot | communication vector) */
+                                experiments/run.py:39-41 (movement one-hot | communication vector).
+                                simple_speaker_listener has one action head per agent (upstream environment.py:
+                                Discrete(3) for the speaker, Discrete(5) for the listener): act_idx [T,B,N] =
+                                (symbol 0..2 of agent 0, movement 0..4 of agent 1), or act_vec [T,B,N,5] with the
+                                speaker's vector in the first three entries; act_comm stays NULL */
 } pw_step_io;
 
 int pw_version(void);
 const char *pw_last_error(void);
 
 /* Canonical upstream constants for a scenario: simple_spread (N agents, L = N
- * landmarks), simple_tag (num_adversaries + good, L = 2) or simple_reference (2 speaking agents, L = 3;
- * obs = [p_vel, landmark - pos, goal_b colour, other agent's c], D = 21). Replaces Scenario.make_world() +
- * World.__init__(). */
+ * landmarks), simple_tag (num_adversaries + good, L = 2), simple_reference (2 speaking agents, L = 3;
+ * obs = [p_vel, landmark - pos, goal_b colour, other agent's c], D = 21) or simple_speaker_listener (a fixed
+ * speaker + a silent moving listener, L = 3; obs = [p_vel, landmark - pos, goal_b colour or zeros], D = 11, the
+ * observation experiments/scenarios.py:45-64 patches in). Replaces Scenario.make_world() + World.__init__(). */
 int pw_config_default(pw_config *cfg, int scenario, int num_envs, int num_agents,
                       int num_landmarks /* <0: scenario default */, int num_adversaries);
 
@@ -143,8 +150,8 @@ int pw_set_state(pw_handle *h, const float *pos, const float *vel, const float *
 int pw_get_state(pw_handle *h, float *pos, float *vel, float *lm,
                  int32_t *ep_step, uint32_t *ep_count, void *stream);
 
-/* simple_reference only: the communication state (agent.state.c, [B,N,PW_DIM_C] f32) and each agent's goal
- * landmark index (goal_b, [B,N] i32).  Either pointer may be NULL. */
+/* Communication scenarios only: the communication state (agent.state.c, [B,N,dim_c] f32) and each agent's goal
+ * landmark index (goal_b, [B,N] i32; the listener's entry is unused).  Either pointer may be NULL. */
 int pw_set_comm_state(pw_handle *h, const float *comm, const int32_t *goal, void *stream);
 int pw_get_comm_state(pw_handle *h, float *comm, int32_t *goal, void *stream);
 

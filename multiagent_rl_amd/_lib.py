@@ -12,10 +12,12 @@ LIB_PATH = os.path.join(HERE, 'libpworld.so')
 
 PW_MAX_AGENTS = 64
 PW_MAX_LANDMARKS = 64
-PW_SIMPLE_SPREAD, PW_SIMPLE_TAG, PW_SIMPLE_REFERENCE = 0, 1, 2
+PW_SIMPLE_SPREAD, PW_SIMPLE_TAG, PW_SIMPLE_REFERENCE, PW_SIMPLE_SPEAKER_LISTENER = 0, 1, 2, 3
 PW_DIM_C = 10
+PW_SL_DIM_C = 3
 PW_OBS_LOCAL, PW_OBS_FULL = 0, 1
-SCENARIOS = {'simple_spread': PW_SIMPLE_SPREAD, 'simple_tag': PW_SIMPLE_TAG, 'simple_reference': PW_SIMPLE_REFERENCE}
+SCENARIOS = {'simple_spread': PW_SIMPLE_SPREAD, 'simple_tag': PW_SIMPLE_TAG, 'simple_reference': PW_SIMPLE_REFERENCE,
+             'simple_speaker_listener': PW_SIMPLE_SPEAKER_LISTENER}
 
 
 class PwConfig(C.Structure):

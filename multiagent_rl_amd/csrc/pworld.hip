@@ -58,6 +58,7 @@ int obs_dim_of(const pw_config &c)
     const int N = c.num_agents, L = c.num_landmarks;
     if (c.scenario == PW_SIMPLE_SPREAD) return c.obs_mode == PW_OBS_FULL ? 4 + 2 * L + 4 * (N - 1) : 4 + 2 * L;
     if (c.scenario == PW_SIMPLE_REFERENCE) return 2 + 2 * L + 3 + PW_DIM_C * (N - 1);
+    if (c.scenario == PW_SIMPLE_SPEAKER_LISTENER) return 2 + 2 * L + 3;
     const int G = N - c.num_adversaries;
     return 4 + 2 * L + 2 * (N - 1) + 2 * (c.num_adversaries > 0 ? G : G - 1);
 }
@@ -74,6 +75,9 @@ RefParams ref_params(const pw_handle *h)
     R.comm = h->comm; R.goal = h->goal; R.ep_step = kp.ep_step; R.ep_count = kp.ep_count;
     return R;
 }
+
+bool is_comm_scenario(int scenario) { return scenario == PW_SIMPLE_REFERENCE || scenario == PW_SIMPLE_SPEAKER_LISTENER; }
+int dim_c_of(int scenario) { return scenario == PW_SIMPLE_REFERENCE ? PW_DIM_C : scenario == PW_SIMPLE_SPEAKER_LISTENER ? PW_SL_DIM_C : 0; }
 
 template <typename F>
 int dispatch(const pw_handle *h, F &&f)
@@ -192,7 +196,8 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
     if ((io->act_idx == nullptr) == (io->act_vec == nullptr))
         return fail(PW_EINVAL, "exactly one of act_idx / act_vec must be given");
     if (io->act_comm && h->cfg.scenario != PW_SIMPLE_REFERENCE)
-        return fail(PW_EINVAL, "act_comm only applies to simple_reference (the other scenarios' agents are silent)");
+        return fail(PW_EINVAL, "act_comm only applies to simple_reference (simple_speaker_listener's speaker takes its symbol "
+                               "from act_idx; the other scenarios' agents are silent)");
     if (io->obs && (reinterpret_cast<uintptr_t>(io->obs) & 15))
         return fail(PW_EINVAL, "obs must be 16-byte aligned");
     if (io->final_obs && (reinterpret_cast<uintptr_t>(io->final_obs) & 15))
@@ -200,8 +205,14 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
     const KParams &kp = h->kp;
     if (h->cfg.scenario == PW_SIMPLE_REFERENCE) {
         if (io->act_idx && !io->act_comm) return fail(PW_EINVAL, "simple_reference needs act_comm next to act_idx");
-        hipLaunchKernelGGL(pw_reference_rollout_kernel, dim3((kp.B + 31) / 32), dim3(kWave), 0,
+        hipLaunchKernelGGL((pw_reference_rollout_kernel<kDimC, false>), dim3((kp.B + 31) / 32), dim3(kWave), 0,
                            static_cast<hipStream_t>(stream), ref_params(h), *io, io->act_comm, T);
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
+    if (h->cfg.scenario == PW_SIMPLE_SPEAKER_LISTENER) {
+        hipLaunchKernelGGL((pw_reference_rollout_kernel<kDimCSL, true>), dim3((kp.B + 31) / 32), dim3(kWave), 0,
+                           static_cast<hipStream_t>(stream), ref_params(h), *io, nullptr, T);
         PW_HIP_CHECK(hipGetLastError());
         return PW_OK;
     }
@@ -319,10 +330,14 @@ int launch_aux(pw_handle *h, int mode, const uint8_t *env_mask, float *obs, floa
     if (int rc = check_ready(h)) return rc;
     if (obs && (reinterpret_cast<uintptr_t>(obs) & 15)) return fail(PW_EINVAL, "obs must be 16-byte aligned");
     const KParams &kp = h->kp;
-    if (h->cfg.scenario == PW_SIMPLE_REFERENCE) {
-        if (coll) return fail(PW_EINVAL, "simple_reference has no collisions");
-        hipLaunchKernelGGL(pw_reference_aux_kernel, dim3((kp.B + 31) / 32), dim3(kWave), 0,
-                           static_cast<hipStream_t>(stream), ref_params(h), mode, env_mask, obs, rew);
+    if (is_comm_scenario(h->cfg.scenario)) {
+        if (coll) return fail(PW_EINVAL, "the communication scenarios have no collisions");
+        if (h->cfg.scenario == PW_SIMPLE_REFERENCE)
+            hipLaunchKernelGGL((pw_reference_aux_kernel<kDimC, false>), dim3((kp.B + 31) / 32), dim3(kWave), 0,
+                               static_cast<hipStream_t>(stream), ref_params(h), mode, env_mask, obs, rew);
+        else
+            hipLaunchKernelGGL((pw_reference_aux_kernel<kDimCSL, true>), dim3((kp.B + 31) / 32), dim3(kWave), 0,
+                               static_cast<hipStream_t>(stream), ref_params(h), mode, env_mask, obs, rew);
         PW_HIP_CHECK(hipGetLastError());
         return PW_OK;
     }
@@ -398,6 +413,17 @@ int pw_config_default(pw_config *cfg, int scenario, int num_envs, int num_agents
             cfg->agent_accel[i] = -1.0f;
             cfg->agent_max_speed[i] = -1.0f;
         }
+    } else if (scenario == PW_SIMPLE_SPEAKER_LISTENER) {
+        cfg->num_agents = 2;  // upstream simple_speaker_listener.make_world: speaker + listener, three landmarks
+        cfg->num_landmarks = num_landmarks < 0 ? 3 : num_landmarks;
+        cfg->num_adversaries = 0;
+        cfg->landmark_collide = 0;
+        cfg->landmark_size = 0.04f;
+        for (int i = 0; i < 2; ++i) {
+            cfg->agent_size[i] = 0.075f;
+            cfg->agent_accel[i] = -1.0f;
+            cfg->agent_max_speed[i] = -1.0f;
+        }
     } else {
         return fail(PW_EINVAL, "unknown scenario");
     }
@@ -408,10 +434,10 @@ int pw_create(const pw_config *cfg, pw_handle **out)
 {
     if (!cfg || !out) return fail(PW_EINVAL, "null argument");
     if (cfg->struct_size != sizeof(pw_config)) return fail(PW_EINVAL, "pw_config.struct_size mismatch (ABI)");
-    if (cfg->scenario != PW_SIMPLE_SPREAD && cfg->scenario != PW_SIMPLE_TAG && cfg->scenario != PW_SIMPLE_REFERENCE)
+    if (cfg->scenario != PW_SIMPLE_SPREAD && cfg->scenario != PW_SIMPLE_TAG && !is_comm_scenario(cfg->scenario))
         return fail(PW_EINVAL, "unknown scenario");
-    if (cfg->scenario == PW_SIMPLE_REFERENCE && (cfg->num_agents != 2 || cfg->num_landmarks < 1 || cfg->num_landmarks > 3))
-        return fail(PW_EINVAL, "simple_reference is two agents and 1..3 landmarks");
+    if (is_comm_scenario(cfg->scenario) && (cfg->num_agents != 2 || cfg->num_landmarks < 1 || cfg->num_landmarks > 3))
+        return fail(PW_EINVAL, "simple_reference / simple_speaker_listener are two agents and 1..3 landmarks");
     if (cfg->num_envs < 1) return fail(PW_EINVAL, "num_envs must be >= 1");
     if (cfg->num_agents < 1 || cfg->num_agents > PW_MAX_AGENTS) return fail(PW_EINVAL, "num_agents out of range [1, 64]");
     if (cfg->num_landmarks < 0 || cfg->num_landmarks > PW_MAX_LANDMARKS) return fail(PW_EINVAL, "num_landmarks out of range [0, 64]");
@@ -466,8 +492,8 @@ int pw_create(const pw_config *cfg, pw_handle **out)
     lo.ep_step = off; off = align_up(off + (size_t)kp.B * 4, 256);
     lo.ep_count = off; off = align_up(off + (size_t)kp.B * 4, 256);
     lo.comm = lo.goal = 0;
-    if (cfg->scenario == PW_SIMPLE_REFERENCE) {
-        lo.comm = off; off = align_up(off + BN * PW_DIM_C * 4, 256);
+    if (is_comm_scenario(cfg->scenario)) {
+        lo.comm = off; off = align_up(off + BN * dim_c_of(cfg->scenario) * 4, 256);
         lo.goal = off; off = align_up(off + BN * 4, 256);
     }
     lo.total_bytes = off;
@@ -551,10 +577,11 @@ int pw_get_state(pw_handle *h, float *pos, float *vel, float *lm, int32_t *ep_st
 int pw_set_comm_state(pw_handle *h, const float *comm, const int32_t *goal, void *stream)
 {
     if (int rc = check_ready(h)) return rc;
-    if (h->cfg.scenario != PW_SIMPLE_REFERENCE) return fail(PW_EINVAL, "this scenario has no communication state");
-    const size_t n = (size_t)h->kp.B * 2 * PW_DIM_C;
+    if (!is_comm_scenario(h->cfg.scenario)) return fail(PW_EINVAL, "this scenario has no communication state");
+    const int dc = dim_c_of(h->cfg.scenario);
+    const size_t n = (size_t)h->kp.B * 2 * dc;
     hipLaunchKernelGGL(pw_reference_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), ref_params(h), 1, const_cast<float *>(comm),
+                       static_cast<hipStream_t>(stream), ref_params(h), 1, dc, const_cast<float *>(comm),
                        const_cast<int32_t *>(goal));
     PW_HIP_CHECK(hipGetLastError());
     return PW_OK;
@@ -563,10 +590,11 @@ int pw_set_comm_state(pw_handle *h, const float *comm, const int32_t *goal, void
 int pw_get_comm_state(pw_handle *h, float *comm, int32_t *goal, void *stream)
 {
     if (int rc = check_ready(h)) return rc;
-    if (h->cfg.scenario != PW_SIMPLE_REFERENCE) return fail(PW_EINVAL, "this scenario has no communication state");
-    const size_t n = (size_t)h->kp.B * 2 * PW_DIM_C;
+    if (!is_comm_scenario(h->cfg.scenario)) return fail(PW_EINVAL, "this scenario has no communication state");
+    const int dc = dim_c_of(h->cfg.scenario);
+    const size_t n = (size_t)h->kp.B * 2 * dc;
     hipLaunchKernelGGL(pw_reference_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), ref_params(h), 0, comm, goal);
+                       static_cast<hipStream_t>(stream), ref_params(h), 0, dc, comm, goal);
     PW_HIP_CHECK(hipGetLastError());
     return PW_OK;
 }

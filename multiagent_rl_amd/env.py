@@ -81,7 +81,7 @@ def make_config(scenario_name, num_envs, num_agents=None, num_landmarks=None, nu
     if scenario_name not in _lib.SCENARIOS:
         raise ValueError('unsupported scenario: %r (supported: %s)' % (scenario_name, sorted(_lib.SCENARIOS)))
     scen = _lib.SCENARIOS[scenario_name]
-    if scen == _lib.PW_SIMPLE_REFERENCE:
+    if scen in (_lib.PW_SIMPLE_REFERENCE, _lib.PW_SIMPLE_SPEAKER_LISTENER):
         adv, n = 0, 2
     elif scen == _lib.PW_SIMPLE_TAG:
         adv = 3 if num_adversaries is None else int(num_adversaries)
@@ -134,10 +134,23 @@ class BatchedParticleEnv(object):
         self.obs_dim = self.lib.pw_obs_dim(h)
         self.want_coll = want_coll
         self.observation_space = [Box((self.obs_dim,)) for _ in range(self.n)]
-        # simple_reference agents move AND speak: MultiDiscrete [5 movement | dim_c symbols]
-        self.dim_c = _lib.PW_DIM_C if self.cfg.scenario == _lib.PW_SIMPLE_REFERENCE else 0
-        self.action_space = [MultiDiscrete([[0, 4], [0, self.dim_c - 1]]) if self.dim_c else Discrete(5)
-                             for _ in range(self.n)]
+        # simple_reference agents move AND speak: MultiDiscrete [5 movement | dim_c symbols];
+        # simple_speaker_listener: a fixed speaker (Discrete(dim_c = 3)) and a silent listener (Discrete(5)),
+        # the per-agent spaces upstream's environment.py builds from agent.movable / agent.silent
+        self.speaker_listener = self.cfg.scenario == _lib.PW_SIMPLE_SPEAKER_LISTENER
+        self.dim_c = {_lib.PW_SIMPLE_REFERENCE: _lib.PW_DIM_C,
+                      _lib.PW_SIMPLE_SPEAKER_LISTENER: _lib.PW_SL_DIM_C}.get(self.cfg.scenario, 0)
+        if self.speaker_listener:
+            if self.cfg.obs_mode != _lib.PW_OBS_LOCAL:
+                raise NotImplementedError('simple_speaker_listener: only the observation the reference patches in '
+                                          '(experiments/scenarios.py:45-64, local_observation=True) is built; '
+                                          "upstream's has a different length per agent")
+            self.action_space = [Discrete(self.dim_c), Discrete(5)]
+            self.act_width = 5
+        else:
+            self.action_space = [MultiDiscrete([[0, 4], [0, self.dim_c - 1]]) if self.dim_c else Discrete(5)
+                                 for _ in range(self.n)]
+            self.act_width = 5 + self.dim_c
         with torch.cuda.device(self.device):
             self._state = torch.zeros(self.lib.pw_state_bytes(h), dtype=torch.uint8, device=self.device)
         check(self.lib.pw_bind_state(h, _ptr(self._state)))
@@ -213,6 +226,10 @@ class BatchedParticleEnv(object):
 
     def reward(self):
         rew = self._f32(self.num_envs, self.n)
+        if self.dim_c:  # the communication scenarios have no collisions
+            coll = torch.zeros(self.num_envs, self.n, dtype=torch.int64, device=self.device)
+            check(self.lib.pw_reward(self._h, _ptr(rew), None, self._stream()))
+            return rew, coll
         coll = torch.empty(self.num_envs, self.n, dtype=torch.int64, device=self.device)
         check(self.lib.pw_reward(self._h, _ptr(rew), _ptr(coll), self._stream()))
         return rew, coll
@@ -237,9 +254,9 @@ class BatchedParticleEnv(object):
         actions = torch.as_tensor(actions)
         if actions.is_floating_point():
             a = actions.to(device=self.device, dtype=torch.float32).contiguous()
-            assert a.shape == lead + (5 + self.dim_c,), 'float actions must be [..., B, N, %d]' % (5 + self.dim_c)
+            assert a.shape == lead + (self.act_width,), 'float actions must be [..., B, N, %d]' % self.act_width
             io.act_vec = a.data_ptr()
-        elif self.dim_c:  # simple_reference: [..., B, N, 2] = (movement index, communication symbol)
+        elif self.dim_c and not self.speaker_listener:  # simple_reference: [..., B, N, 2] = (movement, symbol)
             assert actions.shape == lead + (2,), 'index actions must be [..., B, N, 2] (move, symbol)'
             a = actions.to(device=self.device, dtype=torch.int32)
             a = (a[..., 0].contiguous(), a[..., 1].contiguous())
@@ -323,7 +340,7 @@ class MultiAgentEnv(object):
         self._dims = dims
         self.observation_space = [Box((d,)) for d in dims]
         self.action_space = list(self.batched.action_space)
-        self._act_width = 5 + self.batched.dim_c
+        self._act_width = self.batched.act_width
         self.benchmark = benchmark
         self.discrete_action_space = discrete_action
         self.discrete_action_input = False
@@ -343,6 +360,9 @@ class MultiAgentEnv(object):
             # BEFORE any position is drawn (same global stream)
             idx = list(range(L))
             goal = np.array([[np.random.choice(idx), np.random.choice(idx)]], dtype=np.int32)
+        elif self.scenario_name == 'simple_speaker_listener':
+            # upstream reset_world: ONE choice (the speaker's goal_b) before the positions
+            goal = np.array([[np.random.choice(list(range(L))), 0]], dtype=np.int32)
         lo = 0.9 if self.scenario_name == 'simple_tag' else 1.0
         pos = np.stack([np.random.uniform(-1, +1, 2) for _ in range(N)]) if N else np.zeros((0, 2))
         lm = np.stack([np.random.uniform(-lo, +lo, 2) for _ in range(L)]) if L else np.zeros((0, 2))
@@ -362,7 +382,14 @@ class MultiAgentEnv(object):
         return self._rows(self.batched.observe())
 
     def step(self, action_n):
-        a = np.stack([np.asarray(x, dtype=np.float32).reshape(self._act_width) for x in action_n])[None]
+        if self.scenario_name == 'simple_speaker_listener':
+            # per-agent action lengths (speaker 3, listener 5): rows are padded to the common width
+            a = np.zeros((1, self.n, self._act_width), np.float32)
+            for i, x in enumerate(action_n):
+                x = np.asarray(x, dtype=np.float32).reshape(self.action_space[i].n)
+                a[0, i, :x.size] = x
+        else:
+            a = np.stack([np.asarray(x, dtype=np.float32).reshape(self._act_width) for x in action_n])[None]
         self._sync_force_discrete()
         obs, rew, done, info = self.batched.step(torch.from_numpy(a))
         rew_n = list(rew[0].cpu().numpy().astype(np.float64))  # np.float64 scalars, as upstream's reward()

@@ -205,11 +205,16 @@ class FusedActor(object):
 
 
 class UniformRandomPolicy(object):
-    """i.i.d. uniform action indices (the synthetic-action workload of bench.py)."""
+    """i.i.d. uniform action indices (the synthetic-action workload of bench.py).  ``num_actions`` may be a
+    list with one entry per agent (simple_speaker_listener: [3, 5])."""
 
     def __init__(self, num_actions=5, generator=None):
         self.num_actions, self.generator = num_actions, generator
 
     def __call__(self, obs):
+        if isinstance(self.num_actions, (list, tuple)):
+            cols = [torch.randint(0, int(n), obs.shape[:1], device=obs.device, dtype=torch.int32, generator=self.generator)
+                    for n in self.num_actions]
+            return torch.stack(cols, 1)
         return torch.randint(0, self.num_actions, obs.shape[:2], device=obs.device, dtype=torch.int32,
                              generator=self.generator)

@@ -8,7 +8,7 @@ kernels.  ``make_batched_env`` is the [B x N] tensor form of the same env.
 """
 from .env import BatchedParticleEnv, MultiAgentEnv
 
-SUPPORTED = ('simple_spread', 'simple_tag', 'simple_reference')
+SUPPORTED = ('simple_spread', 'simple_tag', 'simple_reference', 'simple_speaker_listener')
 
 
 def make_env(scenario_name, n=None, local_observation=True, benchmark=False, discrete_action=True, **kw):

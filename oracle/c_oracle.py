@@ -14,8 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, 'libpworld_oracle.so')
 
 PO_MAX_AGENTS = 64
-SIMPLE_SPREAD, SIMPLE_TAG, SIMPLE_REFERENCE = 0, 1, 2
-DIM_C = 10
+SIMPLE_SPREAD, SIMPLE_TAG, SIMPLE_REFERENCE, SIMPLE_SPEAKER_LISTENER = 0, 1, 2, 3
+DIM_C = 10      # simple_reference
+SL_DIM_C = 3    # simple_speaker_listener
 OBS_LOCAL, OBS_FULL = 0, 1
 
 
@@ -97,6 +98,14 @@ def make_config(scenario='simple_spread', num_agents=3, num_landmarks=None, num_
         c.num_adversaries = 0
         for i in range(N):
             c.agent_size[i], c.agent_accel[i], c.agent_max_speed[i] = 0.05, -1.0, -1.0
+    elif scenario == 'simple_speaker_listener':
+        c.scenario = SIMPLE_SPEAKER_LISTENER
+        N, L = 2, 3
+        c.landmark_collide = 0
+        c.landmark_size = 0.04
+        c.num_adversaries = 0
+        for i in range(N):
+            c.agent_size[i], c.agent_accel[i], c.agent_max_speed[i] = 0.075, -1.0, -1.0
     else:
         raise ValueError(scenario)
     c.num_agents, c.num_landmarks = N, L
@@ -187,10 +196,13 @@ class COracle(object):
 
 
 class CRefOracle(object):
-    """simple_reference worlds (comm channel + goals) advanced by the C restatement."""
+    """simple_reference / simple_speaker_listener worlds (comm channel + goals) advanced by the C restatement."""
 
     def __init__(self, cfg, B, dtype=np.float32):
-        assert cfg.scenario == SIMPLE_REFERENCE
+        assert cfg.scenario in (SIMPLE_REFERENCE, SIMPLE_SPEAKER_LISTENER)
+        self.sl = cfg.scenario == SIMPLE_SPEAKER_LISTENER
+        self.dim_c = SL_DIM_C if self.sl else DIM_C
+        self.act_width = 5 if self.sl else 5 + DIM_C
         self.cfg, self.B = cfg, B
         self.dtype = np.dtype(dtype)
         self.sfx = '_f32' if self.dtype == np.float32 else '_f64'
@@ -200,7 +212,7 @@ class CRefOracle(object):
         self.pos = np.zeros((B, self.N, 2), self.dtype)
         self.vel = np.zeros((B, self.N, 2), self.dtype)
         self.lm = np.zeros((B, self.L, 2), self.dtype)
-        self.comm = np.zeros((B, self.N, DIM_C), self.dtype)
+        self.comm = np.zeros((B, self.N, self.dim_c), self.dtype)
         self.goal = np.zeros((B, self.N), np.int32)
         self.ep_step = np.zeros(B, np.int32)
         self.ep_count = np.zeros(B, np.uint32)
@@ -231,7 +243,7 @@ class CRefOracle(object):
                    rew=np.zeros((B, N), self.dtype), done=np.zeros((B, N), np.uint8), terminal=np.zeros(B, np.uint8))
         ai = None if act_idx is None else np.ascontiguousarray(act_idx, np.int32).reshape(B, N)
         ac = None if act_comm is None else np.ascontiguousarray(act_comm, np.int32).reshape(B, N)
-        av = None if act_vec is None else np.ascontiguousarray(act_vec, self.dtype).reshape(B, N, 5 + DIM_C)
+        av = None if act_vec is None else np.ascontiguousarray(act_vec, self.dtype).reshape(B, N, self.act_width)
         rc = getattr(lib(), 'po_ref_step' + self.sfx)(
             C.byref(self.cfg), B, *self._state(), _p(self.ep_step, C.c_int32), _p(self.ep_count, C.c_uint32),
             _p(ai, C.c_int32), _p(ac, C.c_int32), _p(av, self.ct), _p(out['obs'], self.ct),

@@ -503,6 +503,84 @@ class SimpleReference(object):
     observation_local = observation_full  # experiments/scenarios.py:23-42 is the same expression
 
 
+class SimpleSpeakerListener(object):
+    """Canonical simple_speaker_listener (main.py:24 lists it): agent 0 is a fixed
+    speaker that knows the goal landmark and emits one of dim_c = 3 symbols, agent 1 a silent listener that
+    moves; both are rewarded with -|p_listener - p_goal|^2.  Action spaces differ per agent (Discrete(3) for
+    the speaker, Discrete(5) for the listener), as upstream's environment.py builds them.
+    observation_local is the one the reference patches in (experiments/scenarios.py:45-64): [p_vel] +
+    landmark_rel + [goal_b.color, or zeros for the listener] -- 11 numbers for BOTH agents, and the spoken symbol
+    is collected but not included.  observation_full is upstream's (speaker: 3 numbers, listener: 11)."""
+
+    name = 'simple_speaker_listener'
+    LANDMARK_COLORS = [(0.65, 0.15, 0.15), (0.15, 0.65, 0.15), (0.15, 0.15, 0.65)]
+
+    def make_world(self):
+        world = World()
+        world.dim_c = 3
+        world.collaborative = True
+        world.agents = [Agent() for _ in range(2)]
+        for i, agent in enumerate(world.agents):
+            agent.name = 'agent %d' % i
+            agent.collide = False
+            agent.size = 0.075
+        world.agents[0].movable = False   # speaker
+        world.agents[1].silent = True     # listener
+        world.landmarks = [Landmark() for _ in range(3)]
+        for i, landmark in enumerate(world.landmarks):
+            landmark.name = 'landmark %d' % i
+            landmark.collide = False
+            landmark.movable = False
+            landmark.size = 0.04
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for agent in world.agents:
+            agent.goal_a = None
+            agent.goal_b = None
+        # draw order on the global NumPy stream: one choice, then agents, then landmarks
+        world.agents[0].goal_a = world.agents[1]
+        world.agents[0].goal_b = np.random.choice(world.landmarks)
+        for agent in world.agents:
+            agent.color = np.array([0.25, 0.25, 0.25])
+        for landmark, col in zip(world.landmarks, self.LANDMARK_COLORS):
+            landmark.color = np.array(col)
+        world.agents[0].goal_a.color = world.agents[0].goal_b.color + np.array([0.45, 0.45, 0.45])
+        for agent in world.agents:
+            agent.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            agent.state.p_vel = np.zeros(world.dim_p)
+            agent.state.c = np.zeros(world.dim_c)
+        for landmark in world.landmarks:
+            landmark.state.p_pos = np.random.uniform(-1, +1, world.dim_p)
+            landmark.state.p_vel = np.zeros(world.dim_p)
+
+    def reward(self, agent, world):
+        a = world.agents[0]
+        dist2 = np.sum(np.square(a.goal_a.state.p_pos - a.goal_b.state.p_pos))
+        return -dist2
+
+    def benchmark_data(self, agent, world):
+        return self.reward(agent, world)
+
+    def observation_full(self, agent, world):
+        goal_color = np.zeros(world.dim_color)
+        if agent.goal_b is not None:
+            goal_color = agent.goal_b.color
+        entity_pos = [e.state.p_pos - agent.state.p_pos for e in world.landmarks]
+        comm = [other.state.c for other in world.agents if other is not agent and other.state.c is not None]
+        if not agent.movable:   # speaker
+            return np.concatenate([goal_color])
+        return np.concatenate([agent.state.p_vel] + entity_pos + comm)   # listener
+
+    def observation_local(self, agent, world):
+        goal_color = np.zeros(world.dim_color)
+        if agent.goal_b is not None:
+            goal_color = agent.goal_b.color
+        entity_pos = [e.state.p_pos - agent.state.p_pos for e in world.landmarks]
+        return np.concatenate([agent.state.p_vel] + entity_pos + [goal_color])
+
+
 # ----------------------------------------------------------------------------
 # environment (U1, U2)
 # ----------------------------------------------------------------------------
@@ -682,6 +760,9 @@ def make_oracle_env(scenario_name, n=None, local_observation=True, benchmark=Fal
         world = scenario.make_world(**world_kwargs)
     elif scenario_name == 'simple_reference':
         scenario = SimpleReference()
+        world = scenario.make_world(**world_kwargs)
+    elif scenario_name == 'simple_speaker_listener':
+        scenario = SimpleSpeakerListener()
         world = scenario.make_world(**world_kwargs)
     else:
         raise ValueError('unsupported scenario: %r' % (scenario_name,))

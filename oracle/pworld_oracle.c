@@ -30,8 +30,9 @@
 #define PO_EXPORT __attribute__((visibility("default")))
 #define PO_MAX_AGENTS 64
 #define PO_MAX_ENTITIES 192
-enum { PO_SIMPLE_SPREAD = 0, PO_SIMPLE_TAG = 1, PO_SIMPLE_REFERENCE = 2 };
-#define PO_DIM_C 10 /* simple_reference: world.dim_c */
+enum { PO_SIMPLE_SPREAD = 0, PO_SIMPLE_TAG = 1, PO_SIMPLE_REFERENCE = 2, PO_SIMPLE_SPEAKER_LISTENER = 3 };
+#define PO_DIM_C 10   /* simple_reference: world.dim_c */
+#define PO_SL_DIM_C 3 /* simple_speaker_listener: world.dim_c */
 enum { PO_OBS_LOCAL = 0, PO_OBS_FULL = 1 };
 
 typedef struct po_config {
@@ -61,6 +62,7 @@ PO_EXPORT int po_obs_dim(const po_config *c)
     if (c->scenario == PO_SIMPLE_SPREAD)
         return c->obs_mode == PO_OBS_FULL ? 4 + 2 * L + 4 * (N - 1) : 4 + 2 * L;
     if (c->scenario == PO_SIMPLE_REFERENCE) return 2 + 2 * L + 3 + PO_DIM_C * (N - 1);
+    if (c->scenario == PO_SIMPLE_SPEAKER_LISTENER) return 2 + 2 * L + 3; /* experiments/scenarios.py:45-64 */
     /* simple_tag: adversary rows are the widest (see all G good velocities) */
     const int G = N - c->num_adversaries;
     return 4 + 2 * L + 2 * (N - 1) + 2 * (c->num_adversaries > 0 ? G : G - 1);
@@ -161,6 +163,12 @@ PO_EXPORT int32_t po_philox_goal(uint64_t seed, uint64_t env_id, uint32_t episod
 }
 
 static const float PO_LM_COLOR[3][3] = {{0.75f, 0.25f, 0.25f}, {0.25f, 0.75f, 0.25f}, {0.25f, 0.25f, 0.75f}};
+static const float PO_SL_COLOR[3][3] = {{0.65f, 0.15f, 0.15f}, {0.15f, 0.65f, 0.15f}, {0.15f, 0.15f, 0.65f}};
+
+PO_EXPORT int po_dim_c(const po_config *c)
+{
+    return c->scenario == PO_SIMPLE_REFERENCE ? PO_DIM_C : c->scenario == PO_SIMPLE_SPEAKER_LISTENER ? PO_SL_DIM_C : 0;
+}
 
 #define PO_CAT_(a, b) a##b
 #define PO_CAT(a, b) PO_CAT_(a, b)

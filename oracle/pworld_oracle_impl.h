@@ -312,16 +312,23 @@ PO_EXPORT int SUFFIX(po_reward)(const po_config *c, int B, const REAL *pos, cons
 
 
 /* ------------------------------------------------------------------------------------------------
- * simple_reference: N = 2 agents that move and speak (dim_c = 10), L = 3
- * landmarks, nobody collides.  Extra state: comm [B,N,10] (state.c after the last step) and goal [B,N]
- * (index of goal_b).  Actions: act_idx [B,N] (move) + act_comm [B,N] (symbol), or act_vec [B,N,15].
- * obs = [p_vel] + landmark_rel + goal_b.color + other agent's c  (experiments/scenarios.py:23-42).
- * reward_i = -|p_other - p_goal_b(i)|^2.
+ * The two communication scenarios: N = 2 agents, L <= 3 landmarks, nobody collides.
+ * Extra state: comm [B,N,dim_c] (state.c after the last step) and goal [B,N] (index of goal_b).
+ *
+ * simple_reference: both agents move and speak (dim_c = 10).  Actions: act_idx [B,N] (move) + act_comm [B,N]
+ *   (symbol), or act_vec [B,N,15].  obs = [p_vel] + landmark_rel + goal_b.color + other agent's c
+ *   (experiments/scenarios.py:23-42).  reward_i = -|p_other - p_goal_b(i)|^2.
+ * simple_speaker_listener: agent 0 speaks and never moves (dim_c = 3), agent 1 moves and is silent.  Actions:
+ *   act_idx [B,N] = (symbol of the speaker, movement of the listener), or act_vec [B,N,5] (the speaker's
+ *   Discrete(3) vector in the first three entries).  obs = [p_vel] + landmark_rel + (goal_b.color for the
+ *   speaker, zeros for the listener) (experiments/scenarios.py:45-64); reward of both = -|p_listener - p_goal|^2;
+ *   goal[.,1] is unused (0).
  * ------------------------------------------------------------------------------------------------ */
 static void SUFFIX(po_ref_observe_env)(const po_config *c, const REAL *pos, const REAL *vel, const REAL *lm,
                                        const REAL *comm, const int32_t *goal, REAL *obs)
 {
     const int N = c->num_agents, L = c->num_landmarks, D = po_obs_dim(c);
+    const int sl = c->scenario == PO_SIMPLE_SPEAKER_LISTENER, DC = po_dim_c(c);
     for (int i = 0; i < N; ++i) {
         REAL *o = obs + (size_t)i * D;
         int k = 0;
@@ -331,10 +338,14 @@ static void SUFFIX(po_ref_observe_env)(const po_config *c, const REAL *pos, cons
             o[k++] = lm[2 * l] - pos[2 * i];
             o[k++] = lm[2 * l + 1] - pos[2 * i + 1];
         }
+        if (sl) {
+            for (int q = 0; q < 3; ++q) o[k++] = i == 0 ? (REAL)PO_SL_COLOR[goal[0]][q] : (REAL)0;
+            continue;
+        }
         for (int q = 0; q < 3; ++q) o[k++] = (REAL)PO_LM_COLOR[goal[i]][q];
         for (int j = 0; j < N; ++j) {
             if (j == i) continue;
-            for (int q = 0; q < PO_DIM_C; ++q) o[k++] = comm[(size_t)j * PO_DIM_C + q];
+            for (int q = 0; q < DC; ++q) o[k++] = comm[(size_t)j * DC + q];
         }
     }
 }
@@ -343,13 +354,14 @@ static void SUFFIX(po_ref_reset_env)(const po_config *c, uint64_t env_id, uint32
                                      REAL *lm, REAL *comm, int32_t *goal)
 {
     const int N = c->num_agents, L = c->num_landmarks;
+    const int sl = c->scenario == PO_SIMPLE_SPEAKER_LISTENER, DC = po_dim_c(c);
     for (int i = 0; i < N; ++i) {
         float x, y;
         po_philox_xy(c->seed, env_id, episode, (uint32_t)i, -1.0f, 1.0f, &x, &y);
         pos[2 * i] = x; pos[2 * i + 1] = y;
         vel[2 * i] = 0; vel[2 * i + 1] = 0;
-        goal[i] = po_philox_goal(c->seed, env_id, episode, (uint32_t)i, L);
-        for (int q = 0; q < PO_DIM_C; ++q) comm[(size_t)i * PO_DIM_C + q] = 0;
+        goal[i] = (sl && i == 1) ? 0 : po_philox_goal(c->seed, env_id, episode, (uint32_t)i, L);
+        for (int q = 0; q < DC; ++q) comm[(size_t)i * DC + q] = 0;
     }
     for (int l = 0; l < L; ++l) {
         float x, y;
@@ -364,42 +376,50 @@ PO_EXPORT int SUFFIX(po_ref_step)(const po_config *c, int B, REAL *pos, REAL *ve
                                   REAL *rew, uint8_t *done, uint8_t *terminal)
 {
     const int N = c->num_agents, L = c->num_landmarks, D = po_obs_dim(c);
-    if (N != 2 || L < 1 || L > 3) return -1;
+    const int sl = c->scenario == PO_SIMPLE_SPEAKER_LISTENER, DC = po_dim_c(c);
+    if (N != 2 || L < 1 || L > 3 || DC == 0) return -1;
     const REAL damp = (REAL)1 - (REAL)c->damping, dt = (REAL)c->dt, mass = (REAL)c->mass;
     for (int e = 0; e < B; ++e) {
         REAL *p = pos + (size_t)e * N * 2, *v = vel + (size_t)e * N * 2, *l = lm + (size_t)e * L * 2;
-        REAL *cm = comm + (size_t)e * N * PO_DIM_C;
+        REAL *cm = comm + (size_t)e * N * DC;
         int32_t *g = goal + (size_t)e * N;
-        for (int i = 0; i < N; ++i) { /* _set_action (MultiDiscrete split) + World.step, no collisions */
+        for (int i = 0; i < N; ++i) { /* _set_action (per-agent action space) + World.step, no collisions */
             REAL a[5] = {0, 0, 0, 0, 0}, cv[PO_DIM_C];
+            const int moves = !(sl && i == 0), speaks = !(sl && i == 1);
+            for (int q = 0; q < DC; ++q) cv[q] = 0;
             if (act_idx) {
-                a[act_idx[(size_t)e * N + i]] = 1;
-                for (int q = 0; q < PO_DIM_C; ++q) cv[q] = 0;
-                cv[act_comm[(size_t)e * N + i]] = 1;
+                const int ai = act_idx[(size_t)e * N + i];
+                if (moves) a[ai] = 1;
+                if (speaks) cv[sl ? ai : act_comm[(size_t)e * N + i]] = 1;
             } else {
-                const REAL *av = act_vec + ((size_t)e * N + i) * (5 + PO_DIM_C);
-                for (int q = 0; q < 5; ++q) a[q] = av[q];
-                for (int q = 0; q < PO_DIM_C; ++q) cv[q] = av[5 + q];
-                if (c->force_discrete_action) {
-                    int d = 0;
-                    for (int q = 1; q < 5; ++q) if (a[q] > a[d]) d = q;
-                    for (int q = 0; q < 5; ++q) a[q] = 0;
-                    a[d] = 1;
+                const REAL *av = act_vec + ((size_t)e * N + i) * (sl ? 5 : 5 + PO_DIM_C);
+                if (moves) {
+                    for (int q = 0; q < 5; ++q) a[q] = av[q];
+                    if (c->force_discrete_action) {
+                        int d = 0;
+                        for (int q = 1; q < 5; ++q) if (a[q] > a[d]) d = q;
+                        for (int q = 0; q < 5; ++q) a[q] = 0;
+                        a[d] = 1;
+                    }
                 }
+                if (speaks) for (int q = 0; q < DC; ++q) cv[q] = av[(sl ? 0 : 5) + q];
             }
-            REAL ux = (REAL)0 + (a[1] - a[2]), uy = (REAL)0 + (a[3] - a[4]);
-            ux *= (REAL)c->default_sensitivity; uy *= (REAL)c->default_sensitivity;
-            const REAL fx = ux + (REAL)0, fy = uy + (REAL)0;
-            REAL vx = v[2 * i] * damp, vy = v[2 * i + 1] * damp;
-            vx = vx + (fx / mass) * dt;
-            vy = vy + (fy / mass) * dt;
-            v[2 * i] = vx; v[2 * i + 1] = vy;
-            p[2 * i] = p[2 * i] + vx * dt;
-            p[2 * i + 1] = p[2 * i + 1] + vy * dt;
-            for (int q = 0; q < PO_DIM_C; ++q) cm[(size_t)i * PO_DIM_C + q] = cv[q] + (REAL)0; /* update_agent_state */
+            if (moves) { /* apply_action_force + integrate_state skip entities that are not movable */
+                REAL ux = (REAL)0 + (a[1] - a[2]), uy = (REAL)0 + (a[3] - a[4]);
+                ux *= (REAL)c->default_sensitivity; uy *= (REAL)c->default_sensitivity;
+                const REAL fx = ux + (REAL)0, fy = uy + (REAL)0;
+                REAL vx = v[2 * i] * damp, vy = v[2 * i + 1] * damp;
+                vx = vx + (fx / mass) * dt;
+                vy = vy + (fy / mass) * dt;
+                v[2 * i] = vx; v[2 * i + 1] = vy;
+                p[2 * i] = p[2 * i] + vx * dt;
+                p[2 * i + 1] = p[2 * i + 1] + vy * dt;
+            }
+            /* update_agent_state: silent -> zeros, else action.c (+ 0 noise) */
+            for (int q = 0; q < DC; ++q) cm[(size_t)i * DC + q] = speaks ? cv[q] + (REAL)0 : (REAL)0;
         }
         for (int i = 0; i < N; ++i) {
-            const int o = 1 - i, gl = g[i];
+            const int o = sl ? 1 : 1 - i, gl = sl ? g[0] : g[i];
             const REAL dx = p[2 * o] - l[2 * gl], dy = p[2 * o + 1] - l[2 * gl + 1];
             if (rew) rew[(size_t)e * N + i] = -(dx * dx + dy * dy);
             if (done) done[(size_t)e * N + i] = 0;
@@ -427,7 +447,7 @@ PO_EXPORT int SUFFIX(po_ref_reset)(const po_config *c, int B, REAL *pos, REAL *v
     const int N = c->num_agents, L = c->num_landmarks, D = po_obs_dim(c);
     for (int e = 0; e < B; ++e) {
         REAL *p = pos + (size_t)e * N * 2, *v = vel + (size_t)e * N * 2, *l = lm + (size_t)e * L * 2;
-        REAL *cm = comm + (size_t)e * N * PO_DIM_C;
+        REAL *cm = comm + (size_t)e * N * po_dim_c(c);
         int32_t *g = goal + (size_t)e * N;
         ep_count[e] += 1;
         ep_step[e] = 0;
@@ -443,6 +463,6 @@ PO_EXPORT int SUFFIX(po_ref_observe)(const po_config *c, int B, const REAL *pos,
     const int N = c->num_agents, L = c->num_landmarks, D = po_obs_dim(c);
     for (int e = 0; e < B; ++e)
         SUFFIX(po_ref_observe_env)(c, pos + (size_t)e * N * 2, vel + (size_t)e * N * 2, lm + (size_t)e * L * 2,
-                                   comm + (size_t)e * N * PO_DIM_C, goal + (size_t)e * N, obs + (size_t)e * N * D);
+                                   comm + (size_t)e * N * po_dim_c(c), goal + (size_t)e * N, obs + (size_t)e * N * D);
     return 0;
 }
