@@ -14,7 +14,7 @@ from oracle import particle_oracle as po  # noqa: E402
 
 CASES = [('simple_spread', dict(), 12345678), ('simple_spread', dict(n=6), 12345679),
          ('simple_tag', dict(), 12345680), ('simple_tag', dict(num_good=2, num_adversaries=4), 12345681),
-         ('simple_reference', dict(), 12345682)]
+         ('simple_reference', dict(), 12345682), ('simple_speaker_listener', dict(), 12345683)]
 
 
 def trajectory(name, kw, seed, steps=30):
@@ -28,7 +28,11 @@ def trajectory(name, kw, seed, steps=30):
     for t in range(steps):
         idx = rng.randint(0, 5, env.n)
         cidx = rng.randint(0, 10, env.n)
-        acts = [np.concatenate([np.eye(5)[i], np.eye(10)[c]]) if multi else np.eye(5)[i] for i, c in zip(idx, cidx)]
+        if name == 'simple_speaker_listener':  # per-agent heads: Discrete(3) speaker, Discrete(5) listener
+            idx[0] %= 3
+            acts = [np.eye(sp.n)[i] for sp, i in zip(env.action_space, idx)]
+        else:
+            acts = [np.concatenate([np.eye(5)[i], np.eye(10)[c]]) if multi else np.eye(5)[i] for i, c in zip(idx, cidx)]
         o, r, d, _ = env.step(acts)
         out['actions'].append(np.stack([idx, cidx], -1))
         out['obs'].append(np.stack([np.pad(x, (0, 32 - len(x))) for x in o]))
