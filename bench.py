@@ -90,7 +90,9 @@ def c_oracle_rate(B, n_agents, steps=50):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=1000)
+    ap.add_argument('--steps', type=int, default=20000,
+                    help='timed batched env steps (40 launches of --chunk; ~20 ms, so that the closing barrier of an N-GPU run '
+                         'is a small part of the timed region)')
     ap.add_argument('--warmup', type=int, default=500)
     ap.add_argument('--envs', type=int, default=4096, help='B per GPU')
     ap.add_argument('--agents', type=int, default=6)
@@ -131,6 +133,9 @@ def main():
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
+        # RCCL's streams in their own (high-priority) hardware queue: the exchange then overlaps the next rollout
+        # launch instead of sitting in front of it in the main stream's queue (profiles/README.md, timeline)
+        os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     B, N, K, W, T = args.envs, args.agents, args.steps, args.warmup, max(1, args.chunk)
@@ -144,18 +149,24 @@ def main():
     def make_chunks(total):
         return [min(T, total - s) for s in range(0, total, T)]
 
+    RING = 4  # output buffers of 4 launches, reused round-robin (a launch's outputs are consumed -- here: sampled by
+    #           the exchange right after it -- long before 3 more launches have run)
+
     def alloc(total):
-        acts = torch.randint(0, 5, (total, B, N), generator=gen, device=dev, dtype=torch.int32)
-        outs = env.alloc_outputs(total, coll=False)
+        rows = min(total, RING * T)
+        acts = torch.randint(0, 5, (rows, B, N), generator=gen, device=dev, dtype=torch.int32)
+        outs = env.alloc_outputs(rows, coll=False)
         return acts, outs
 
     def plan(acts, outs, chunks):
-        """pw_step_io structs bound once per chunk (as a C host would); the timed loop only launches."""
-        plans, s = [], 0
-        for n in chunks:
-            view = {k: v[s:s + n] for k, v in outs.items()}
-            plans.append((env.plan_rollout(acts[s:s + n], view), view, acts[s:s + n]))
-            s += n
+        """pw_step_io structs bound once per ring slot (as a C host would); the timed loop only launches."""
+        plans, cache = [], {}
+        for i, n in enumerate(chunks):
+            s = (i % RING) * T
+            if (s, n) not in cache:
+                view = {k: v[s:s + n] for k, v in outs.items()}
+                cache[(s, n)] = (env.plan_rollout(acts[s:s + n], view), view, acts[s:s + n])
+            plans.append(cache[(s, n)])
         return plans
 
     exchange_state = {'error': None}
@@ -184,7 +195,8 @@ def main():
     if use_dist:
         from multiagent_rl_amd.dist import SampledTransitionGather
         # one exchange per update_rate (100) env-steps, the learner's cadence (rls/arglist.py:18)
-        shard = SampledTransitionGather(env, args.batch_size, rank, world, dev, every=max(1, args.exchange_steps // T))
+        shard = SampledTransitionGather(env, args.batch_size, rank, world, dev, every=max(1, args.exchange_steps // T),
+                                        side_stream=not os.environ.get('PW_BENCH_NO_SIDE_STREAM'))
 
     env.reset()
     if W > 0:
@@ -239,7 +251,7 @@ def main():
     except Exception:
         pass
 
-    finite = bool(torch.isfinite(outs['obs'][-1]).all().item()) and (K < 25 or bool(outs['terminal'][24].all().item()))
+    finite = bool(torch.isfinite(outs['obs']).all().item()) and (K < 25 or bool(outs['terminal'][24].all().item()))
     steps_per_launch_f = K / len(chunks)
 
     # Reported next to the headline ("report policy-in-the-loop separately"): the same env with the
