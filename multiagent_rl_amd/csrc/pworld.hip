@@ -468,7 +468,7 @@ int pw_create(const pw_config *cfg, pw_handle **out)
     }
     if (const char *e = std::getenv("PWORLD_EPW")) {  // experiments: fewer envs per wave (more, shorter waves)
         const int v = std::atoi(e);
-        if (v >= 1 && v <= kWave / kp.N) kp.epw = v;
+        if (v >= 1) kp.epw = v < kWave / kp.N ? v : kWave / kp.N;  // e.g. 64 = the dense packing of large batches
     }
     kp.max_episode_len = cfg->max_episode_len;
     kp.auto_reset = cfg->auto_reset;

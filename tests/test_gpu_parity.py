@@ -84,7 +84,7 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=['duo', 'stream', 'fast', 'generic'])
+@pytest.fixture(params=['duo', 'stream', 'fast', 'generic', 'duo-dense', 'stream-dense', 'fast-dense', 'generic-dense'])
 def kernel_path(request, monkeypatch):
     """Four kernels serve simple_spread with homogeneous agents; all must give the same bits.
     'duo'     pw_spread_duo_kernel    (default when all standard outputs are present, no coll output),
@@ -92,17 +92,24 @@ def kernel_path(request, monkeypatch):
     'fast'    pw_spread_fast_kernel   (PWORLD_NO_STREAM, or when coll is requested),
     'generic' pw_rollout_kernel       (PWORLD_FORCE_GENERIC, read by pw_create).
     simple_tag has three: pw_tag_duo_kernel ('duo'), pw_tag_stream_kernel ('stream') and the generic kernel
-    ('fast'/'generic')."""
+    ('fast'/'generic').
+    Small batches are spread over ~512 workgroups (few envs per wave); '-dense' forces the packing large batches
+    get (64 // N envs per wave, PWORLD_EPW) so that the multi-env-per-wave indexing is exercised at test sizes."""
+    param = request.param
+    monkeypatch.delenv('PWORLD_EPW', raising=False)
+    if param.endswith('-dense'):
+        monkeypatch.setenv('PWORLD_EPW', '64')
+        param = param[:-6]
     monkeypatch.delenv('PWORLD_FORCE_GENERIC', raising=False)
     monkeypatch.delenv('PWORLD_NO_STREAM', raising=False)
     monkeypatch.delenv('PWORLD_NO_DUO', raising=False)
-    if request.param == 'stream':
+    if param == 'stream':
         monkeypatch.setenv('PWORLD_NO_DUO', '1')
-    if request.param == 'generic':
+    if param == 'generic':
         monkeypatch.setenv('PWORLD_FORCE_GENERIC', '1')
-    elif request.param == 'fast':
+    elif param == 'fast':
         monkeypatch.setenv('PWORLD_NO_STREAM', '1')
-    return request.param
+    return param
 
 
 @pytest.mark.parametrize('case', CASES, ids=lambda c: '%s-N%d-L%s-B%d-%s' % (
