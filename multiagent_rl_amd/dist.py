@@ -37,6 +37,25 @@ def row_width(num_agents, obs_dim):
     return 2 * num_agents * obs_dim + num_agents + 2
 
 
+@torch.no_grad()
+def broadcast_actor(actor, src=0, group=None, fused=None):
+    """After the learner rank's ``optimize()``: ship the actor's parameters (~27 k floats, 108 KB) to every rollout
+    rank as ONE flat RCCL broadcast -- a per-tensor broadcast would be 13 latency-bound
+    collectives -- and, if given, refresh the ``FusedActor`` weight snapshot / MFMA fragments on this rank.
+    Returns the number of floats moved."""
+    tensors = [p.data for p in actor.parameters()] + [b.data for b in actor.buffers() if b.is_floating_point()]
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+    if fused is not None:
+        fused.refresh()
+    return off
+
+
 class SampledTransitionGather(object):
     """Call once per rollout chunk: ``gather(chunk_outputs, chunk_actions)``.
 

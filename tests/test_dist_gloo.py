@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from multiagent_rl_amd.dist import SampledTransitionGather, row_width, shard_env_ids
+from multiagent_rl_amd.dist import SampledTransitionGather, broadcast_actor, row_width, shard_env_ids
 
 B, N, D, T = 8, 3, 10, 5
 
@@ -65,6 +65,15 @@ def _worker(rank, world, port, q):
         gat(out, acts)
     gat.finish()
     dist.barrier()
+    # learner -> rollout ranks: the actor's parameters as one flat broadcast
+    from multiagent_rl_amd.policy import ActorNetwork
+    torch.manual_seed(100 + rank)                       # every rank starts from different weights
+    actor = ActorNetwork(D, 5)
+    n_moved = broadcast_actor(actor, src=0)
+    torch.manual_seed(100)
+    want = ActorNetwork(D, 5)
+    same = all(torch.equal(a, b) for a, b in zip(actor.state_dict().values(), want.state_dict().values()))
+    assert same and n_moved == sum(p.numel() for p in want.parameters())
     if rank == 0:
         q.put((gat.exchanges, gat.rows_ingested, [r.numpy() for r in gat.memory.rows]))
     else:
