@@ -100,3 +100,28 @@ def test_product_never_imports_the_oracle():
                 m = pat.search(open(os.path.join(d, f)).read())
                 assert m is None, '%s references the oracle (%r): the product must not depend on it' % (f, m.group(0))
     assert seen >= 8
+
+
+def test_header_is_plain_c_and_the_c_host_example_links(tmp_path):
+    """include/pworld.h must be consumable by a C compiler (it is the FFI surface), and examples/c_host.c -- a
+    caller with no Python and no PyTorch -- must compile warning-free as C11 and link against libpworld.so.
+    (Run on a GPU box: ./examples/c_host.bin > out.txt && python tools/check_c_host.py out.txt -- the checker
+    compares every printed value with the CPU oracle, bit for bit.)"""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which('gcc') is None or not os.path.isdir('/opt/rocm/include'):
+        pytest.skip('needs gcc and the ROCm headers')
+    from multiagent_rl_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH)
+    out = str(tmp_path / 'c_host')
+    cmd = ['gcc', '-std=c11', '-Wall', '-Wextra', '-Werror', '-D__HIP_PLATFORM_AMD__', '-I', os.path.join(root, 'include'),
+           '-I', '/opt/rocm/include', os.path.join(root, 'examples', 'c_host.c'), '-L', os.path.dirname(_lib.LIB_PATH),
+           '-lpworld', '-L', '/opt/rocm/lib', '-lamdhip64', '-o', out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    hdr = str(tmp_path / 'only_header.c')
+    open(hdr, 'w').write('#include "pworld.h"\n#include "pworld_math.h"\nint main(void) { return pw_exp(0.0f) == 1.0f ? 0 : 1; }\n')
+    r = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic', '-I', os.path.join(root, 'include'),
+                        '-c', hdr, '-o', str(tmp_path / 'h.o')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
