@@ -263,14 +263,17 @@ int pw_bilstm_forward(const float *G, const float *w_hh_fw, const float *w_hh_bw
 int pw_actor_head(const float *H, const float *w2, const float *b2, int64_t rows, uint64_t seed, uint64_t step,
                   const int64_t *step_dev /* device, or NULL */, float *logits, int32_t *act, void *stream);
 
-/* The whole actor in ONE launch: X [B,N,in_dim] observations -> act [B,N] (Gumbel-argmax index), and/or
- * logits [B,N,5], H [B,N,64] (each optional, NULL to skip).  Same arithmetic and the same Philox keying as
+/* The whole actor in ONE launch: X [B,N,in_dim] observations -> act (Gumbel-argmax index per head), and/or
+ * logits, H [B,N,64] (each optional, NULL to skip).  One head: w2 [n_out0,64], b2 [n_out0], n_out1 = 0,
+ * logits [B,N,n_out0], act [B,N].  Two heads (MultiDiscrete actors, main.py:52-54: dense2_1 / dense2_2): w2 / b2 =
+ * the two layers concatenated, logits [B,N,n_out0+n_out1] in that order (run.py:39-41), act [B,N,2].
+ * n_out0 + n_out1 <= 16.  With n_out0 = 5, n_out1 = 0: same arithmetic and the same Philox keying as
  * pw_actor_front + pw_bilstm_forward + pw_actor_head chained (identical results); G and H stay in LDS.
  * frag = pw_actor_front_pack's image; N <= 96. */
 int pw_actor_fused(const float *X, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
-                   const float *w_hh_bw, const float *w2, const float *b2, int64_t B, int32_t N, int32_t in_dim,
-                   int32_t relu_out, uint64_t seed, uint64_t step, const int64_t *step_dev /* device, or NULL */,
-                   float *H, float *logits, int32_t *act, void *stream);
+                   const float *w_hh_bw, const float *w2, const float *b2, int32_t n_out0, int32_t n_out1, int64_t B,
+                   int32_t N, int32_t in_dim, int32_t relu_out, uint64_t seed, uint64_t step,
+                   const int64_t *step_dev /* device, or NULL */, float *H, float *logits, int32_t *act, void *stream);
 
 /* Test hook: y[i] = f(x[i]) with the DEVICE implementation of one math primitive, so its bits can be compared
  * with a CPU implementation of pworld_math.h.  fn: 0 the kernels' fast correctly-rounded sqrt, 1 their

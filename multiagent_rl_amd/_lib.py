@@ -87,8 +87,8 @@ SIGNATURES = {
     'pw_actor_front_pack_floats': (C.c_size_t, [C.c_int32]),
     'pw_actor_front_pack': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'pw_actor_front': (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
-    'pw_actor_fused': (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64]
-                       + [C.c_void_p] * 5),
+    'pw_actor_fused': (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                                    C.c_uint64, C.c_uint64] + [C.c_void_p] * 5),
     'pw_bilstm_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p]),
     'pw_actor_head': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p,

@@ -340,7 +340,8 @@ __global__ void __launch_bounds__(256) pw_actor_head_kernel(const float *__restr
 //     LSTM    lane = (sequence, hidden unit): 8 waves x 2 sequences, the unit's 128 W_hh weights in VGPRs,
 //             N recurrence steps of 64 packed FMAs; relu(h) -> LDS tile Hs [R][64] (row stride 68)
 //   head      thread = (row, logit): 64 FMAs, Gumbel noise from Philox4x32-10 keyed (seed; step, row) exactly
-//             as pw_actor_head_kernel; argmax per row.
+//             as pw_actor_head_kernel; argmax per row and head (one head of <= 16 logits, or the two heads of a
+//             MultiDiscrete actor, main.py:52-54: act [rows, 2]).
 // Same arithmetic, in the same order, as pw_actor_front_kernel + pw_bilstm_kernel + pw_actor_head_kernel
 // (the tests demand identical bits); what is removed is the HBM round trip of G (1 KB per row, twice), of H,
 // and two launches.  LDS: 6-16 KB stage-1 fragments + 32 + 16 + 48.4 (Gs) + 25.5 (Hs) + 7 KB small = <= 145 KB.
@@ -348,6 +349,7 @@ __global__ void __launch_bounds__(256) pw_actor_head_kernel(const float *__restr
 struct ActorFusedArgs {
     const float *X, *frag, *b1, *bih, *whh_f, *whh_r, *w2, *b2;
     int B, N, D, E, relu_out;
+    int n_out0, n_out1;  // logits of head 0 / head 1 (0 = single head); n_out0 + n_out1 <= 16
     uint64_t seed, step;
     const int64_t *step_dev;
     float *H, *logits;
@@ -367,10 +369,10 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
     float *s_hid = s_g + kFusedRows * kGs;                             // [96][68]
     float *s_b1 = s_hid + kFusedRows * kHs;                            // [64]
     float *s_bih = s_b1 + 64;                                          // [256]
-    float *s_w2 = s_bih + 256;                                         // [5][64]
-    float *s_b2 = s_w2 + 320;                                          // [8]
-    float *s_hx = s_b2 + 8;                                            // [16 sequences][32]
-    float *s_lg = s_hx + 512;                                          // [96 * 5] perturbed logits
+    float *s_w2 = s_bih + 256;                                         // [16][64] (n_out0 + n_out1 rows used)
+    float *s_b2 = s_w2 + 1024;                                         // [16]
+    float *s_hx = s_b2 + 16;                                           // [16 sequences][32]
+    float *s_lg = s_hx + 512;                                          // [96 * 16] perturbed logits
 
     PW_STAMP_DECL;
     PW_STAMP_START;
@@ -414,8 +416,9 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
         for (int f = tid; f < (2 * S1 * 64) / 4; f += 512) reinterpret_cast<float4 *>(f_w1)[f] = src[f];
         if (tid < 64) s_b1[tid] = A.b1[tid];
         if (tid < 256) s_bih[tid] = A.bih[tid];
-        if (tid < 320) s_w2[tid] = A.w2[tid];
-        if (tid < 5) s_b2[tid] = A.b2[tid];
+        const int OUTc = A.n_out0 + A.n_out1;
+        for (int f = tid; f < OUTc * 64; f += 512) s_w2[f] = A.w2[f];
+        if (tid < OUTc) s_b2[tid] = A.b2[tid];
         fill_dir(0);
     }
     __syncthreads();
@@ -504,8 +507,11 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
         for (int idx = tid; idx < rows_here * 64; idx += 512)
             A.H[(size_t)row_base * 64 + idx] = s_hid[(idx >> 6) * kHs + (idx & 63)];
     }
-    if (tid < rows_here * 5) {
-        const int r = tid / 5, o = tid - r * 5;
+    // thread = (row, logit); the heads' logits are concatenated ([n_out0 | n_out1], run.py:39-41 order)
+    const int OUT = A.n_out0 + A.n_out1, nheads = A.n_out1 > 0 ? 2 : 1;
+    const uint64_t step = (A.act && A.step_dev) ? (uint64_t)*A.step_dev : A.step;
+    for (int idx = tid; idx < rows_here * OUT; idx += 512) {
+        const int r = idx / OUT, o = idx - r * OUT;
         float acc = s_b2[o];
         const float4 *hv = reinterpret_cast<const float4 *>(s_hid + r * kHs), *wv = reinterpret_cast<const float4 *>(s_w2 + o * 64);
 #pragma unroll
@@ -517,28 +523,31 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
             acc = __builtin_fmaf(wq.w, hq.w, acc);
         }
         const long grow = row_base + r;
-        if (A.logits) A.logits[(size_t)grow * 5 + o] = acc;
+        if (A.logits) A.logits[(size_t)grow * OUT + o] = acc;
         if (A.act) {
-            const uint64_t step = A.step_dev ? (uint64_t)*A.step_dev : A.step;
+            // uniform o of a row = word (o & 3) of Philox block (o >> 2); the block index sits in the two top bits
+            // of counter word 1 (block 1 = 0x80000000, as pw_actor_head_kernel's second call)
+            const uint32_t blk = (uint32_t)o >> 2, tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
             uint32_t u[4];
-            pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | (o == 4 ? 0x80000000u : 0u), (uint32_t)step,
-                             (uint32_t)(step >> 32), (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
-            const uint32_t uw = o == 4 ? u[0] : (o == 0 ? u[0] : o == 1 ? u[1] : o == 2 ? u[2] : u[3]);
+            pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | tag, (uint32_t)step, (uint32_t)(step >> 32),
+                             (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
+            const int w = o & 3;
+            const uint32_t uw = w == 0 ? u[0] : w == 1 ? u[1] : w == 2 ? u[2] : u[3];
             const float uo = ((float)(uw >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
-            s_lg[tid] = acc - __logf(-__logf(uo));
+            s_lg[idx] = acc - __logf(-__logf(uo));
         }
     }
     if (A.act) {
         __syncthreads();
-        if (tid < rows_here) {
+        for (int idx = tid; idx < rows_here * nheads; idx += 512) {
+            const int r = idx / nheads, hd = idx - r * nheads;
+            const int lo = hd ? A.n_out0 : 0, cnt = hd ? A.n_out1 : A.n_out0;
+            const float *v = s_lg + r * OUT + lo;
             int best = 0;
-            float bv = 0.0f;
-#pragma unroll
-            for (int o = 0; o < 5; ++o) {
-                const float v = s_lg[tid * 5 + o];
-                if (o == 0 || v > bv) { bv = v; best = o; }
-            }
-            A.act[row_base + tid] = best;
+            float bv = v[0];
+            for (int o = 1; o < cnt; ++o)
+                if (v[o] > bv) { bv = v[o]; best = o; }
+            A.act[(row_base + r) * nheads + hd] = best;
         }
     }
     PW_STAMP(7);

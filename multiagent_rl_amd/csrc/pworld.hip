@@ -784,10 +784,11 @@ int pw_actor_head(const float *H, const float *w2, const float *b2, int64_t rows
 }
 
 int pw_actor_fused(const float *X, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
-                   const float *w_hh_bw, const float *w2, const float *b2, int64_t B, int32_t N, int32_t in_dim,
-                   int32_t relu_out, uint64_t seed, uint64_t step, const int64_t *step_dev, float *H, float *logits,
-                   int32_t *act, void *stream)
+                   const float *w_hh_bw, const float *w2, const float *b2, int32_t n_out0, int32_t n_out1, int64_t B,
+                   int32_t N, int32_t in_dim, int32_t relu_out, uint64_t seed, uint64_t step, const int64_t *step_dev,
+                   float *H, float *logits, int32_t *act, void *stream)
 {
+    if (n_out0 < 1 || n_out1 < 0 || n_out0 + n_out1 > 16) return fail(PW_EINVAL, "head sizes: n_out0 >= 1, n_out0 + n_out1 <= 16");
     if (!X || !frag || !b1 || !b_ih || !w_hh_fw || !w_hh_bw || !w2 || !b2 || (!H && !logits && !act))
         return fail(PW_EINVAL, "null argument");
     if (B < 1 || N < 1 || N > 96 || B > (int64_t)0x7fffffff) return fail(PW_EINVAL, "N must be in [1, 96]");
@@ -796,12 +797,12 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
         return fail(PW_EINVAL, "frag and w_hh must be 16-byte aligned");
     ActorFusedArgs a;
     a.X = X; a.frag = frag; a.b1 = b1; a.bih = b_ih; a.whh_f = w_hh_fw; a.whh_r = w_hh_bw; a.w2 = w2; a.b2 = b2;
-    a.B = (int)B; a.N = N; a.D = in_dim; a.relu_out = relu_out;
+    a.B = (int)B; a.N = N; a.D = in_dim; a.relu_out = relu_out; a.n_out0 = n_out0; a.n_out1 = n_out1;
     a.E = 96 / N < 16 ? 96 / N : 16;
     a.seed = seed; a.step = step; a.step_dev = step_dev; a.H = H; a.logits = logits; a.act = act;
     const int S1C = (in_dim + 7) / 8, S1 = 4 * S1C;
     const size_t shm = (size_t)(4 * 2 * 4 * 64 + 4 * 8 * 32) * sizeof(float4) +
-                       (size_t)(2 * S1 * 64 + kFusedRows * kGs + kFusedRows * kHs + 64 + 256 + 320 + 8 + 512 + 512) * sizeof(float);
+                       (size_t)(2 * S1 * 64 + kFusedRows * kGs + kFusedRows * kHs + 64 + 256 + 1024 + 16 + 512 + kFusedRows * 16) * sizeof(float);
     const unsigned grid = (unsigned)((B + a.E - 1) / a.E);
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool attr_set[9] = {};

@@ -108,8 +108,11 @@ class FusedActor(object):
     @torch.no_grad()
     def refresh(self):
         a = self.actor
-        lin1, lstm, lin2 = a.dense1.module, a.bilstm, a.dense2.module
-        assert lstm.hidden_size == 32 and lstm.bidirectional and lstm.num_layers == 1 and lin2.out_features == 5
+        lin1, lstm = a.dense1.module, a.bilstm
+        two = type(a.out_dim) is list  # MultiDiscrete actor: two heads on the same BiLSTM output
+        heads = [a.dense2_1.module, a.dense2_2.module] if two else [a.dense2.module]
+        self.heads = tuple(int(h.out_features) for h in heads)
+        assert lstm.hidden_size == 32 and lstm.bidirectional and lstm.num_layers == 1 and sum(self.heads) <= 16
         dev = lin1.weight.device
         assert dev.type == 'cuda', 'FusedActor needs the actor on the GPU (no CPU fallback)'
         f = lambda t: t.detach().to(torch.float32).contiguous()  # noqa: E731
@@ -119,7 +122,8 @@ class FusedActor(object):
         self.bih = f(torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0,
                                 lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse], 0))         # [256]
         self.whh_f, self.whh_r = f(lstm.weight_hh_l0), f(lstm.weight_hh_l0_reverse)             # [128, 32]
-        self.w2, self.b2 = f(lin2.weight), f(lin2.bias)                                         # [5, 64]
+        self.w2 = f(torch.cat([h.weight for h in heads], 0))                                    # [sum(heads), 64]
+        self.b2 = f(torch.cat([h.bias for h in heads], 0))
         self.device = dev
         D = self.w1.shape[1]
         self.frag = torch.empty(self.lib.pw_actor_front_pack_floats(D), dtype=torch.float32, device=dev)
@@ -136,13 +140,15 @@ class FusedActor(object):
         B, N, D = obs.shape
         x = obs.reshape(B * N, D).to(torch.float32).contiguous()
         h = torch.empty(B, N, 64, dtype=torch.float32, device=self.device) if want_h else None
-        logits = torch.empty(B, N, 5, dtype=torch.float32, device=self.device) if want_logits else None
-        act = torch.empty(B, N, dtype=torch.int32, device=self.device) if want_act else None
+        n0, n1 = self.heads[0], (self.heads[1] if len(self.heads) > 1 else 0)
+        logits = torch.empty(B, N, n0 + n1, dtype=torch.float32, device=self.device) if want_logits else None
+        act = torch.empty((B, N, 2) if n1 else (B, N), dtype=torch.int32, device=self.device) if want_act else None
         p = lambda t: None if t is None else self._C.c_void_p(t.data_ptr())  # noqa: E731
         step_dev = p(self._step_dev) if (self.graph_mode and want_act) else None
         self._lib_mod.check(self.lib.pw_actor_fused(p(x), p(self.frag), p(self.b1), p(self.bih), p(self.whh_f),
-                                                    p(self.whh_r), p(self.w2), p(self.b2), B, N, D, 1, self.seed,
-                                                    self.calls, step_dev, p(h), p(logits), p(act), self._stream()))
+                                                    p(self.whh_r), p(self.w2), p(self.b2), n0, n1, B, N, D, 1,
+                                                    self.seed, self.calls, step_dev, p(h), p(logits), p(act),
+                                                    self._stream()))
         if step_dev is not None and not self.defer_step_advance:  # captured: the counter advances on the device
             self._lib_mod.check(self.lib.pw_counter_add(p(self._step_dev), 1, 0, self._stream()))
         return h, logits, act
@@ -184,14 +190,24 @@ class FusedActor(object):
             self._lib_mod.check(self.lib.pw_counter_add(p(self._step_dev), 1, 0, self._stream()))
         return logits, act
 
-    def logits(self, obs):
+    def _one_launch(self, obs):
         if self.use_fused and obs.shape[1] <= 96:
-            return self._fused(obs, want_logits=True)[1]
+            return True
+        if self.heads != (5,):
+            raise NotImplementedError('the three-launch chain serves the single 5-logit head only; two-head '
+                                      '(MultiDiscrete) actors need the one-launch kernel (N <= 96)')
+        return False
+
+    def logits(self, obs):
+        """[B,N,5]; two-head actors: the list [logits_move [B,N,n0], logits_comm [B,N,n1]] like ActorNetwork."""
+        if self._one_launch(obs):
+            lg = self._fused(obs, want_logits=True)[1]
+            return lg if len(self.heads) == 1 else [lg[..., :self.heads[0]], lg[..., self.heads[0]:]]
         return self._head(self.hidden(obs), True, False)[0]
 
     def __call__(self, obs):
         """-> Gumbel-sampled action index [B,N] int32 (one fresh Philox stream per call)."""
-        if self.use_fused and obs.shape[1] <= 96:
+        if self._one_launch(obs):
             act = self._fused(obs, want_act=True)[2]
         else:
             act = self._head(self.hidden(obs), False, True)[1]

@@ -224,3 +224,50 @@ def test_batched_two_head_policy_rollout():
     obs, _, _, _ = env.step(a)
     heard = obs[:, 0, 11:].argmax(-1).cpu()
     assert torch.equal(heard, a[:, 1, 1].long().cpu()) and (obs[:, 0, 11:].sum(-1) == 1).all()
+
+
+@gpu
+def test_one_launch_two_head_actor_matches_pytorch_and_drives_the_rollout():
+    """FusedActor on a MultiDiscrete actor ([5, 10] heads, main.py:52-54): logits of both heads within 2e-5 of plain
+    PyTorch fp32, sampled (movement, symbol) pairs follow softmax of each head, and the batched simple_reference
+    rollout runs with it (3 launches per step, no MIOpen RNN path)."""
+    import torch
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    from multiagent_rl_amd.rollout import BatchedRollout
+    torch.manual_seed(2)
+    ref = ActorNetwork(21, [5, 10])
+    actor = ActorNetwork(21, [5, 10]).cuda().eval()
+    actor.load_state_dict(ref.state_dict())
+    fused = FusedActor(actor, seed=11)
+    assert fused.heads == (5, 10) and fused.use_fused
+    for B, N in [(1, 2), (257, 2), (33, 5)]:
+        obs = torch.randn(B, N, 21) * 2
+        with torch.no_grad():
+            want = ref(obs)
+        got = fused.logits(obs.cuda())
+        for g, w in zip(got, want):
+            np.testing.assert_allclose(g.cpu().numpy(), w.numpy(), rtol=0, atol=2e-5)
+    # sampling: same two rows, 20000 independent draws per head
+    obs = torch.randn(1, 2, 21).cuda().repeat(20000, 1, 1)
+    p = [torch.softmax(x, -1)[0].cpu().numpy() for x in fused.logits(obs[:1])]
+    a = fused(obs)
+    assert tuple(a.shape) == (20000, 2, 2) and a.dtype == torch.int32
+    a = a.cpu().numpy()
+    for ag in range(2):
+        for hd, n in ((0, 5), (1, 10)):
+            freq = np.bincount(a[:, ag, hd], minlength=n) / 20000.0
+            assert np.abs(freq - p[hd][ag]).max() < 0.015, (ag, hd, freq, p[hd][ag])
+    # the two heads draw independent noise: the joint frequency factorises
+    joint = np.zeros((5, 10))
+    np.add.at(joint, (a[:, 0, 0], a[:, 0, 1]), 1.0 / 20000)
+    assert np.abs(joint - np.outer(p[0][0], p[1][0])).max() < 0.01
+    assert np.array_equal(FusedActor(actor, seed=11)(obs).cpu().numpy(), a)      # same seed + call index => same actions
+    # in the loop
+    env = make_batched_env('simple_reference', 512, auto_reset=True, max_episode_len=25)
+    ro = BatchedRollout(env, FusedActor(actor, seed=3), memory=None)
+    ro.collect(26)
+    st = ro.stats()
+    assert st['episodes'] == 512 and st['mean_episode_reward'] < 0
+    obs, _, _, _ = env.step(ro.policy(ro.obs))
+    assert (obs[:, 0, 11:].sum(-1) == 1).all()        # agent 0 hears exactly one symbol from agent 1

@@ -19,9 +19,9 @@ int main(int argc, char **argv)
     fill(w1, 64 * D); fill(wih, 256 * 64); fill(b1, 64); fill(bih, 256); fill(whf, 4096); fill(whr, 4096); fill(w2, 320); fill(b2, 5);
     pw_actor_front_pack(w1, wih, D, frag, nullptr);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 10; ++i) pw_actor_fused(X, frag, b1, bih, whf, whr, w2, b2, B, N, D, 1, 1, i, nullptr, nullptr, nullptr, act, nullptr);
+    for (int i = 0; i < 10; ++i) pw_actor_fused(X, frag, b1, bih, whf, whr, w2, b2, 5, 0, B, N, D, 1, 1, i, nullptr, nullptr, nullptr, act, nullptr);
     hipEventRecord(e0, 0);
-    for (int i = 0; i < 100; ++i) pw_actor_fused(X, frag, b1, bih, whf, whr, w2, b2, B, N, D, 1, 1, i, nullptr, nullptr, nullptr, act, nullptr);
+    for (int i = 0; i < 100; ++i) pw_actor_fused(X, frag, b1, bih, whf, whr, w2, b2, 5, 0, B, N, D, 1, 1, i, nullptr, nullptr, nullptr, act, nullptr);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("B=%d: %.2f us per launch (%s)\n", B, ms * 10.f, pw_last_error());

@@ -20,13 +20,16 @@ ap.add_argument('--steps', type=int, default=300)
 ap.add_argument('--policy', default='actor', choices=['actor', 'fused', 'uniform'])
 ap.add_argument('--no-replay', action='store_true')
 ap.add_argument('--graph', action='store_true')
+ap.add_argument('--scenario', default='simple_spread', choices=['simple_spread', 'simple_reference'])
 a = ap.parse_args()
 torch.manual_seed(0)
-env = make_batched_env('simple_spread', a.envs, n=a.agents, auto_reset=True)
-pol = {'actor': lambda: GumbelPolicy(ActorNetwork(env.obs_dim, 5).cuda()),
-       'fused': lambda: FusedActor(ActorNetwork(env.obs_dim, 5).cuda()),
+ref = a.scenario == 'simple_reference'
+env = make_batched_env(a.scenario, a.envs, n=None if ref else a.agents, auto_reset=True)
+out_dim = [5, 10] if ref else 5          # main.py:52-54: MultiDiscrete -> two heads
+pol = {'actor': lambda: GumbelPolicy(ActorNetwork(env.obs_dim, out_dim).cuda()),
+       'fused': lambda: FusedActor(ActorNetwork(env.obs_dim, out_dim).cuda()),
        'uniform': UniformRandomPolicy}[a.policy]()
-mem = None if a.no_replay else ReplayBuffer(1e6, a.agents, env.obs_dim)
+mem = None if (a.no_replay or ref) else ReplayBuffer(1e6, a.agents, env.obs_dim)  # the ring stores single-head actions
 ro = BatchedRollout(env, pol, mem)
 if a.graph:
     ro.capture()
@@ -36,5 +39,5 @@ t0 = time.perf_counter()
 ro.collect(a.steps)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print('B=%d N=%d policy=%s replay=%s graph=%s: %.1f us/step  %.3e env-steps/s  %s' % (
-    a.envs, a.agents, a.policy, mem is not None, a.graph, dt / a.steps * 1e6, a.envs * a.steps / dt, ro.stats()))
+print('%s B=%d N=%d policy=%s replay=%s graph=%s: %.1f us/step  %.3e env-steps/s  %s' % (
+    a.scenario, a.envs, env.n, a.policy, mem is not None, a.graph, dt / a.steps * 1e6, a.envs * a.steps / dt, ro.stats()))
