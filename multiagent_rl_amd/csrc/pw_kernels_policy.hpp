@@ -357,41 +357,69 @@ struct ActorFusedArgs {
 };
 constexpr int kFusedRows = 96, kGs = 129, kHs = 68;  // kHs: 16-byte aligned rows for the head's float4 reads
 
-template <int S1C>
-__global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArgs A)
+// LDS of one actor workgroup (carved from dynamic shared memory; kActorLdsFloats(S1) floats in total)
+struct ActorLds {
+    float4 *f_wih;  // [4 n][2 m][4 rq][64 lane] float4, one direction
+    float4 *s_whh;  // [4 gate][8 q][32 unit] float4, one direction
+    float *f_w1;    // [2 m][S1][64 lane]
+    float *s_g;     // [96][129]
+    float *s_hid;   // [96][68]
+    float *s_b1, *s_bih;  // [64], [256]
+    float *s_w2, *s_b2;   // [16][64] (n_out0 + n_out1 rows used), [16]
+    float *s_hx;    // [16 sequences][32]
+    float *s_lg;    // [96 * 16] perturbed logits
+    unsigned char *end;
+};
+__host__ __device__ constexpr size_t actor_lds_bytes(int S1)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int S1 = 4 * S1C;
-    float4 *f_wih = reinterpret_cast<float4 *>(smem_raw);              // [4 n][2 m][4 rq][64 lane] float4, one direction
-    float4 *s_whh = f_wih + 4 * 2 * 4 * 64;                            // [4 gate][8 q][32 unit] float4, one direction
-    float *f_w1 = reinterpret_cast<float *>(s_whh + 4 * 8 * 32);       // [2 m][S1][64 lane]
-    float *s_g = f_w1 + 2 * S1 * 64;                                   // [96][129]
-    float *s_hid = s_g + kFusedRows * kGs;                             // [96][68]
-    float *s_b1 = s_hid + kFusedRows * kHs;                            // [64]
-    float *s_bih = s_b1 + 64;                                          // [256]
-    float *s_w2 = s_bih + 256;                                         // [16][64] (n_out0 + n_out1 rows used)
-    float *s_b2 = s_w2 + 1024;                                         // [16]
-    float *s_hx = s_b2 + 16;                                           // [16 sequences][32]
-    float *s_lg = s_hx + 512;                                          // [96 * 16] perturbed logits
+    return (size_t)(4 * 2 * 4 * 64 + 4 * 8 * 32) * 16 +
+           (size_t)(2 * S1 * 64 + kFusedRows * kGs + kFusedRows * kHs + 64 + 256 + 1024 + 16 + 512 + kFusedRows * 16) * 4;
+}
+__device__ __forceinline__ ActorLds actor_carve(unsigned char *raw, const int S1)
+{
+    ActorLds S;
+    S.f_wih = reinterpret_cast<float4 *>(raw);
+    S.s_whh = S.f_wih + 4 * 2 * 4 * 64;
+    S.f_w1 = reinterpret_cast<float *>(S.s_whh + 4 * 8 * 32);
+    S.s_g = S.f_w1 + 2 * S1 * 64;
+    S.s_hid = S.s_g + kFusedRows * kGs;
+    S.s_b1 = S.s_hid + kFusedRows * kHs;
+    S.s_bih = S.s_b1 + 64;
+    S.s_w2 = S.s_bih + 256;
+    S.s_b2 = S.s_w2 + 1024;
+    S.s_hx = S.s_b2 + 16;
+    S.s_lg = S.s_hx + 512;
+    S.end = reinterpret_cast<unsigned char *>(S.s_lg + kFusedRows * 16);
+    return S;
+}
 
-    PW_STAMP_DECL;
-    PW_STAMP_START;
+// One forward pass of the actor for the rows of this workgroup (all 512 threads call it).
+//   xrows      observation rows of this workgroup, row-major [rows_here][A.D] -- global memory or LDS
+//   load_const stage-1 fragments, biases and head weights -> LDS (needed once per kernel)
+//   step       Philox step of the Gumbel noise
+//   act_g      global sink of the sampled indices [rows_here * nheads] (or NULL), act_l the same in LDS (or NULL)
+// On return every thread has passed a barrier after the last LDS write of the pass.
+template <int S1C>
+__device__ __forceinline__ void actor_forward_wg(const ActorFusedArgs &A, const ActorLds &S, const float *xrows,
+                                                 const int rows_here, const int envs_here, const long row_base,
+                                                 const bool load_const, const uint64_t step, int32_t *act_g,
+                                                 int32_t *act_l)
+{
+    constexpr int S1 = 4 * S1C;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = A.N, E = A.E;
-    const long env0 = (long)blockIdx.x * E;
-    const int envs_here = (int)((long)A.B - env0 < (long)E ? (long)A.B - env0 : (long)E);
-    const int rows_here = envs_here * N;
-    const long row_base = env0 * N;
+    const int N = A.N;
+    PW_STAMP_DECL;
+    PW_STAMP_START;
 
     // one direction's weights -> LDS: W_ih fragments (32 KB) + W_hh (16 KB, re-laid as [gate][k/4][unit])
     auto fill_dir = [&](const int dir) {
         const float4 *src = reinterpret_cast<const float4 *>(A.frag) + dir * 2048;
-        for (int f = tid; f < 2048; f += 512) f_wih[f] = src[f];
+        for (int f = tid; f < 2048; f += 512) S.f_wih[f] = src[f];
         const float4 *wh = reinterpret_cast<const float4 *>(dir ? A.whh_r : A.whh_f);
         for (int f = tid; f < 1024; f += 512) {
             const int row = f >> 3, q = f & 7, gate = row >> 5, unit = row & 31;
-            s_whh[(gate * 8 + q) * 32 + unit] = wh[f];
+            S.s_whh[(gate * 8 + q) * 32 + unit] = wh[f];
         }
     };
     // Matrix-core job map: 3 row tiles x 4 unit tiles per direction = 12 jobs over 4 SIMDs (waves w and w + 4
@@ -404,23 +432,23 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
     {
         int lr = rt * 32 + col;
         if (lr >= rows_here) lr = rows_here - 1;
-        const float *xr = A.X + (size_t)(row_base + lr) * A.D;
+        const float *xr = xrows + (size_t)lr * A.D;
 #pragma unroll
         for (int sidx = 0; sidx < S1; ++sidx) {
             const int k = 2 * sidx + half;
             xb[sidx] = k < A.D ? xr[k] : 0.0f;
         }
     }
-    {   // stage-1 fragments, the small vectors and the forward direction's weights
+    if (load_const) {  // stage-1 fragments, the small vectors
         const float4 *src = reinterpret_cast<const float4 *>(A.frag + 8 * 2 * 4 * 64 * 4);
-        for (int f = tid; f < (2 * S1 * 64) / 4; f += 512) reinterpret_cast<float4 *>(f_w1)[f] = src[f];
-        if (tid < 64) s_b1[tid] = A.b1[tid];
-        if (tid < 256) s_bih[tid] = A.bih[tid];
+        for (int f = tid; f < (2 * S1 * 64) / 4; f += 512) reinterpret_cast<float4 *>(S.f_w1)[f] = src[f];
+        if (tid < 64) S.s_b1[tid] = A.b1[tid];
+        if (tid < 256) S.s_bih[tid] = A.bih[tid];
         const int OUTc = A.n_out0 + A.n_out1;
-        for (int f = tid; f < OUTc * 64; f += 512) s_w2[f] = A.w2[f];
-        if (tid < OUTc) s_b2[tid] = A.b2[tid];
-        fill_dir(0);
+        for (int f = tid; f < OUTc * 64; f += 512) S.s_w2[f] = A.w2[f];
+        if (tid < OUTc) S.s_b2[tid] = A.b2[tid];
     }
+    fill_dir(0);
     __syncthreads();
     PW_STAMP(0);
 
@@ -435,19 +463,19 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
         for (int sidx = 0; sidx < S1; ++sidx) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
-                acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f_w1[(m * S1 + sidx) * 64 + lane], xb[sidx], acc1[m], 0, 0, 0);
+                acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(S.f_w1[(m * S1 + sidx) * 64 + lane], xb[sidx], acc1[m], 0, 0, 0);
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[m][r] = fmaxf(acc1[m][r] + s_b1[m * 32 + mfma_row(r, half)], 0.0f);
+            for (int r = 0; r < 16; ++r) acc1[m][r] = fmaxf(acc1[m][r] + S.s_b1[m * 32 + mfma_row(r, half)], 0.0f);
     }
     PW_STAMP(1);
     // ---- LSTM lane identity: 2 sequences per wave, sequence slot = local environment
     const int j = lane & 31, sl = wave * 2 + (lane >> 5);
     const bool seq_ok = sl < envs_here;
     const int se = seq_ok ? sl : 0;  // idle half-waves shadow environment 0 (they write nothing)
-    float *hs = s_hx + sl * 32;
+    float *hs = S.s_hx + sl * 32;
 
 #pragma unroll 1
     for (int dir = 0; dir < 2; ++dir) {
@@ -467,15 +495,15 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
                 for (int m = 0; m < 2; ++m) {
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
-                        const float4 a = f_wih[((n * 2 + m) * 4 + rq) * 64 + lane];
+                        const float4 a = S.f_wih[((n * 2 + m) * 4 + rq) * 64 + lane];
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc1[m][4 * rq + 0], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc1[m][4 * rq + 1], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, acc1[m][4 * rq + 2], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, acc1[m][4 * rq + 3], acc, 0, 0, 0);
                     }
                 }
-                float *dst = s_g + (rt * 32 + col) * kGs + n * 32;
-                const float *bb = s_bih + dir * 128 + n * 32;
+                float *dst = S.s_g + (rt * 32 + col) * kGs + n * 32;
+                const float *bb = S.s_bih + dir * 128 + n * 32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dst[mfma_row(r, half)] = acc[r] + bb[mfma_row(r, half)];
             }
@@ -485,16 +513,16 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
         PW_STAMP(4);
         {   // recurrence over the agent axis
             LstmUnitW w;
-            lstm_load_unit(s_whh, j, w);
+            lstm_load_unit(S.s_whh, j, w);
             float h = 0.0f, c = 0.0f;
             for (int s = 0; s < N; ++s) {
                 const int t = dir ? N - 1 - s : s;
-                const float *g = s_g + (se * N + t) * kGs;
+                const float *g = S.s_g + (se * N + t) * kGs;
                 const float gi = g[j], gf = g[32 + j], gg = g[64 + j], go = g[96 + j];
                 hs[j] = h;
                 wave_lds_sync();
                 lstm_step(w, hs, gi, gf, gg, go, h, c);
-                if (seq_ok) s_hid[(se * N + t) * kHs + dir * 32 + j] = A.relu_out ? fmaxf(h, 0.0f) : h;
+                if (seq_ok) S.s_hid[(se * N + t) * kHs + dir * 32 + j] = A.relu_out ? fmaxf(h, 0.0f) : h;
             }
         }
         PW_STAMP(5);
@@ -505,15 +533,15 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
     // ---- head
     if (A.H) {
         for (int idx = tid; idx < rows_here * 64; idx += 512)
-            A.H[(size_t)row_base * 64 + idx] = s_hid[(idx >> 6) * kHs + (idx & 63)];
+            A.H[(size_t)row_base * 64 + idx] = S.s_hid[(idx >> 6) * kHs + (idx & 63)];
     }
     // thread = (row, logit); the heads' logits are concatenated ([n_out0 | n_out1], run.py:39-41 order)
     const int OUT = A.n_out0 + A.n_out1, nheads = A.n_out1 > 0 ? 2 : 1;
-    const uint64_t step = (A.act && A.step_dev) ? (uint64_t)*A.step_dev : A.step;
+    const bool sample = act_g != nullptr || act_l != nullptr;
     for (int idx = tid; idx < rows_here * OUT; idx += 512) {
         const int r = idx / OUT, o = idx - r * OUT;
-        float acc = s_b2[o];
-        const float4 *hv = reinterpret_cast<const float4 *>(s_hid + r * kHs), *wv = reinterpret_cast<const float4 *>(s_w2 + o * 64);
+        float acc = S.s_b2[o];
+        const float4 *hv = reinterpret_cast<const float4 *>(S.s_hid + r * kHs), *wv = reinterpret_cast<const float4 *>(S.s_w2 + o * 64);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float4 hq = hv[q], wq = wv[q];
@@ -524,7 +552,7 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
         }
         const long grow = row_base + r;
         if (A.logits) A.logits[(size_t)grow * OUT + o] = acc;
-        if (A.act) {
+        if (sample) {
             // uniform o of a row = word (o & 3) of Philox block (o >> 2); the block index sits in the two top bits
             // of counter word 1 (block 1 = 0x80000000, as pw_actor_head_kernel's second call)
             const uint32_t blk = (uint32_t)o >> 2, tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
@@ -534,24 +562,40 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
             const int w = o & 3;
             const uint32_t uw = w == 0 ? u[0] : w == 1 ? u[1] : w == 2 ? u[2] : u[3];
             const float uo = ((float)(uw >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
-            s_lg[idx] = acc - __logf(-__logf(uo));
+            S.s_lg[idx] = acc - __logf(-__logf(uo));
         }
     }
-    if (A.act) {
+    if (sample) {
         __syncthreads();
         for (int idx = tid; idx < rows_here * nheads; idx += 512) {
             const int r = idx / nheads, hd = idx - r * nheads;
             const int lo = hd ? A.n_out0 : 0, cnt = hd ? A.n_out1 : A.n_out0;
-            const float *v = s_lg + r * OUT + lo;
+            const float *v = S.s_lg + r * OUT + lo;
             int best = 0;
             float bv = v[0];
             for (int o = 1; o < cnt; ++o)
                 if (v[o] > bv) { bv = v[o]; best = o; }
-            A.act[(row_base + r) * nheads + hd] = best;
+            if (act_g) act_g[idx] = best;
+            if (act_l) act_l[idx] = best;
         }
     }
     PW_STAMP(7);
     PW_STAMP_FLUSH;
+}
+
+template <int S1C>
+__global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const ActorLds S = actor_carve(smem_raw, 4 * S1C);
+    const int N = A.N, E = A.E;
+    const long env0 = (long)blockIdx.x * E;
+    const int envs_here = (int)((long)A.B - env0 < (long)E ? (long)A.B - env0 : (long)E);
+    const long row_base = env0 * N;
+    const int nheads = A.n_out1 > 0 ? 2 : 1;
+    const uint64_t step = (A.act && A.step_dev) ? (uint64_t)*A.step_dev : A.step;
+    actor_forward_wg<S1C>(A, S, A.X + (size_t)row_base * A.D, envs_here * N, envs_here, row_base, true, step,
+                          A.act ? A.act + row_base * nheads : nullptr, nullptr);
 }
 
 // Test hook: evaluate one device math primitive element-wise so that tests can compare the exact bits

@@ -801,8 +801,7 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
     a.E = 96 / N < 16 ? 96 / N : 16;
     a.seed = seed; a.step = step; a.step_dev = step_dev; a.H = H; a.logits = logits; a.act = act;
     const int S1C = (in_dim + 7) / 8, S1 = 4 * S1C;
-    const size_t shm = (size_t)(4 * 2 * 4 * 64 + 4 * 8 * 32) * sizeof(float4) +
-                       (size_t)(2 * S1 * 64 + kFusedRows * kGs + kFusedRows * kHs + 64 + 256 + 1024 + 16 + 512 + kFusedRows * 16) * sizeof(float);
+    const size_t shm = actor_lds_bytes(S1);
     const unsigned grid = (unsigned)((B + a.E - 1) / a.E);
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool attr_set[9] = {};
