@@ -205,6 +205,16 @@ int pw_replay_add_tail(const pw_replay_store *st, int64_t start, const int64_t *
                        const float *next_obs, const float *final_obs, const uint8_t *terminal, const float *done,
                        float *episode_return, double *finished_sum, int64_t *finished_count, int64_t *step_counter,
                        void *stream);
+/* A whole rollout chunk (pw_policy_rollout / pw_rollout outputs, [T, ...]) into the ring in one launch: transition
+ * (t, e) goes to slot (start + t*B + e) % capacity -- the order of T pw_replay_add calls -- with obs = obs0 [B,N,D]
+ * for t = 0 and the chunk's obs[t-1] after that, next_obs = final_obs where terminal.  io needs obs, rew_shared,
+ * terminal (final_obs optional); act [T,B,N] int32.  episode_return / finished_sum / finished_count / scratch
+ * (all or none): the chunk's episode-return bookkeeping, as T pw_episode_stats calls up to float64 summation
+ * order (fixed, so reproducible); scratch = pw_replay_add_rollout_scratch_bytes(B) device bytes, zeroed once. */
+int pw_replay_add_rollout(const pw_replay_store *st, int64_t start, int32_t B, int32_t T, const float *obs0,
+                          const pw_step_io *io, const int32_t *act, float *episode_return, double *finished_sum,
+                          int64_t *finished_count, void *scratch, void *stream);
+size_t pw_replay_add_rollout_scratch_bytes(int32_t B);
 int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b,
                      float *out_obs, float *out_act, float *out_rew, float *out_next_obs,
                      float *out_done, void *stream);
@@ -274,6 +284,19 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
                    const float *w_hh_bw, const float *w2, const float *b2, int32_t n_out0, int32_t n_out1, int64_t B,
                    int32_t N, int32_t in_dim, int32_t relu_out, uint64_t seed, uint64_t step,
                    const int64_t *step_dev /* device, or NULL */, float *H, float *logits, int32_t *act, void *stream);
+
+/* Policy-in-the-loop rollout as ONE launch: num_steps x (actor forward + Gumbel sampling + environment step +
+ * auto-reset) on the handle's bound state, starting from the observation of the current state; observations,
+ * sampled actions and world state stay on the CU between steps.  io: the pw_rollout outputs ([num_steps, ...];
+ * obs, rew, rew_shared, done, terminal required, final_obs optional; no action inputs, no coll); act_out
+ * [num_steps,B,N] int32 receives the sampled indices; the Gumbel noise of step t is keyed (seed; step + t, row)
+ * exactly as pw_actor_fused / pw_actor_head, so the results equal a loop of pw_actor_fused + pw_step.
+ * simple_spread fast-path configurations (local observation, homogeneous agents, L <= N), one 5-logit head;
+ * weights as for pw_actor_fused. */
+int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
+                      const float *w_hh_bw, const float *w2, const float *b2, int32_t relu_out, uint64_t seed,
+                      uint64_t step, const int64_t *step_dev /* device, or NULL */, const pw_step_io *io,
+                      int32_t *act_out, int32_t num_steps, void *stream);
 
 /* Test hook: y[i] = f(x[i]) with the DEVICE implementation of one math primitive, so its bits can be compared
  * with a CPU implementation of pworld_math.h.  fn: 0 the kernels' fast correctly-rounded sqrt, 1 their

@@ -89,11 +89,15 @@ SIGNATURES = {
     'pw_actor_front': (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     'pw_actor_fused': (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                                     C.c_uint64, C.c_uint64] + [C.c_void_p] * 5),
+    'pw_policy_rollout': (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.c_int32, C.c_void_p]),
     'pw_bilstm_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p]),
     'pw_actor_head': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     'pw_episode_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pw_replay_add_rollout': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 8),
+    'pw_replay_add_rollout_scratch_bytes': (C.c_size_t, [C.c_int32]),
     'pw_replay_add_tail': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 12),
     'pw_rollout_tail': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),

@@ -367,13 +367,13 @@ struct ActorLds {
     float *s_b1, *s_bih;  // [64], [256]
     float *s_w2, *s_b2;   // [16][64] (n_out0 + n_out1 rows used), [16]
     float *s_hx;    // [16 sequences][32]
-    float *s_lg;    // [96 * 16] perturbed logits
+    float *s_lg;    // [96 * 16] perturbed logits -- aliases s_g, which is dead once the last recurrence has finished
     unsigned char *end;
 };
 __host__ __device__ constexpr size_t actor_lds_bytes(int S1)
 {
     return (size_t)(4 * 2 * 4 * 64 + 4 * 8 * 32) * 16 +
-           (size_t)(2 * S1 * 64 + kFusedRows * kGs + kFusedRows * kHs + 64 + 256 + 1024 + 16 + 512 + kFusedRows * 16) * 4;
+           (size_t)(2 * S1 * 64 + kFusedRows * kGs + kFusedRows * kHs + 64 + 256 + 1024 + 16 + 512) * 4;
 }
 __device__ __forceinline__ ActorLds actor_carve(unsigned char *raw, const int S1)
 {
@@ -388,22 +388,37 @@ __device__ __forceinline__ ActorLds actor_carve(unsigned char *raw, const int S1
     S.s_w2 = S.s_bih + 256;
     S.s_b2 = S.s_w2 + 1024;
     S.s_hx = S.s_b2 + 16;
-    S.s_lg = S.s_hx + 512;
-    S.end = reinterpret_cast<unsigned char *>(S.s_lg + kFusedRows * 16);
+    S.s_lg = S.s_g;
+    S.end = reinterpret_cast<unsigned char *>(S.s_hx + 512);
     return S;
+}
+
+// one direction's weights -> LDS: W_ih fragments (32 KB) + W_hh (16 KB, re-laid as [gate][k/4][unit]); called by
+// `nthr` threads numbered t0 = 0 .. nthr - 1
+__device__ __forceinline__ void actor_fill_dir(const ActorFusedArgs &A, const ActorLds &S, const int dir, const int t0,
+                                               const int nthr)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(A.frag) + dir * 2048;
+    for (int f = t0; f < 2048; f += nthr) S.f_wih[f] = src[f];
+    const float4 *wh = reinterpret_cast<const float4 *>(dir ? A.whh_r : A.whh_f);
+    for (int f = t0; f < 1024; f += nthr) {
+        const int row = f >> 3, q = f & 7, gate = row >> 5, unit = row & 31;
+        S.s_whh[(gate * 8 + q) * 32 + unit] = wh[f];
+    }
 }
 
 // One forward pass of the actor for the rows of this workgroup (all 512 threads call it).
 //   xrows      observation rows of this workgroup, row-major [rows_here][A.D] -- global memory or LDS
 //   load_const stage-1 fragments, biases and head weights -> LDS (needed once per kernel)
+//   fill0      fetch the forward direction's weights here (false: the caller already did, behind a barrier)
 //   step       Philox step of the Gumbel noise
 //   act_g      global sink of the sampled indices [rows_here * nheads] (or NULL), act_l the same in LDS (or NULL)
 // On return every thread has passed a barrier after the last LDS write of the pass.
 template <int S1C>
 __device__ __forceinline__ void actor_forward_wg(const ActorFusedArgs &A, const ActorLds &S, const float *xrows,
                                                  const int rows_here, const int envs_here, const long row_base,
-                                                 const bool load_const, const uint64_t step, int32_t *act_g,
-                                                 int32_t *act_l)
+                                                 const bool load_const, const bool fill0, const uint64_t step,
+                                                 int32_t *act_g, int32_t *act_l)
 {
     constexpr int S1 = 4 * S1C;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
@@ -412,16 +427,6 @@ __device__ __forceinline__ void actor_forward_wg(const ActorFusedArgs &A, const 
     PW_STAMP_DECL;
     PW_STAMP_START;
 
-    // one direction's weights -> LDS: W_ih fragments (32 KB) + W_hh (16 KB, re-laid as [gate][k/4][unit])
-    auto fill_dir = [&](const int dir) {
-        const float4 *src = reinterpret_cast<const float4 *>(A.frag) + dir * 2048;
-        for (int f = tid; f < 2048; f += 512) S.f_wih[f] = src[f];
-        const float4 *wh = reinterpret_cast<const float4 *>(dir ? A.whh_r : A.whh_f);
-        for (int f = tid; f < 1024; f += 512) {
-            const int row = f >> 3, q = f & 7, gate = row >> 5, unit = row & 31;
-            S.s_whh[(gate * 8 + q) * 32 + unit] = wh[f];
-        }
-    };
     // Matrix-core job map: 3 row tiles x 4 unit tiles per direction = 12 jobs over 4 SIMDs (waves w and w + 4
     // share one): waves 0-3 take two unit tiles of row tiles 0 / 1, waves 4-7 one unit tile of row tile 2, so
     // every SIMD carries three jobs.  Each wave needs stage 1 of its own row tile only.
@@ -448,8 +453,8 @@ __device__ __forceinline__ void actor_forward_wg(const ActorFusedArgs &A, const 
         for (int f = tid; f < OUTc * 64; f += 512) S.s_w2[f] = A.w2[f];
         if (tid < OUTc) S.s_b2[tid] = A.b2[tid];
     }
-    fill_dir(0);
-    __syncthreads();
+    if (fill0) actor_fill_dir(A, S, 0, tid, 512);
+    if (fill0 || load_const) __syncthreads();
     PW_STAMP(0);
 
     // ---- stage 1
@@ -480,7 +485,7 @@ __device__ __forceinline__ void actor_forward_wg(const ActorFusedArgs &A, const 
 #pragma unroll 1
     for (int dir = 0; dir < 2; ++dir) {
         if (dir == 1) {
-            fill_dir(1);
+            actor_fill_dir(A, S, 1, tid, 512);
             __syncthreads();
         }
         PW_STAMP(2);
@@ -594,8 +599,191 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
     const long row_base = env0 * N;
     const int nheads = A.n_out1 > 0 ? 2 : 1;
     const uint64_t step = (A.act && A.step_dev) ? (uint64_t)*A.step_dev : A.step;
-    actor_forward_wg<S1C>(A, S, A.X + (size_t)row_base * A.D, envs_here * N, envs_here, row_base, true, step,
+    actor_forward_wg<S1C>(A, S, A.X + (size_t)row_base * A.D, envs_here * N, envs_here, row_base, true, true, step,
                           A.act ? A.act + row_base * nheads : nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// Policy-in-the-loop rollout as ONE launch: T x (actor forward + Gumbel sampling + environment step) with the
+// observations, the sampled actions and the world state of a workgroup's 16 environments never leaving the
+// CU between steps.  Per step a workgroup runs actor_forward_wg on the observation rows it keeps in LDS,
+// then its first one or two waves advance the environments exactly as pw_spread_stream_kernel does (lane =
+// (env, agent); same expressions, same order, same bits) and write the step's outputs -- and the next
+// observation rows back into LDS.  HBM sees the outputs of a step once; there is no launch, no kernel
+// boundary and no weight-constant refill between steps (only the per-direction W_ih / W_hh tiles, from L2).
+// simple_spread fast-path configurations (local observation, homogeneous agents, L <= N), one 5-logit head.
+// ------------------------------------------------------------------------------------------
+struct PolicyRolloutArgs {
+    ActorFusedArgs A;   // weights, B, N, D, E, heads, seed, step / step_dev (Philox step of the FIRST pass)
+    StreamParams V;     // world constants, state planes, outputs (V.act unused)
+    int T;
+    int32_t *act_out;   // [T,B,N] sampled action indices
+};
+
+template <int S1C, int NT>
+__global__ void __launch_bounds__(512) pw_policy_rollout_kernel(const PolicyRolloutArgs P)
+{
+    constexpr int LT = NT;  // NT > 0: N = L = NT at compile time (the environment loops unroll)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const ActorFusedArgs &A = P.A;
+    const StreamParams &V = P.V;
+    const ActorLds S = actor_carve(smem_raw, 4 * S1C);
+    const int N = NT ? NT : A.N, L = LT ? LT : V.L, D = A.D;
+    float *s_obs = reinterpret_cast<float *>(S.end);                       // [96][D] observation rows
+    int32_t *s_act = reinterpret_cast<int32_t *>(s_obs + kFusedRows * D);  // [96]
+    float2 *s_posb = reinterpret_cast<float2 *>(s_act + kFusedRows);       // [2 env waves][64]
+    float2 *s_lmb = s_posb + 2 * kWave;                                    // [E * L]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long env0 = (long)blockIdx.x * A.E;
+    const int envs_here = (int)((long)A.B - env0 < (long)A.E ? (long)A.B - env0 : (long)A.E);
+    const int rows_here = envs_here * N;
+    const long row_base = env0 * N;
+    const size_t BN = (size_t)A.B * N;
+
+    // ---- environment lanes: wave w < n_env_waves owns local envs [w * epw, ...), lane = e_loc * N + a
+    const int epw = A.E < kWave / N ? A.E : kWave / N;
+    const int n_env_waves = (envs_here + epw - 1) / epw;
+    const bool env_wave = wave < n_env_waves;
+    int e_loc = lane / N, a = lane - e_loc * N;
+    int el = wave * epw + e_loc;                       // local env index in the workgroup
+    const bool live = env_wave && e_loc < epw && el < envs_here;
+    if (!live) { e_loc = 0; a = 0; el = env_wave ? wave * epw : 0; }  // idle lanes shadow lane 0, store nothing
+    const int base = e_loc * N, r = el * N + a;
+    const long env = env0 + el;
+    const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
+    float2 *s_pos = s_posb + (env_wave ? wave : 0) * kWave;
+    const float2 *pp = s_pos + base;
+    float2 *lmv = s_lmb + el * L;
+    const int la = a < L ? a : 0;
+
+    float px = 0.f, py = 0.f, vx = 0.f, vy = 0.f, olx = 0.f, oly = 0.f, best = 0.f;
+    int ep_step = 0;
+    uint32_t ep_count = 0;
+    uint64_t coll = 0, near = 0;
+    if (env_wave) {
+        px = V.pos_x[g]; py = V.pos_y[g]; vx = V.vel_x[g]; vy = V.vel_y[g];
+        ep_step = V.ep_step[env];
+        ep_count = V.ep_count[env];
+        if (L > 0) {
+            olx = V.lm_x[(size_t)env * L + la];
+            oly = V.lm_y[(size_t)env * L + la];
+            if (live) lmv[la] = make_float2(olx, oly);
+        }
+        if (live) s_pos[base + a] = make_float2(px, py);
+        wave_lds_sync();
+        stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
+        if (live) stream_write_obs<LT>(s_obs + r * D, L, lmv, px, py, vx, vy);
+    }
+    const float k = V.contact_margin, cf = V.contact_force, dt = V.dt, damp = V.damp, mass = V.mass;
+    const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
+    __syncthreads();
+
+#ifdef PW_STAMPS
+    unsigned long long mt[4] = {0, 0, 0, 0}, m0 = 0, m1 = 0;
+#define PW_MSTAMP(i) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(m1)::"memory"); mt[i] += m1 - m0; m0 = m1; } while (0)
+#else
+#define PW_MSTAMP(i)
+#endif
+    for (int t = 0; t < P.T; ++t) {
+#ifdef PW_STAMPS
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(m0)::"memory");
+#endif
+        // ---- policy: observation rows (LDS) -> sampled action index per row (LDS)
+        actor_forward_wg<S1C>(A, S, s_obs, rows_here, envs_here, row_base, t == 0, t == 0, step0 + (uint64_t)t, nullptr,
+                              s_act);
+        PW_MSTAMP(0);
+        __syncthreads();
+        PW_MSTAMP(1);
+        // ---- environment step (pw_spread_stream_kernel's arithmetic)
+        if (env_wave) {
+            const size_t tBN = (size_t)t * BN;
+            const int ai = s_act[r];
+            float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
+            float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
+            ux *= V.sens; uy *= V.sens;
+            if (V.fscale != 1.0f) { ux = V.fscale * ux; uy = V.fscale * uy; }
+            float fx = ux + 0.0f, fy = uy + 0.0f;
+            near_force_loop<uint64_t, float2>(live ? near : 0, pp, px, py, V.dist_min, k, cf, fx, fy);
+            vx = vx * damp; vy = vy * damp;
+            vx = vx + (fx / mass) * dt;
+            vy = vy + (fy / mass) * dt;
+            px = px + vx * dt;
+            py = py + vy * dt;
+            wave_lds_sync();
+            if (live) s_pos[base + a] = make_float2(px, py);
+            wave_lds_sync();
+            stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
+            const float own = sqrtf(best);
+            float rw = 0.0f;
+#pragma unroll(LT > 0 ? LT : 1)
+            for (int l = 0; l < L; ++l) rw -= __shfl(own, base + l, kWave);
+#pragma unroll(NT > 0 ? NT : 1)
+            for (int j = 0; j < N; ++j)
+                if ((coll >> j) & 1) rw -= 1.0f;
+            float acc = 0.0f;
+#pragma unroll(NT > 0 ? NT : 1)
+            for (int i = 0; i < N; ++i) acc += __shfl(rw, base + i, kWave);
+            ep_step += 1;
+            const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
+            if (live) {
+                P.act_out[tBN + g] = ai;
+                V.rew[tBN + g] = rw;
+                V.done[tBN + g] = 0;
+                if (a == 0) {
+                    V.rew_shared[(size_t)t * A.B + env] = acc;
+                    V.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+                }
+            }
+            if (term && V.auto_reset) {  // same for every lane of an env
+                if (live && V.final_obs) stream_write_obs<LT>(V.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+                wave_lds_sync();
+                ep_count += 1;
+                ep_step = 0;
+                const uint64_t env_id = V.env_id_base + (uint64_t)env;
+                pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
+                vx = 0.f; vy = 0.f;
+                if (L > 0) {
+                    pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)(N + la), -1.0f, 1.0f, &olx, &oly);
+                    if (live) lmv[la] = make_float2(olx, oly);
+                }
+                if (live) s_pos[base + a] = make_float2(px, py);
+            }
+            wave_lds_sync();
+            if (V.auto_reset && __any(term))
+                stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
+            if (live) {
+                stream_write_obs<LT>(V.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+                stream_write_obs<LT>(s_obs + r * D, L, lmv, px, py, vx, vy);
+            }
+        } else if (t + 1 < P.T) {
+            // the other waves fetch the next pass's forward-direction weights meanwhile (their LDS tiles are idle)
+            const int nw = 8 - n_env_waves;
+            actor_fill_dir(A, S, 0, tid - n_env_waves * kWave, nw * kWave);
+        }
+        PW_MSTAMP(2);
+        __syncthreads();
+        PW_MSTAMP(3);
+    }
+#ifdef PW_STAMPS
+    if (blockIdx.x == 0 && tid == 0)
+        for (int i_ = 0; i_ < 4; ++i_) g_pw_stamps[8 + i_] = mt[i_];
+#endif
+#undef PW_MSTAMP
+
+    if (live) {
+        V.pos_x[g] = px; V.pos_y[g] = py;
+        V.vel_x[g] = vx; V.vel_y[g] = vy;
+        if (L > 0 && a < L) {
+            V.lm_x[(size_t)env * L + la] = olx;
+            V.lm_y[(size_t)env * L + la] = oly;
+        }
+        if (a == 0) {
+            V.ep_step[env] = ep_step;
+            V.ep_count[env] = ep_count;
+        }
+    }
 }
 
 // Test hook: evaluate one device math primitive element-wise so that tests can compare the exact bits

@@ -110,6 +110,101 @@ __global__ void __launch_bounds__(256) pw_replay_add_tail_kernel(const pw_replay
     }
 }
 
+// A whole rollout chunk into the ring in ONE launch (the sink of pw_policy_rollout / pw_rollout): transition
+// (t, e) -> slot (start + t * B + e) % capacity, i.e. the order in which T calls of pw_replay_add would have stored
+// them; obs of step t is obs0 (t = 0) or the chunk's obs[t - 1], next_obs the PRE-reset observation where the env
+// terminated (run.py:52 vs :60).  The last `stat_blocks` workgroups do the episode-return bookkeeping of the
+// chunk: thread = env, walking its T steps in order (loads batched 8 deep), a fixed-order tree per workgroup, the
+// partial (sum, count) into `scratch`, and the workgroup that arrives last adds the partials in index order --
+// bit-reproducible without float atomics.  scratch: [2 * stat_blocks + 1] 8-byte words, zero before first use.
+__global__ void __launch_bounds__(256) pw_replay_add_rollout_kernel(const pw_replay_store st, const int64_t start,
+                                                                    const int B, const int T, const float *obs0,
+                                                                    const pw_step_io io, const int32_t *act,
+                                                                    const ReplayTail tl, const unsigned stat_blocks,
+                                                                    unsigned long long *scratch)
+{
+    const int ND = st.num_agents * st.obs_dim, N = st.num_agents;
+    const size_t per_step = (size_t)B * ND, total = (size_t)T * per_step;
+    const unsigned copy_blocks = gridDim.x - stat_blocks;
+    if (blockIdx.x < copy_blocks) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)copy_blocks * blockDim.x) {
+            const size_t t = i / per_step, rem = i - t * per_step, e = rem / ND, c = rem - e * ND;
+            const size_t te = t * B + e;
+            const size_t slot = (size_t)((start + (int64_t)te) % st.capacity);
+            st.obs[slot * ND + c] = t == 0 ? obs0[rem] : io.obs[i - per_step];
+            const bool fin = io.final_obs && io.terminal[te];
+            st.next_obs[slot * ND + c] = fin ? io.final_obs[i] : io.obs[i];
+            if (c < (size_t)N) st.act[slot * N + c] = (uint8_t)act[te * N + c];
+            if (c == 0) {
+                st.rew[slot] = io.rew_shared[te];
+                st.done[slot] = 0.0f;
+            }
+        }
+        return;
+    }
+    const unsigned sb = blockIdx.x - copy_blocks;
+    __shared__ double s_sum[256];
+    __shared__ int s_cnt[256];
+    __shared__ bool s_last;
+    double acc = 0.0;
+    int cnt = 0;
+    const int e = (int)(sb * 256 + threadIdx.x);
+    if (e < B) {
+        float ret = tl.episode_return[e];
+        for (int t0 = 0; t0 < T; t0 += 8) {
+            float rw[8];
+            uint8_t tm[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int t = t0 + q < T ? t0 + q : T - 1;
+                rw[q] = io.rew_shared[(size_t)t * B + e];
+                tm[q] = io.terminal[(size_t)t * B + e];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (t0 + q < T) {
+                    const float r = ret + rw[q];
+                    if (tm[q]) { acc += (double)r; cnt += 1; ret = 0.0f; }
+                    else ret = r;
+                }
+            }
+        }
+        tl.episode_return[e] = ret;
+    }
+    s_sum[threadIdx.x] = acc;
+    s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + w];
+            s_cnt[threadIdx.x] += s_cnt[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    double *part_sum = reinterpret_cast<double *>(scratch);
+    long long *part_cnt = reinterpret_cast<long long *>(scratch + stat_blocks);
+    unsigned long long *ticket = scratch + 2 * stat_blocks;
+    if (threadIdx.x == 0) {
+        part_sum[sb] = s_sum[0];
+        part_cnt[sb] = s_cnt[0];
+        __threadfence();
+        s_last = atomicAdd(ticket, 1ull) == (unsigned long long)stat_blocks - 1;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        __threadfence();
+        double ssum = 0.0;
+        long long scnt = 0;
+        for (unsigned i = 0; i < stat_blocks; ++i) {
+            ssum += __builtin_nontemporal_load(part_sum + i);
+            scnt += __builtin_nontemporal_load(part_cnt + i);
+        }
+        *tl.finished_sum += ssum;
+        *tl.finished_count += scnt;
+        *ticket = 0;
+    }
+}
+
 __global__ void pw_replay_gather_kernel(const pw_replay_store st, const int64_t *idx, const int b,
                                         float *out_obs, float *out_act, float *out_rew, float *out_next_obs,
                                         float *out_done)

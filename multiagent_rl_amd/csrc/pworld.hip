@@ -688,6 +688,32 @@ int pw_replay_add_tail(const pw_replay_store *st, int64_t start, const int64_t *
     return PW_OK;
 }
 
+int pw_replay_add_rollout(const pw_replay_store *st, int64_t start, int32_t B, int32_t T, const float *obs0,
+                          const pw_step_io *io, const int32_t *act, float *episode_return, double *finished_sum,
+                          int64_t *finished_count, void *scratch, void *stream)
+{
+    if (!st || !obs0 || !io || !act || !io->obs || !io->rew_shared || !io->terminal) return fail(PW_EINVAL, "null argument");
+    if (st->capacity < 1 || B < 1 || T < 1 || (int64_t)B * T > st->capacity || start < 0)
+        return fail(PW_EINVAL, "bad ring arguments (the chunk must fit the ring)");
+    if (st->obs_dim < 5) return fail(PW_EINVAL, "obs_dim must be >= 5");
+    if (episode_return && (!finished_sum || !finished_count || !scratch))
+        return fail(PW_EINVAL, "bookkeeping needs episode_return, finished_sum, finished_count and scratch");
+    const size_t total = (size_t)T * B * st->num_agents * st->obs_dim;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    const unsigned stat_blocks = episode_return ? (unsigned)((B + 255) / 256) : 0;
+    ReplayTail tl;
+    tl.episode_return = episode_return; tl.finished_sum = finished_sum; tl.finished_count = finished_count;
+    tl.next_start_dev = nullptr; tl.step_counter = nullptr;
+    hipLaunchKernelGGL(pw_replay_add_rollout_kernel, dim3((unsigned)blocks + stat_blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *st, start, B, T, obs0, *io, act, tl, stat_blocks,
+                       static_cast<unsigned long long *>(scratch));
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+size_t pw_replay_add_rollout_scratch_bytes(int32_t B) { return (size_t)(2 * ((B + 255) / 256) + 1) * 8; }
+
 int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b, float *out_obs, float *out_act,
                      float *out_rew, float *out_next_obs, float *out_done, void *stream)
 {
@@ -818,6 +844,74 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
         PW_FUSED(1) PW_FUSED(2) PW_FUSED(3) PW_FUSED(4) PW_FUSED(5) PW_FUSED(6) PW_FUSED(7) PW_FUSED(8)
     }
 #undef PW_FUSED
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
+                      const float *w_hh_bw, const float *w2, const float *b2, int32_t relu_out, uint64_t seed,
+                      uint64_t step, const int64_t *step_dev, const pw_step_io *io, int32_t *act_out, int32_t num_steps,
+                      void *stream)
+{
+    if (int rc = check_ready(h)) return rc;
+    if (!frag || !b1 || !b_ih || !w_hh_fw || !w_hh_bw || !w2 || !b2 || !io || !act_out) return fail(PW_EINVAL, "null argument");
+    if (num_steps < 1) return fail(PW_EINVAL, "num_steps must be >= 1");
+    const KParams &kp = h->kp;
+    if (!h->fast)
+        return fail(PW_EINVAL, "pw_policy_rollout serves the simple_spread fast-path configurations (local observation, "
+                               "homogeneous agents, L <= N)");
+    if (kp.N > 64 || kp.D > 64) return fail(PW_EINVAL, "N and the observation length must be <= 64");
+    if (io->act_idx || io->act_vec || io->act_comm || io->coll)
+        return fail(PW_EINVAL, "pw_policy_rollout produces the actions itself (act_out) and has no coll output");
+    if (!io->obs || !io->rew || !io->rew_shared || !io->done || !io->terminal)
+        return fail(PW_EINVAL, "obs, rew, rew_shared, done and terminal outputs are required");
+    if ((reinterpret_cast<uintptr_t>(io->obs) | reinterpret_cast<uintptr_t>(io->final_obs) | reinterpret_cast<uintptr_t>(frag) |
+         reinterpret_cast<uintptr_t>(w_hh_fw) | reinterpret_cast<uintptr_t>(w_hh_bw)) & 15)
+        return fail(PW_EINVAL, "obs, final_obs, frag and w_hh must be 16-byte aligned");
+    PolicyRolloutArgs P;
+    std::memset(&P, 0, sizeof(P));
+    ActorFusedArgs &a = P.A;
+    a.frag = frag; a.b1 = b1; a.bih = b_ih; a.whh_f = w_hh_fw; a.whh_r = w_hh_bw; a.w2 = w2; a.b2 = b2;
+    a.B = kp.B; a.N = kp.N; a.D = kp.D; a.relu_out = relu_out; a.n_out0 = 5; a.n_out1 = 0;
+    a.E = 96 / kp.N < 16 ? 96 / kp.N : 16;
+    a.seed = seed; a.step = step; a.step_dev = step_dev;
+    StreamParams &A = P.V;
+    A.B = kp.B; A.N = kp.N; A.L = kp.L; A.epw = kp.epw;
+    A.max_episode_len = kp.max_episode_len; A.auto_reset = kp.auto_reset;
+    A.seed = kp.seed; A.env_id_base = kp.env_id_base;
+    A.dt = kp.dt; A.damp = kp.damp; A.contact_force = kp.contact_force; A.contact_margin = kp.contact_margin;
+    A.mass = kp.mass;
+    A.dist_min = h->fc.dist_min; A.coll_thr2 = h->fc.coll_thr2; A.near_thr2 = h->fc.near_thr2;
+    A.sens = h->fc.sens; A.fscale = h->fc.fscale;
+    A.pos_x = kp.pos_x; A.pos_y = kp.pos_y; A.vel_x = kp.vel_x; A.vel_y = kp.vel_y;
+    A.lm_x = kp.lm_x; A.lm_y = kp.lm_y; A.ep_step = kp.ep_step; A.ep_count = kp.ep_count;
+    A.obs = io->obs; A.final_obs = io->final_obs; A.rew = io->rew; A.rew_shared = io->rew_shared;
+    A.done = io->done; A.terminal = io->terminal;
+    P.T = num_steps; P.act_out = act_out;
+    const int S1C = (kp.D + 7) / 8, S1 = 4 * S1C;
+    const size_t shm = actor_lds_bytes(S1) + (size_t)kFusedRows * kp.D * sizeof(float) + kFusedRows * sizeof(int32_t) +
+                       2 * kWave * sizeof(float2) + (size_t)a.E * kp.L * sizeof(float2);
+    if (shm > 160 * 1024) return fail(PW_EINVAL, "observation too long for the one-launch rollout (LDS)");
+    const unsigned grid = (unsigned)((kp.B + a.E - 1) / a.E);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define PW_PR2(C, NT)                                                                                                    \
+    do {                                                                                                                 \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_kernel<C, NT>),            \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL((pw_policy_rollout_kernel<C, NT>), dim3(grid), dim3(512), shm, st, P);                        \
+    } while (0)
+#define PW_PR(C) case C: PW_PR2(C, 0); break;
+    if (kp.N == 6 && kp.L == 6) PW_PR2(2, 6);        // BASELINE configs[1]: D = 16
+    else if (kp.N == 3 && kp.L == 3) PW_PR2(2, 3);   // configs[0]: D = 10
+    else switch (S1C) {
+        PW_PR(1) PW_PR(2) PW_PR(3) PW_PR(4) PW_PR(5) PW_PR(6) PW_PR(7) PW_PR(8)
+    }
+#undef PW_PR2
+#undef PW_PR
     PW_HIP_CHECK(hipGetLastError());
     return PW_OK;
 }

@@ -214,6 +214,34 @@ class FusedActor(object):
         self.calls += 1
         return act
 
+    @torch.no_grad()
+    def rollout(self, env, num_steps, out=None):
+        """``num_steps`` x (this actor + Gumbel sampling + ``env`` step with auto-reset) as ONE launch
+        (``pw_policy_rollout``): observations, actions and world state stay on the CU between steps.  Continues
+        from the env's current state.  -> dict of [T, ...] outputs as ``BatchedParticleEnv.rollout`` plus
+        ``act`` [T,B,N] int32.  Same results as ``num_steps`` iterations of ``act = self(obs); env.step(act)``."""
+        from ._lib import PwStepIO
+        assert len(self.heads) == 1 and self.heads[0] == 5, 'single 5-logit head only'
+        T, B, N = int(num_steps), env.num_envs, env.n
+        out = env.alloc_outputs(T, coll=False) if out is None else out
+        if 'act' not in out:
+            out['act'] = torch.empty(T, B, N, dtype=torch.int32, device=self.device)
+        io = PwStepIO()
+        for name in ('obs', 'final_obs', 'rew', 'rew_shared', 'done', 'terminal'):
+            t = out.get(name)
+            if t is not None:
+                assert t.is_contiguous() and t.shape[0] == T
+                setattr(io, name, t.data_ptr())
+        p = lambda t: None if t is None else self._C.c_void_p(t.data_ptr())  # noqa: E731
+        step_dev = p(self._step_dev) if self.graph_mode else None
+        self._lib_mod.check(self.lib.pw_policy_rollout(env._h, p(self.frag), p(self.b1), p(self.bih), p(self.whh_f),
+                                                       p(self.whh_r), p(self.w2), p(self.b2), 1, self.seed, self.calls,
+                                                       step_dev, self._C.byref(io), p(out['act']), T, self._stream()))
+        if step_dev is not None and not self.defer_step_advance:
+            self._lib_mod.check(self.lib.pw_counter_add(p(self._step_dev), T, 0, self._stream()))
+        self.calls += T
+        return out
+
     def begin_graph(self):
         """Switch to the device-side step counter (call before hipGraph capture)."""
         self._step_dev.fill_(self.calls)

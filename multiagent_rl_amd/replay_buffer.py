@@ -156,6 +156,37 @@ class ReplayBuffer(object):
             self._next_idx = (self._next_idx + B) % self._maxsize
             self._len = min(self._len + B, self._maxsize)
 
+    def add_rollout(self, obs0, out, episode_return=None, finished_sum=None, finished_count=None):
+        """A whole rollout chunk in ONE launch: ``out`` = the [T, ...] outputs of ``FusedActor.rollout`` /
+        ``BatchedParticleEnv.rollout`` (obs, rew_shared, terminal, final_obs, act), ``obs0`` [B,N,D] the
+        observation before its first step.  Stored in the order T ``add_batch`` calls would have used; optionally
+        does the chunk's episode-return bookkeeping in the same launch."""
+        from ._lib import PwStepIO
+        T, B, N, D = out['obs'].shape
+        if self._store is None:
+            self._device = obs0.device if self._device is None else self._device
+            self._allocate(N, D)
+        assert (N, D) == (self.num_agents, self.obs_dim) and T * B <= self._maxsize
+        io = PwStepIO()
+        for name in ('obs', 'final_obs', 'rew_shared', 'terminal'):
+            t = out.get(name)
+            if t is not None:
+                assert t.is_cuda and t.is_contiguous()
+                setattr(io, name, t.data_ptr())
+        act = out['act']
+        assert act.dtype == torch.int32 and act.is_contiguous() and obs0.is_contiguous() and obs0.dtype == torch.float32
+        scratch = None
+        if episode_return is not None:
+            if getattr(self, '_roll_scratch_B', None) != B:
+                n = self._lib.pw_replay_add_rollout_scratch_bytes(B)
+                self._roll_scratch, self._roll_scratch_B = torch.zeros(n, dtype=torch.uint8, device=self._device), B
+            scratch = self._roll_scratch
+        check(self._lib.pw_replay_add_rollout(C.byref(self._store), self._next_idx, B, T, _ptr(obs0), C.byref(io),
+                                              _ptr(act), _ptr(episode_return), _ptr(finished_sum),
+                                              _ptr(finished_count), _ptr(scratch), self._stream()))
+        self._next_idx = (self._next_idx + T * B) % self._maxsize
+        self._len = min(self._len + T * B, self._maxsize)
+
     # -- rls/replay_buffer.py:51-57
     def make_index(self, batch_size):
         return [random.randint(0, self._len - 1) for _ in range(batch_size)]

@@ -391,3 +391,71 @@ def test_one_launch_actor_equals_three_launch_chain(monkeypatch):
     # N > 96 falls back to the chain
     obs = torch.randn(2, 100, 40).cuda()
     assert torch.equal(one(obs), three(obs))
+
+
+@pytest.mark.parametrize('B,N,T', [(16, 6, 3), (4096, 6, 30), (100, 3, 60), (37, 7, 27), (5, 16, 4), (70, 2, 26), (9, 12, 26)])
+def test_one_launch_policy_rollout_equals_the_step_loop(B, N, T):
+    """pw_policy_rollout (T x (actor + sampling + env step) in ONE launch, everything resident on the CU) vs the
+    loop of FusedActor() + env.step(): sampled actions, observations, rewards, terminals, pre-reset observations
+    and the final world state must be IDENTICAL, across auto-resets, ragged batches and N that does not divide 96."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    torch.manual_seed(4)
+    mk = lambda: make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=25, seed=21)  # noqa: E731
+    env_a, env_b = mk(), mk()
+    actor = ActorNetwork(env_a.obs_dim, 5).cuda().eval()
+    loop, one = FusedActor(actor, seed=9), FusedActor(actor, seed=9)
+    obs = env_a.reset()
+    env_b.reset()
+    want = dict(obs=[], act=[], rew=[], rew_shared=[], terminal=[], final_obs=[])
+    for t in range(T):
+        act = loop(obs)
+        obs, rew, done, info = env_a.step(act)
+        for k, v in (('obs', obs), ('act', act), ('rew', rew), ('rew_shared', info['rew_shared']),
+                     ('terminal', info['terminal']), ('final_obs', info['final_obs'])):
+            want[k].append(v.clone())
+    got = one.rollout(env_b, T)
+    assert one.calls == loop.calls == T
+    for k in ('act', 'obs', 'rew', 'rew_shared', 'terminal'):
+        assert torch.equal(got[k], torch.stack(want[k])), k
+    term = got['terminal']
+    if term.any():
+        assert torch.equal(got['final_obs'][term], torch.stack(want['final_obs'])[term])
+    sa, sb = env_a.get_state(), env_b.get_state()
+    for k in ('pos', 'vel', 'landmarks', 'ep_step', 'ep_count'):
+        assert torch.equal(sa[k], sb[k]), k
+    assert not got['done'].any()
+    # continue both for a second chunk: the one-launch form resumes from the stored state and Philox step
+    act = loop(obs)
+    obs2, _, _, _ = env_a.step(act)
+    got2 = one.rollout(env_b, 1)
+    assert torch.equal(got2['act'][0], act) and torch.equal(got2['obs'][0], obs2)
+
+
+def test_collect_one_launch_fills_the_ring_like_the_step_loop():
+    """BatchedRollout.collect_one_launch (2 launches per chunk: pw_policy_rollout + pw_replay_add_rollout) vs
+    BatchedRollout.collect (3 launches per step): identical ring contents (wrapping), cursor, final observation
+    and world state; episode statistics equal up to float64 summation order."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    from multiagent_rl_amd.rollout import BatchedRollout
+    torch.manual_seed(0)
+    actor = ActorNetwork(16, 5).cuda().eval()
+    res = []
+    for one in (False, True):
+        env = make_batched_env('simple_spread', 200, n=6, auto_reset=True, max_episode_len=25, seed=11)
+        mem = ReplayBuffer(200 * 40, 6, env.obs_dim)              # 57 steps into 40 slots-of-B: wraps
+        ro = BatchedRollout(env, FusedActor(actor, seed=7), mem)
+        if one:
+            ro.collect_one_launch(57, chunk=20)                   # chunks of 20, 20, 17
+        else:
+            ro.collect(57)
+        st = ro.stats()
+        assert st['env_steps'] == 57 * 200 and st['episodes'] == 2 * 200 and len(mem) == 200 * 40
+        assert mem._next_idx == (57 * 200) % (200 * 40)
+        res.append((mem.obs.clone(), mem.next_obs.clone(), mem.act.clone(), mem.rew.clone(), mem.done.clone(),
+                    ro.obs.clone(), env.get_state()['pos'].clone(), ro.episode_return.clone(), st['mean_episode_reward']))
+    for a, b in zip(res[0][:8], res[1][:8]):
+        assert torch.equal(a, b)
+    assert abs(res[0][8] - res[1][8]) < 1e-9 * abs(res[0][8])
