@@ -14,6 +14,7 @@ hand-written HIP work is the environment, not the policy GEMMs.
 the same RNG call, but the result stays an int32 index tensor [B,N] in HBM -- no
 ``.cpu().numpy()`` round trip per env-step.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -246,6 +247,52 @@ class FusedActor(object):
         """Switch to the device-side step counter (call before hipGraph capture)."""
         self._step_dev.fill_(self.calls)
         self.graph_mode = True
+
+
+class FusedExploration(object):
+    """``Trainer.get_exploration_action`` (rls/agent/multiagent/ddpg_gumbel_fix.py:86-107) on the one-launch actor:
+    list of N observation arrays -> the hard Gumbel-softmax one-hot(s) the reference returns -- ``ndarray [1,N,5]``
+    float32 (Discrete) or a list of two such arrays (MultiDiscrete, [1,N,5] and [1,N,dim_c]).  One HIP launch
+    instead of MIOpen's ~45-kernel RNN path per environment step; weights are re-snapshotted by ``refresh()``."""
+
+    def __init__(self, actor, action_type='Discrete', seed=0):
+        self.action_type = action_type
+        self.fused = FusedActor(actor, seed=seed)
+        assert (len(self.fused.heads) == 2) == (action_type == 'MultiDiscrete')
+
+    def refresh(self):
+        self.fused.refresh()
+
+    @torch.no_grad()
+    def get_exploration_action(self, state):
+        obs = torch.from_numpy(np.array([np.stack(state)], dtype='float32')).to(self.fused.device)   # process_obs
+        idx = self.fused(obs).cpu().numpy()
+        eye = [np.eye(n, dtype=np.float32) for n in self.fused.heads]
+        if self.action_type == 'Discrete':
+            return eye[0][idx]
+        return [eye[0][idx[..., 0]], eye[1][idx[..., 1]]]
+
+
+def accelerate_trainer(trainer, seed=0):
+    """Patch an instance of the reference's ``Trainer`` in place: ``get_exploration_action`` runs on the one-launch
+    HIP actor, and the weight snapshot is refreshed after every ``optimize()`` (and ``load_models``).  Everything
+    else of the learner is untouched.  Returns the ``FusedExploration`` object."""
+    fx = FusedExploration(trainer.actor, getattr(trainer, 'action_type', 'Discrete'), seed=seed)
+    trainer.get_exploration_action = fx.get_exploration_action
+
+    def _wrap(name):
+        inner = getattr(trainer, name, None)
+        if inner is None:
+            return
+
+        def wrapped(*a, **k):
+            out = inner(*a, **k)
+            fx.refresh()
+            return out
+        setattr(trainer, name, wrapped)
+    _wrap('optimize')
+    _wrap('load_models')
+    return fx
 
 
 class UniformRandomPolicy(object):

@@ -459,3 +459,48 @@ def test_collect_one_launch_fills_the_ring_like_the_step_loop():
     for a, b in zip(res[0][:8], res[1][:8]):
         assert torch.equal(a, b)
     assert abs(res[0][8] - res[1][8]) < 1e-9 * abs(res[0][8])
+
+
+def test_accelerate_trainer_patches_get_exploration_action():
+    """accelerate_trainer(): the reference Trainer's get_exploration_action surface (list of N obs arrays ->
+    one-hot ndarray [1,N,5], ddpg_gumbel_fix.py:86-107) served by the one-launch actor; the snapshot follows
+    optimize()."""
+    from multiagent_rl_amd.policy import ActorNetwork, accelerate_trainer
+    torch.manual_seed(0)
+
+    class Trainer(object):                      # the attributes / methods of the reference's Trainer that matter here
+        action_type = 'Discrete'
+
+        def __init__(self):
+            self.actor = ActorNetwork(16, 5).cuda()
+            self.optimized = 0
+
+        def optimize(self):
+            with torch.no_grad():
+                self.actor.dense2.module.bias[:] = torch.tensor([0.0, 0.0, 50.0, 0.0, 0.0])   # "learning": always act 2
+            self.optimized += 1
+            return 0.0, 0.0
+
+    tr = Trainer()
+    accelerate_trainer(tr, seed=5)
+    obs_n = [np.random.RandomState(i).randn(16) for i in range(6)]
+    a = tr.get_exploration_action(obs_n)
+    assert isinstance(a, np.ndarray) and a.shape == (1, 6, 5) and a.dtype == np.float32
+    assert (a.sum(-1) == 1).all() and set(np.unique(a)) == {0.0, 1.0}
+    draws = np.stack([tr.get_exploration_action(obs_n)[0] for _ in range(300)])
+    with torch.no_grad():
+        p = torch.softmax(tr.actor(torch.from_numpy(np.stack(obs_n)[None].astype(np.float32)).cuda()), -1)[0].cpu().numpy()
+    assert np.abs(draws.mean(0) - p).max() < 0.12
+    assert tr.optimize() == (0.0, 0.0) and tr.optimized == 1
+    assert (tr.get_exploration_action(obs_n)[0].argmax(-1) == 2).all()       # the refreshed snapshot is in use
+    # MultiDiscrete: two one-hots, as the reference returns them
+    class Trainer2(object):
+        action_type = 'MultiDiscrete'
+
+        def __init__(self):
+            self.actor = ActorNetwork(21, [5, 10]).cuda()
+    t2 = Trainer2()
+    accelerate_trainer(t2)
+    a2 = t2.get_exploration_action([np.zeros(21), np.ones(21)])
+    assert isinstance(a2, list) and a2[0].shape == (1, 2, 5) and a2[1].shape == (1, 2, 10)
+    assert (a2[0].sum(-1) == 1).all() and (a2[1].sum(-1) == 1).all()
