@@ -247,3 +247,38 @@ def test_act_comm_is_rejected_and_listener_reaches_goal_with_greedy_actions():
         obs, rew, _, info = env.step(act)
         first = rew.mean().item() if first is None else first
     assert rew.mean().item() > -0.05 > first and torch.equal(rew[:, 0], rew[:, 1])
+
+
+# ------------------------------------------------------------------------------------------------ properties (CPU)
+def test_c_oracle_invariants_over_random_states_and_actions():
+    """Size-independent properties over many random worlds: the speaker never moves, the listener's state follows the
+    damped-Euler recurrence of its own action only, state.c is exactly the speaker's action / zeros for the listener,
+    both rewards are -|p_listener - p_goal|^2, float32 stays within 1e-5 of float64 per step."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=25, deadline=None)
+    @given(st.integers(0, 2 ** 31 - 1))
+    def prop(seed):
+        rng = np.random.RandomState(seed)
+        B = 17
+        pos, vel, lm, comm, goal = _rand(rng, B)
+        cfg = co.make_config('simple_speaker_listener', max_episode_len=0)
+        o64, o32 = co.CRefOracle(cfg, B, np.float64), co.CRefOracle(cfg, B, np.float32)
+        for o in (o64, o32):
+            o.set_state(pos, vel, lm, comm, goal)
+        for t in range(5):
+            ai = np.stack([rng.randint(0, 3, B), rng.randint(0, 5, B)], 1)
+            p_before, v_before = o64.pos.copy(), o64.vel.copy()
+            w64, w32 = o64.step(act_idx=ai), o32.step(act_idx=ai)
+            assert np.array_equal(o64.pos[:, 0], p_before[:, 0]) and not o64.vel[:, 0].any()
+            u = np.stack([(ai[:, 1] == 1).astype(float) - (ai[:, 1] == 2), (ai[:, 1] == 3).astype(float) - (ai[:, 1] == 4)], 1) * 5.0
+            v = v_before[:, 1] * 0.75 + u / 1.0 * 0.1
+            np.testing.assert_allclose(o64.vel[:, 1], v, rtol=0, atol=1e-15)
+            np.testing.assert_allclose(o64.pos[:, 1], p_before[:, 1] + v * 0.1, rtol=0, atol=1e-15)
+            assert np.array_equal(o64.comm[:, 0], np.eye(3)[ai[:, 0]]) and not o64.comm[:, 1].any()
+            d = o64.pos[:, 1] - lm.astype(np.float64)[np.arange(B), goal[:, 0]]
+            np.testing.assert_allclose(w64['rew'][:, 0], -(d ** 2).sum(-1), rtol=0, atol=1e-14)
+            assert np.array_equal(w64['rew'][:, 0], w64['rew'][:, 1])
+            np.testing.assert_allclose(w32['obs'], w64['obs'], rtol=0, atol=1e-5)
+            np.testing.assert_allclose(w32['rew'], w64['rew'], rtol=0, atol=2e-5)
+    prop()
