@@ -270,8 +270,8 @@ def main():
                                       seed=12345678)
             ro = BatchedRollout(penv, FusedActor(ActorNetwork(penv.obs_dim, 5).to(dev).eval(), seed=12345678),
                                 ReplayBuffer(1e6, N, penv.obs_dim))
-            # (a) two launches per 100 steps: pw_policy_rollout (policy + sampling + env step resident on the CU)
-            #     + pw_replay_add_rollout (ring append + episode bookkeeping of the chunk)
+            # (a) ONE launch per 100 steps: pw_policy_rollout (policy + sampling + env step resident on the CU, the
+            #     transitions written straight into the device replay ring, episode bookkeeping in the same kernel)
             ro.collect_one_launch(100, chunk=100)
             torch.cuda.synchronize()
             tp = time.perf_counter()
@@ -280,8 +280,8 @@ def main():
             tp = time.perf_counter() - tp
             policy_line = dict(value=B * 1000 / tp, unit='env-steps/s', us_per_step=tp / 1000 * 1e6, steps=1000,
                                policy='FusedActor (reference ActorNetwork: Linear-BiLSTM-Linear, random init) + Gumbel sampling',
-                               loop='100-step chunks: pw_policy_rollout (actor + sampling + env step in one launch) + '
-                                    'pw_replay_add_rollout (device replay append + episode stats)')
+                               loop='100-step chunks, one launch each: pw_policy_rollout (actor + sampling + env step + device '
+                                    'replay append + episode stats)')
             # (b) the per-step form: actor, env step, replay append + bookkeeping = 3 launches per step in a hipGraph
             ro.capture(2)
             ro.collect(50)

@@ -285,18 +285,34 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
                    int32_t N, int32_t in_dim, int32_t relu_out, uint64_t seed, uint64_t step,
                    const int64_t *step_dev /* device, or NULL */, float *H, float *logits, int32_t *act, void *stream);
 
+/* Optional direct sink of pw_policy_rollout: the chunk's transitions go straight into the replay ring (slot
+ * (ring_start + t*B + env) % capacity -- the order of T pw_replay_add calls; next_obs = the PRE-reset observation)
+ * and the episode returns are kept in the same launch (episode_return [B] running returns, finished_sum /
+ * finished_count accumulated reproducibly; scratch = pw_policy_rollout_scratch_bytes(h) device bytes, zeroed once).
+ * ring may be NULL (bookkeeping only) and episode_return may be NULL (ring only). */
+typedef struct pw_rollout_sink {
+    const pw_replay_store *ring;
+    int64_t ring_start;
+    float *episode_return;
+    double *finished_sum;
+    int64_t *finished_count;
+    void *scratch;
+} pw_rollout_sink;
+
 /* Policy-in-the-loop rollout as ONE launch: num_steps x (actor forward + Gumbel sampling + environment step +
  * auto-reset) on the handle's bound state, starting from the observation of the current state; observations,
  * sampled actions and world state stay on the CU between steps.  io: the pw_rollout outputs ([num_steps, ...];
- * obs, rew, rew_shared, done, terminal required, final_obs optional; no action inputs, no coll); act_out
- * [num_steps,B,N] int32 receives the sampled indices; the Gumbel noise of step t is keyed (seed; step + t, row)
- * exactly as pw_actor_fused / pw_actor_head, so the results equal a loop of pw_actor_fused + pw_step.
+ * no action inputs, no coll); act_out [num_steps,B,N] int32 receives the sampled indices.  Without a ring sink
+ * act_out and obs, rew, rew_shared, done, terminal are required (final_obs optional); with one every output is
+ * optional.  The Gumbel noise of step t is keyed (seed; step + t, row) exactly as pw_actor_fused / pw_actor_head, so
+ * the results equal a loop of pw_actor_fused + pw_step (+ pw_replay_add_tail).
  * simple_spread fast-path configurations (local observation, homogeneous agents, L <= N), one 5-logit head;
  * weights as for pw_actor_fused. */
 int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
                       const float *w_hh_bw, const float *w2, const float *b2, int32_t relu_out, uint64_t seed,
                       uint64_t step, const int64_t *step_dev /* device, or NULL */, const pw_step_io *io,
-                      int32_t *act_out, int32_t num_steps, void *stream);
+                      int32_t *act_out, int32_t num_steps, const pw_rollout_sink *sink /* or NULL */, void *stream);
+size_t pw_policy_rollout_scratch_bytes(const pw_handle *h);
 
 /* Test hook: y[i] = f(x[i]) with the DEVICE implementation of one math primitive, so its bits can be compared
  * with a CPU implementation of pworld_math.h.  fn: 0 the kernels' fast correctly-rounded sqrt, 1 their

@@ -47,6 +47,11 @@ class PwStepIO(C.Structure):
                 ('act_idx', 'act_vec', 'obs', 'final_obs', 'rew', 'rew_shared', 'done', 'terminal', 'coll', 'act_comm')]
 
 
+class PwRolloutSink(C.Structure):
+    _fields_ = [('ring', C.c_void_p), ('ring_start', C.c_int64), ('episode_return', C.c_void_p),
+                ('finished_sum', C.c_void_p), ('finished_count', C.c_void_p), ('scratch', C.c_void_p)]
+
+
 class PwReplayStore(C.Structure):
     _fields_ = [('obs', C.c_void_p), ('next_obs', C.c_void_p), ('rew', C.c_void_p), ('done', C.c_void_p),
                 ('act', C.c_void_p), ('capacity', C.c_int64), ('num_agents', C.c_int32), ('obs_dim', C.c_int32)]
@@ -90,7 +95,8 @@ SIGNATURES = {
     'pw_actor_fused': (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                                     C.c_uint64, C.c_uint64] + [C.c_void_p] * 5),
     'pw_policy_rollout': (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                       C.c_int32, C.c_void_p]),
+                                                       C.c_int32, C.c_void_p, C.c_void_p]),
+    'pw_policy_rollout_scratch_bytes': (C.c_size_t, [C.c_void_p]),
     'pw_bilstm_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                    C.c_void_p]),
     'pw_actor_head': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p,

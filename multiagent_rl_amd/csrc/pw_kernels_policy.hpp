@@ -357,6 +357,12 @@ struct ActorFusedArgs {
 };
 constexpr int kFusedRows = 96, kGs = 129, kHs = 68;  // kHs: 16-byte aligned rows for the head's float4 reads
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a workgroup-scope fence for GLOBAL
+// memory, i.e. an s_waitcnt vmcnt(0): every wave would sit out the full HBM latency of its outstanding stores at
+// each of the ~8 barriers of a pass.  Inside these kernels waves hand data to each other through LDS alone, and
+// what they store to global memory is only read after the kernel (or behind an explicit __threadfence).
+__device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // LDS of one actor workgroup (carved from dynamic shared memory; kActorLdsFloats(S1) floats in total)
 struct ActorLds {
     float4 *f_wih;  // [4 n][2 m][4 rq][64 lane] float4, one direction
@@ -454,7 +460,7 @@ __device__ __forceinline__ void actor_forward_wg(const ActorFusedArgs &A, const 
         if (tid < OUTc) S.s_b2[tid] = A.b2[tid];
     }
     if (fill0) actor_fill_dir(A, S, 0, tid, 512);
-    if (fill0 || load_const) __syncthreads();
+    if (fill0 || load_const) wg_lds_barrier();
     PW_STAMP(0);
 
     // ---- stage 1
@@ -486,7 +492,7 @@ __device__ __forceinline__ void actor_forward_wg(const ActorFusedArgs &A, const 
     for (int dir = 0; dir < 2; ++dir) {
         if (dir == 1) {
             actor_fill_dir(A, S, 1, tid, 512);
-            __syncthreads();
+            wg_lds_barrier();
         }
         PW_STAMP(2);
         if (front) {
@@ -514,7 +520,7 @@ __device__ __forceinline__ void actor_forward_wg(const ActorFusedArgs &A, const 
             }
         }
         PW_STAMP(3);
-        __syncthreads();
+        wg_lds_barrier();
         PW_STAMP(4);
         {   // recurrence over the agent axis
             LstmUnitW w;
@@ -531,7 +537,7 @@ __device__ __forceinline__ void actor_forward_wg(const ActorFusedArgs &A, const 
             }
         }
         PW_STAMP(5);
-        __syncthreads();  // Gs / weights are overwritten by the next direction; Hs complete after the last
+        wg_lds_barrier();  // Gs / weights are overwritten by the next direction; Hs complete after the last
         PW_STAMP(6);
     }
 
@@ -571,7 +577,7 @@ __device__ __forceinline__ void actor_forward_wg(const ActorFusedArgs &A, const 
         }
     }
     if (sample) {
-        __syncthreads();
+        wg_lds_barrier();
         for (int idx = tid; idx < rows_here * nheads; idx += 512) {
             const int r = idx / nheads, hd = idx - r * nheads;
             const int lo = hd ? A.n_out0 : 0, cnt = hd ? A.n_out1 : A.n_out0;
@@ -617,10 +623,20 @@ struct PolicyRolloutArgs {
     ActorFusedArgs A;   // weights, B, N, D, E, heads, seed, step / step_dev (Philox step of the FIRST pass)
     StreamParams V;     // world constants, state planes, outputs (V.act unused)
     int T;
-    int32_t *act_out;   // [T,B,N] sampled action indices
+    int32_t *act_out;   // [T,B,N] sampled action indices (or NULL)
+    // optional direct sink: the transitions go straight into the replay ring (slot (ring_start + t*B + env) %
+    // capacity, the order of T pw_replay_add calls) and the episode returns are kept here, so no second launch
+    // has to re-read the step outputs (which then may all be NULL)
+    pw_replay_store ring;
+    int has_ring;
+    int64_t ring_start;
+    float *episode_return;          // [B] running return per env (or NULL)
+    double *finished_sum;
+    int64_t *finished_count;
+    unsigned long long *scratch;    // [2 * gridDim.x + 1] words, zero before first use
 };
 
-template <int S1C, int NT>
+template <int S1C, int NT, bool SINK>
 __global__ void __launch_bounds__(512) pw_policy_rollout_kernel(const PolicyRolloutArgs P)
 {
     constexpr int LT = NT;  // NT > 0: N = L = NT at compile time (the environment loops unroll)
@@ -662,7 +678,11 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_kernel(const PolicyRoll
     int ep_step = 0;
     uint32_t ep_count = 0;
     uint64_t coll = 0, near = 0;
+    float ep_ret = 0.f;
+    double fin_sum = 0.0;
+    int fin_cnt = 0;
     if (env_wave) {
+        if (SINK && P.episode_return && live && a == 0) ep_ret = P.episode_return[env];
         px = V.pos_x[g]; py = V.pos_y[g]; vx = V.vel_x[g]; vy = V.vel_y[g];
         ep_step = V.ep_step[env];
         ep_count = V.ep_count[env];
@@ -678,7 +698,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_kernel(const PolicyRoll
     }
     const float k = V.contact_margin, cf = V.contact_force, dt = V.dt, damp = V.damp, mass = V.mass;
     const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
-    __syncthreads();
+    wg_lds_barrier();
 
 #ifdef PW_STAMPS
     unsigned long long mt[4] = {0, 0, 0, 0}, m0 = 0, m1 = 0;
@@ -694,12 +714,22 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_kernel(const PolicyRoll
         actor_forward_wg<S1C>(A, S, s_obs, rows_here, envs_here, row_base, t == 0, t == 0, step0 + (uint64_t)t, nullptr,
                               s_act);
         PW_MSTAMP(0);
-        __syncthreads();
+        wg_lds_barrier();
         PW_MSTAMP(1);
         // ---- environment step (pw_spread_stream_kernel's arithmetic)
         if (env_wave) {
             const size_t tBN = (size_t)t * BN;
             const int ai = s_act[r];
+            size_t slot = 0;
+            if (SINK && P.has_ring) {  // the observation the policy acted on (still in LDS) -> ring.obs
+                slot = (size_t)((P.ring_start + (int64_t)t * A.B + env) % P.ring.capacity);
+                if (live) {
+                    const float2 *src = reinterpret_cast<const float2 *>(s_obs + r * D);
+                    float2 *dst = reinterpret_cast<float2 *>(P.ring.obs + (slot * N + a) * D);
+                    for (int c = 0; c < D / 2; ++c) dst[c] = src[c];
+                    P.ring.act[slot * N + a] = (uint8_t)ai;
+                }
+            }
             float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
             float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
             ux *= V.sens; uy *= V.sens;
@@ -728,12 +758,21 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_kernel(const PolicyRoll
             ep_step += 1;
             const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
             if (live) {
-                P.act_out[tBN + g] = ai;
-                V.rew[tBN + g] = rw;
-                V.done[tBN + g] = 0;
+                if (P.act_out) P.act_out[tBN + g] = ai;
+                if (V.rew) V.rew[tBN + g] = rw;
+                if (V.done) V.done[tBN + g] = 0;
                 if (a == 0) {
-                    V.rew_shared[(size_t)t * A.B + env] = acc;
-                    V.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+                    if (V.rew_shared) V.rew_shared[(size_t)t * A.B + env] = acc;
+                    if (V.terminal) V.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+                }
+                if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
+                    stream_write_obs<LT>(P.ring.next_obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
+                    if (a == 0) { P.ring.rew[slot] = acc; P.ring.done[slot] = 0.0f; }
+                }
+                if (SINK && a == 0 && P.episode_return) {  // run.py:55-65, per env
+                    const float rsum = ep_ret + acc;
+                    if (term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
+                    else ep_ret = rsum;
                 }
             }
             if (term && V.auto_reset) {  // same for every lane of an env
@@ -754,7 +793,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_kernel(const PolicyRoll
             if (V.auto_reset && __any(term))
                 stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
             if (live) {
-                stream_write_obs<LT>(V.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+                if (V.obs) stream_write_obs<LT>(V.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
                 stream_write_obs<LT>(s_obs + r * D, L, lmv, px, py, vx, vy);
             }
         } else if (t + 1 < P.T) {
@@ -763,7 +802,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_kernel(const PolicyRoll
             actor_fill_dir(A, S, 0, tid - n_env_waves * kWave, nw * kWave);
         }
         PW_MSTAMP(2);
-        __syncthreads();
+        wg_lds_barrier();
         PW_MSTAMP(3);
     }
 #ifdef PW_STAMPS
@@ -782,6 +821,39 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_kernel(const PolicyRoll
         if (a == 0) {
             V.ep_step[env] = ep_step;
             V.ep_count[env] = ep_count;
+            if (SINK && P.episode_return) P.episode_return[env] = ep_ret;
+        }
+    }
+    if (SINK && P.episode_return) {
+        // finished-episode statistics: fixed-order sum over this workgroup's envs, the partial into scratch, and the
+        // workgroup that arrives last adds the partials in index order (reproducible; no float atomics)
+        double *s_fs = reinterpret_cast<double *>(s_lmb + A.E * L);  // [16] (+ [16] ints): dynamic LDS, after the landmarks
+        int *s_fc = reinterpret_cast<int *>(s_fs + 16);
+        wg_lds_barrier();
+        if (live && a == 0) { s_fs[el] = fin_sum; s_fc[el] = fin_cnt; }
+        wg_lds_barrier();
+        if (tid == 0) {
+            double ws = 0.0;
+            long long wc = 0;
+            for (int i = 0; i < envs_here; ++i) { ws += s_fs[i]; wc += s_fc[i]; }
+            double *part_sum = reinterpret_cast<double *>(P.scratch);
+            long long *part_cnt = reinterpret_cast<long long *>(P.scratch + gridDim.x);
+            unsigned long long *ticket = P.scratch + 2 * gridDim.x;
+            part_sum[blockIdx.x] = ws;
+            part_cnt[blockIdx.x] = wc;
+            __threadfence();
+            if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1) {
+                __threadfence();
+                double ssum = 0.0;
+                long long scnt = 0;
+                for (unsigned i = 0; i < gridDim.x; ++i) {
+                    ssum += __builtin_nontemporal_load(part_sum + i);
+                    scnt += __builtin_nontemporal_load(part_cnt + i);
+                }
+                *P.finished_sum += ssum;
+                *P.finished_count += scnt;
+                *ticket = 0;
+            }
         }
     }
 }

@@ -712,6 +712,13 @@ int pw_replay_add_rollout(const pw_replay_store *st, int64_t start, int32_t B, i
     return PW_OK;
 }
 
+size_t pw_policy_rollout_scratch_bytes(const pw_handle *h)
+{
+    if (!h) return 0;
+    const int E = 96 / h->kp.N < 16 ? 96 / h->kp.N : 16;
+    return (size_t)(2 * ((h->kp.B + E - 1) / E) + 1) * 8;
+}
+
 size_t pw_replay_add_rollout_scratch_bytes(int32_t B) { return (size_t)(2 * ((B + 255) / 256) + 1) * 8; }
 
 int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b, float *out_obs, float *out_act,
@@ -851,10 +858,10 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
 int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
                       const float *w_hh_bw, const float *w2, const float *b2, int32_t relu_out, uint64_t seed,
                       uint64_t step, const int64_t *step_dev, const pw_step_io *io, int32_t *act_out, int32_t num_steps,
-                      void *stream)
+                      const pw_rollout_sink *sink, void *stream)
 {
     if (int rc = check_ready(h)) return rc;
-    if (!frag || !b1 || !b_ih || !w_hh_fw || !w_hh_bw || !w2 || !b2 || !io || !act_out) return fail(PW_EINVAL, "null argument");
+    if (!frag || !b1 || !b_ih || !w_hh_fw || !w_hh_bw || !w2 || !b2 || !io) return fail(PW_EINVAL, "null argument");
     if (num_steps < 1) return fail(PW_EINVAL, "num_steps must be >= 1");
     const KParams &kp = h->kp;
     if (!h->fast)
@@ -863,11 +870,20 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     if (kp.N > 64 || kp.D > 64) return fail(PW_EINVAL, "N and the observation length must be <= 64");
     if (io->act_idx || io->act_vec || io->act_comm || io->coll)
         return fail(PW_EINVAL, "pw_policy_rollout produces the actions itself (act_out) and has no coll output");
-    if (!io->obs || !io->rew || !io->rew_shared || !io->done || !io->terminal)
-        return fail(PW_EINVAL, "obs, rew, rew_shared, done and terminal outputs are required");
+    const bool have_sink = sink && sink->ring;
+    if (!have_sink && (!act_out || !io->obs || !io->rew || !io->rew_shared || !io->done || !io->terminal))
+        return fail(PW_EINVAL, "without a ring sink, act_out and the obs, rew, rew_shared, done, terminal outputs are required");
+    if (sink) {
+        if (sink->ring && (sink->ring->num_agents != kp.N || sink->ring->obs_dim != kp.D || sink->ring->capacity < 1 ||
+                           sink->ring_start < 0 || (int64_t)num_steps * kp.B > sink->ring->capacity))
+            return fail(PW_EINVAL, "ring sink: shape mismatch or the chunk does not fit the ring");
+        if (sink->episode_return && (!sink->finished_sum || !sink->finished_count || !sink->scratch))
+            return fail(PW_EINVAL, "bookkeeping needs episode_return, finished_sum, finished_count and scratch");
+    }
     if ((reinterpret_cast<uintptr_t>(io->obs) | reinterpret_cast<uintptr_t>(io->final_obs) | reinterpret_cast<uintptr_t>(frag) |
-         reinterpret_cast<uintptr_t>(w_hh_fw) | reinterpret_cast<uintptr_t>(w_hh_bw)) & 15)
-        return fail(PW_EINVAL, "obs, final_obs, frag and w_hh must be 16-byte aligned");
+         reinterpret_cast<uintptr_t>(w_hh_fw) | reinterpret_cast<uintptr_t>(w_hh_bw) |
+         (have_sink ? reinterpret_cast<uintptr_t>(sink->ring->next_obs) | reinterpret_cast<uintptr_t>(sink->ring->obs) : 0)) & 15)
+        return fail(PW_EINVAL, "obs, final_obs, frag, w_hh and the ring planes must be 16-byte aligned");
     PolicyRolloutArgs P;
     std::memset(&P, 0, sizeof(P));
     ActorFusedArgs &a = P.A;
@@ -888,28 +904,35 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     A.obs = io->obs; A.final_obs = io->final_obs; A.rew = io->rew; A.rew_shared = io->rew_shared;
     A.done = io->done; A.terminal = io->terminal;
     P.T = num_steps; P.act_out = act_out;
+    if (have_sink) { P.ring = *sink->ring; P.has_ring = 1; P.ring_start = sink->ring_start; }
+    if (sink && sink->episode_return) {
+        P.episode_return = sink->episode_return; P.finished_sum = sink->finished_sum;
+        P.finished_count = sink->finished_count; P.scratch = static_cast<unsigned long long *>(sink->scratch);
+    }
     const int S1C = (kp.D + 7) / 8, S1 = 4 * S1C;
     const size_t shm = actor_lds_bytes(S1) + (size_t)kFusedRows * kp.D * sizeof(float) + kFusedRows * sizeof(int32_t) +
-                       2 * kWave * sizeof(float2) + (size_t)a.E * kp.L * sizeof(float2);
+                       2 * kWave * sizeof(float2) + (size_t)a.E * kp.L * sizeof(float2) + 16 * (sizeof(double) + sizeof(int));
     if (shm > 160 * 1024) return fail(PW_EINVAL, "observation too long for the one-launch rollout (LDS)");
     const unsigned grid = (unsigned)((kp.B + a.E - 1) / a.E);
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define PW_PR2(C, NT)                                                                                                    \
+#define PW_PR3(C, NT, SK)                                                                                                \
     do {                                                                                                                 \
         static bool attr_set = false;                                                                                    \
         if (!attr_set) {                                                                                                 \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_kernel<C, NT>),            \
+            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_kernel<C, NT, SK>),        \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((pw_policy_rollout_kernel<C, NT>), dim3(grid), dim3(512), shm, st, P);                        \
+        hipLaunchKernelGGL((pw_policy_rollout_kernel<C, NT, SK>), dim3(grid), dim3(512), shm, st, P);                    \
     } while (0)
+#define PW_PR2(C, NT) do { if (sink) PW_PR3(C, NT, true); else PW_PR3(C, NT, false); } while (0)
 #define PW_PR(C) case C: PW_PR2(C, 0); break;
     if (kp.N == 6 && kp.L == 6) PW_PR2(2, 6);        // BASELINE configs[1]: D = 16
     else if (kp.N == 3 && kp.L == 3) PW_PR2(2, 3);   // configs[0]: D = 10
     else switch (S1C) {
         PW_PR(1) PW_PR(2) PW_PR(3) PW_PR(4) PW_PR(5) PW_PR(6) PW_PR(7) PW_PR(8)
     }
+#undef PW_PR3
 #undef PW_PR2
 #undef PW_PR
     PW_HIP_CHECK(hipGetLastError());

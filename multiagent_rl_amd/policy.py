@@ -216,17 +216,25 @@ class FusedActor(object):
         return act
 
     @torch.no_grad()
-    def rollout(self, env, num_steps, out=None):
+    def rollout(self, env, num_steps, out=None, memory=None, stats=None):
         """``num_steps`` x (this actor + Gumbel sampling + ``env`` step with auto-reset) as ONE launch
         (``pw_policy_rollout``): observations, actions and world state stay on the CU between steps.  Continues
         from the env's current state.  -> dict of [T, ...] outputs as ``BatchedParticleEnv.rollout`` plus
-        ``act`` [T,B,N] int32.  Same results as ``num_steps`` iterations of ``act = self(obs); env.step(act)``."""
-        from ._lib import PwStepIO
+        ``act`` [T,B,N] int32.  Same results as ``num_steps`` iterations of ``act = self(obs); env.step(act)``.
+
+        ``memory`` (a device ``ReplayBuffer``): the transitions go straight into the ring from the same launch;
+        ``stats`` = (episode_return [B], finished_sum, finished_count) tensors: the episode bookkeeping too.  With a
+        sink, ``out=False`` skips the step outputs altogether (only the ring / statistics are written)."""
+        from ._lib import PwRolloutSink, PwStepIO
         assert len(self.heads) == 1 and self.heads[0] == 5, 'single 5-logit head only'
         T, B, N = int(num_steps), env.num_envs, env.n
-        out = env.alloc_outputs(T, coll=False) if out is None else out
-        if 'act' not in out:
-            out['act'] = torch.empty(T, B, N, dtype=torch.int32, device=self.device)
+        if out is False:
+            assert memory is not None or stats is not None
+            out = {}
+        else:
+            out = env.alloc_outputs(T, coll=False) if out is None else out
+            if 'act' not in out:
+                out['act'] = torch.empty(T, B, N, dtype=torch.int32, device=self.device)
         io = PwStepIO()
         for name in ('obs', 'final_obs', 'rew', 'rew_shared', 'done', 'terminal'):
             t = out.get(name)
@@ -234,10 +242,31 @@ class FusedActor(object):
                 assert t.is_contiguous() and t.shape[0] == T
                 setattr(io, name, t.data_ptr())
         p = lambda t: None if t is None else self._C.c_void_p(t.data_ptr())  # noqa: E731
+        sink = None
+        if memory is not None or stats is not None:
+            sink = PwRolloutSink()
+            if memory is not None:
+                if memory._store is None:
+                    memory._device = self.device if memory._device is None else memory._device
+                    memory._allocate(N, env.obs_dim)
+                assert T * B <= memory._maxsize
+                sink.ring = self._C.addressof(memory._store)
+                sink.ring_start = memory._next_idx
+            if stats is not None:
+                if getattr(self, '_sink_scratch_key', None) != (B, N):
+                    nbytes = self.lib.pw_policy_rollout_scratch_bytes(env._h)
+                    self._sink_scratch = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+                    self._sink_scratch_key = (B, N)
+                sink.episode_return, sink.finished_sum, sink.finished_count = (t.data_ptr() for t in stats)
+                sink.scratch = self._sink_scratch.data_ptr()
         step_dev = p(self._step_dev) if self.graph_mode else None
         self._lib_mod.check(self.lib.pw_policy_rollout(env._h, p(self.frag), p(self.b1), p(self.bih), p(self.whh_f),
                                                        p(self.whh_r), p(self.w2), p(self.b2), 1, self.seed, self.calls,
-                                                       step_dev, self._C.byref(io), p(out['act']), T, self._stream()))
+                                                       step_dev, self._C.byref(io), p(out.get('act')), T,
+                                                       None if sink is None else self._C.byref(sink), self._stream()))
+        if memory is not None:
+            memory._next_idx = (memory._next_idx + T * B) % memory._maxsize
+            memory._len = min(memory._len + T * B, memory._maxsize)
         if step_dev is not None and not self.defer_step_advance:
             self._lib_mod.check(self.lib.pw_counter_add(p(self._step_dev), T, 0, self._stream()))
         self.calls += T

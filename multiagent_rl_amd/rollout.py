@@ -241,29 +241,27 @@ class BatchedRollout(object):
             self.step()
         return self.env_steps
 
-    def collect_one_launch(self, num_steps, chunk=100):
-        """The same rollout with TWO launches per ``chunk`` steps instead of three per step: ``FusedActor.rollout``
-        (policy + sampling + env step x chunk in one kernel, observations / actions / world state resident on the
-        CU) and ``ReplayBuffer.add_rollout`` (ring append + episode bookkeeping of the chunk).  Both on the current
-        stream: running the append concurrently (high-priority side stream) was measured and is SLOWER -- it takes
-        SIMD slots from a rollout kernel whose workgroups are latency bound (24.4 -> 28.9 us/step).
-        Needs a FusedActor and a simple_spread fast-path env; stores exactly what ``collect`` stores."""
+    def collect_one_launch(self, num_steps, chunk=100, keep_outputs=False):
+        """The same rollout with ONE launch per ``chunk`` steps instead of three per step: ``FusedActor.rollout``
+        runs policy + sampling + env step for the whole chunk with observations / actions / world state resident on
+        the CU, and writes the transitions straight into the replay ring and the episode statistics from the same
+        kernel (``pw_rollout_sink``).  ``keep_outputs=True`` also materialises the chunk's [T, ...] step outputs
+        (``self.last_chunk``).  Needs a FusedActor and a simple_spread fast-path env; stores exactly what ``collect``
+        stores (statistics up to float64 summation order)."""
         assert self._graph is None and hasattr(self.policy, 'rollout')
+        stats = (self.episode_return, self.finished_return_sum, self.finished_episodes)
         done_steps = 0
         while done_steps < num_steps:
             T = min(chunk, num_steps - done_steps)
-            if getattr(self, '_chunk_T', None) != T:
-                self._chunk_T, self._chunk_out = T, None
-            out = self._chunk_out = self.policy.rollout(self.env, T, self._chunk_out)
-            if self.memory is not None:
-                self.memory.add_rollout(self.obs, out, self.episode_return, self.finished_return_sum,
-                                        self.finished_episodes)
+            if keep_outputs:
+                if getattr(self, '_chunk_T', None) != T:
+                    self._chunk_T, self.last_chunk = T, None
+                self.last_chunk = self.policy.rollout(self.env, T, self.last_chunk, memory=self.memory, stats=stats)
             else:
-                for t in range(T):
-                    self._bookkeeping(out['rew_shared'][t], out['terminal'][t])
-            self.obs = out['obs'][T - 1].clone()
+                self.policy.rollout(self.env, T, False, memory=self.memory, stats=stats)
             done_steps += T
             self.env_steps += T * self.env.num_envs
+        self.obs = self.env.observe()
         return self.env_steps
 
     def stats(self):

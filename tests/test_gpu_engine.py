@@ -504,3 +504,37 @@ def test_accelerate_trainer_patches_get_exploration_action():
     a2 = t2.get_exploration_action([np.zeros(21), np.ones(21)])
     assert isinstance(a2, list) and a2[0].shape == (1, 2, 5) and a2[1].shape == (1, 2, 10)
     assert (a2[0].sum(-1) == 1).all() and (a2[1].sum(-1) == 1).all()
+
+
+def test_add_rollout_equals_a_loop_of_add_batch():
+    """ReplayBuffer.add_rollout (a whole chunk of step outputs in one launch, incl. the episode bookkeeping) vs T x
+    add_batch + pw_episode_stats on the same outputs."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import UniformRandomPolicy
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    from multiagent_rl_amd.rollout import BatchedRollout
+    torch.manual_seed(1)
+    B, T = 300, 31
+    env = make_batched_env('simple_spread', B, n=3, auto_reset=True, max_episode_len=25, seed=2)
+    obs0 = env.reset()
+    acts = torch.randint(0, 5, (T, B, 3), device='cuda', dtype=torch.int32)
+    out = env.rollout(acts)
+    out['act'] = acts
+    a, b = ReplayBuffer(B * 40, 3, env.obs_dim), ReplayBuffer(B * 40, 3, env.obs_dim)
+    ro = BatchedRollout(make_batched_env('simple_spread', B, n=3, auto_reset=True), UniformRandomPolicy(), None)
+    prev = obs0
+    for t in range(T):
+        a.add_batch(prev, acts[t], out['rew_shared'][t], out['obs'][t], out['final_obs'][t], out['terminal'][t])
+        ro._bookkeeping(out['rew_shared'][t], out['terminal'][t])
+        prev = out['obs'][t]
+    ret = torch.zeros(B, device='cuda')
+    fs, fc = torch.zeros((), dtype=torch.float64, device='cuda'), torch.zeros((), dtype=torch.int64, device='cuda')
+    b.add_rollout(obs0, out, ret, fs, fc)
+    b.add_rollout(out['obs'][T - 1], {k: v[:1] for k, v in out.items()})        # a second chunk, no bookkeeping
+    a.add_batch(out['obs'][T - 1], acts[0], out['rew_shared'][0], out['obs'][0], out['final_obs'][0], out['terminal'][0])
+    assert a._next_idx == b._next_idx == (T + 1) * B and len(a) == len(b)
+    n = (T + 1) * B
+    for x, y in ((a.obs, b.obs), (a.next_obs, b.next_obs), (a.act, b.act), (a.rew, b.rew), (a.done, b.done)):
+        assert torch.equal(x[:n], y[:n])
+    assert torch.equal(ret, ro.episode_return) and int(fc.item()) == int(ro.finished_episodes.item()) == B
+    assert abs(fs.item() - ro.finished_return_sum.item()) < 1e-9 * abs(fs.item())

@@ -31,9 +31,9 @@ int main(int argc, char **argv)
     hipMalloc((void **)&io.done, T * BN); hipMalloc((void **)&io.terminal, (size_t)T * B);
     pw_reset(h, nullptr, nullptr, nullptr);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) if (pw_policy_rollout(h, frag, b1, bih, whf, whr, w2, b2, 1, 1, 0, nullptr, &io, act, T, nullptr)) { printf("%s\n", pw_last_error()); return 1; }
+    for (int i = 0; i < 2; ++i) if (pw_policy_rollout(h, frag, b1, bih, whf, whr, w2, b2, 1, 1, 0, nullptr, &io, act, T, nullptr, nullptr)) { printf("%s\n", pw_last_error()); return 1; }
     hipEventRecord(e0, 0);
-    for (int i = 0; i < 5; ++i) pw_policy_rollout(h, frag, b1, bih, whf, whr, w2, b2, 1, 1, 100 * i, nullptr, &io, act, T, nullptr);
+    for (int i = 0; i < 5; ++i) pw_policy_rollout(h, frag, b1, bih, whf, whr, w2, b2, 1, 1, 100 * i, nullptr, &io, act, T, nullptr, nullptr);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("B=%d: %.2f us per step (%s)\n", B, ms * 1000.f / (5 * T), pw_last_error());
