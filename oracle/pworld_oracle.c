@@ -1,7 +1,7 @@
 /* CPU ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
- * Plain-C restatement of the batched particle world (simple_spread /
- * simple_tag) in two precisions:
+ * Plain-C restatement of the batched particle world (simple_spread,
+ * simple_tag, simple_reference, simple_speaker_listener) in two precisions:
  *   *_f64  NumPy-float64 semantics of the canonical upstream `multiagent`
  *          package the reference imports (experiments/scenarios.py:2-3) --
  *          libm exp/log1p, i.e. np.logaddexp's stable form.

@@ -125,3 +125,20 @@ def test_header_is_plain_c_and_the_c_host_example_links(tmp_path):
     r = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic', '-I', os.path.join(root, 'include'),
                         '-c', hdr, '-o', str(tmp_path / 'h.o')], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_integration_doc_stub_matches_the_abi_structs():
+    """INTEGRATION.md shows a hand-written ctypes binding: its struct field lists must stay in step with
+    include/pworld.h (as mirrored, and size-checked against the library, by multiagent_rl_amd/_lib.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+    cfg_block = doc[doc.index('class pw_config(C.Structure)'):doc.index('class pw_step_io(C.Structure)')]
+    doc_cfg = re.findall(r"\('(\w+)', C\.", cfg_block)
+    assert doc_cfg == [f[0] for f in _lib.PwConfig._fields_]
+    io_block = doc[doc.index('class pw_step_io(C.Structure)'):doc.index('cfg, h = pw_config()')]
+    doc_io = re.findall(r"'(\w+)'", io_block[io_block.index('for n in'):])
+    assert doc_io == [f[0] for f in _lib.PwStepIO._fields_]
+    # every entry point the doc's table names exists in the header
+    hdr = open(os.path.join(root, 'include', 'pworld.h')).read()
+    for name in set(re.findall(r'`(pw_[a-z_0-9]+)`', doc)):
+        assert re.search(r'\b%s\b' % name, hdr), name
