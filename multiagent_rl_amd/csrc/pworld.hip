@@ -458,10 +458,15 @@ int pw_create(const pw_config *cfg, pw_handle **out)
     kp.A = cfg->scenario == PW_SIMPLE_TAG ? cfg->num_adversaries : 0;
     kp.D = obs_dim_of(*cfg);
     kp.epw = kWave / kp.N;
+    // Envs per wave.  Dense packing (64 / N) is not the fastest for the small N of the BASELINE configs: measured on
+    // MI355X (tools/sweep.py, PWORLD_EPW), 48-lane waves beat 60/63-lane ones at N = 6 (8 vs 10 envs per wave: +3.5 %
+    // at B = 4096, +7 % at 8192, +2-4 % up to 262144; simple_tag 4+2: +10-12 %) and N = 3 (16 vs 21: +14 % at
+    // B = 65536) -- fewer near-pair iterations per wave-step (max over the wave's lanes) and workgroup counts that are
+    // multiples of the 256 CUs -- while N = 9, 12, 24 are faster densely packed.
+    if (kp.N == 6) kp.epw = 8;
+    else if (kp.N == 3) kp.epw = 16;
     // Small batches are latency bound (one wave per SIMD, the chip not even full): spread the envs over about
-    // 512 workgroups (2 waves each in the duo kernels = the 1024 SIMDs) instead of packing 64 / N per wave -- a
-    // wave's near-pair loop runs max-over-its-lanes iterations, so fewer envs per wave shorten every step
-    // (B = 4096, N = 6: 8 instead of 10 envs per wave, +3.5 %).  Large batches keep the dense packing.
+    // 512 workgroups (2 waves each in the duo kernels = the 1024 SIMDs) instead of packing them densely.
     {
         const int spread = (kp.B + 511) / 512;
         if (spread < kp.epw) kp.epw = spread < 1 ? 1 : spread;
