@@ -659,7 +659,10 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_kernel(const PolicyRoll
     const size_t BN = (size_t)A.B * N;
 
     // ---- environment lanes: wave w < n_env_waves owns local envs [w * epw, ...), lane = e_loc * N + a
-    const int epw = A.E < kWave / N ? A.E : kWave / N;
+    // balanced over the fewest waves that can hold E envs: N = 6 -> two waves of 8 envs (not 10 + 6)
+    const int epw_max = A.E < kWave / N ? A.E : kWave / N;
+    const int waves_full = (A.E + epw_max - 1) / epw_max;
+    const int epw = (A.E + waves_full - 1) / waves_full;
     const int n_env_waves = (envs_here + epw - 1) / epw;
     const bool env_wave = wave < n_env_waves;
     int e_loc = lane / N, a = lane - e_loc * N;
