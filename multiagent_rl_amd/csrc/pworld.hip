@@ -278,7 +278,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         if (um) hipLaunchKernelGGL((pw_spread_duo_kernel<n, n, true>), grid, block2, shm2, st, A, T);        \
         else hipLaunchKernelGGL((pw_spread_duo_kernel<n, n, false>), grid, block2, shm2, st, A, T);          \
         break;
-                PW_DUO_CASE(3) PW_DUO_CASE(6) PW_DUO_CASE(9) PW_DUO_CASE(12)
+                PW_DUO_CASE(3) PW_DUO_CASE(6) PW_DUO_CASE(9) PW_DUO_CASE(12) PW_DUO_CASE(24) PW_DUO_CASE(48)
 #undef PW_DUO_CASE
             default:
                 if (um) hipLaunchKernelGGL((pw_spread_duo_kernel<0, 0, true>), grid, block2, shm2, st, A, T);
@@ -293,7 +293,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         if (um) hipLaunchKernelGGL((pw_spread_stream_kernel<n, n, true>), grid, block, shm, st, A, T);       \
         else hipLaunchKernelGGL((pw_spread_stream_kernel<n, n, false>), grid, block, shm, st, A, T);         \
         break;
-            PW_STREAM_CASE(3) PW_STREAM_CASE(6) PW_STREAM_CASE(9) PW_STREAM_CASE(12)
+            PW_STREAM_CASE(3) PW_STREAM_CASE(6) PW_STREAM_CASE(9) PW_STREAM_CASE(12) PW_STREAM_CASE(24) PW_STREAM_CASE(48)
 #undef PW_STREAM_CASE
         default:
             if (um) hipLaunchKernelGGL((pw_spread_stream_kernel<0, 0, true>), grid, block, shm, st, A, T);
