@@ -87,6 +87,22 @@ def c_oracle_rate(B, n_agents, steps=50):
     return B * steps / (time.perf_counter() - t0)
 
 
+def _c_worker(args):
+    B, n_agents = args
+    return c_oracle_rate(B, n_agents, steps=25)
+
+
+def c_oracle_all_cores(B, n_agents):
+    """The plain-C float32 restatement (the strongest CPU form in this repo: batched, compiled, no Python in the
+    loop) on every host core this process may use: what a multi-core CPU port of the same arithmetic delivers."""
+    import multiprocessing as mp
+    n = max(1, min(len(os.sched_getaffinity(0)), 16))
+    with mp.get_context('fork').Pool(n) as pool:
+        rates = pool.map(_c_worker, [(B, n_agents)] * n)
+    return dict(value=float(sum(rates)), unit='env-steps/s', cores=n,
+                sample='%d processes x 25 batched steps of B=%d' % (n, B))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -119,6 +135,7 @@ def main():
         cpu_line = cpu_baseline(args.cpu_seconds, args.agents)
         cpu_line['c_oracle_f32_1core_env_steps_per_s'] = c_oracle_rate(args.envs, args.agents)
         cpu_line['all_cores'] = cpu_baseline_all_cores(min(6.0, args.cpu_seconds), args.agents)
+        cpu_line['c_oracle_f32_all_cores'] = c_oracle_all_cores(args.envs, args.agents)
 
     import torch
     import torch.distributed as dist
