@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the batched particle world on MI355X.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched by
-``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).  Rank 0
-prints ONE JSON line.
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line (rank 0).  For N > 1 the
+driver may start it under ``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL); a
+plain ``python bench.py --gpus N`` starts those N rank processes ITSELF, as fresh children, before this process
+has imported torch or touched a GPU, and exits with their return code.
 
-Workload (BASELINE.json configs[1]): simple_spread, N = 6 agents, L = 6 landmarks, B = 4096 envs per
-GPU, local observation (D = 16), episode length 25 with in-kernel auto-reset, synthetic uniform
-action indices pre-generated on the device, seed 12345678.  A "step" is one batched
-MultiAgentEnv.step of all B envs (state update + obs + reward + done/terminal + auto-reset);
-steps are issued as pw_rollout launches of ``--chunk`` (500) steps each, every step's outputs
-written to their own HBM buffers.  value = n_gpus * B * K / max-over-ranks wall time.
+Workload (BASELINE.json configs[1]): simple_spread, N = 6 agents, L = 6 landmarks, B = 4096 envs per GPU, local
+observation (D = 16), episode length 25 with in-kernel auto-reset, synthetic uniform action indices
+pre-generated on the device, seed 12345678.
 
-N > 1 (weak scaling, B per GPU fixed): envs are sharded by env_id_base; the only exchange is the
-RCCL gather of the replay minibatch rows sampled from each rank's local shard to rank 0 once per
-chunk (DESIGN.md "Multi-GPU").
+ONE BENCH STEP = one pass of the hot path over one batch of synthetic input = ONE ``pw_rollout`` launch over an
+action batch [T, B, N] with T = ``--chunk`` (1000) batched MultiAgentEnv.step's (state update + obs + reward +
+done/terminal + auto-reset for all B envs; every step's outputs written to their own HBM buffers).  EXACTLY K such
+launches are timed (after W untimed ones), so the driver's ``--steps 20 --warmup 5`` times 20 000 batched env
+steps (~20 ms): a steady-state region, not one cold launch.  ``value`` = n_gpus * B * T * K / max-over-ranks wall
+time; ``ms_per_step`` is per launch; ``config`` states T, K and the env-steps per bench step.
 
-Extra objects: ``roofline`` (HIP-event timed pw_rollout launches vs the 8 TB/s HBM peak, algorithmic
-bytes = 678 B per env-step) and ``cpu_baseline`` (the upstream-structured scalar NumPy oracle on one
-host core, bounded sample; rank 0, N = 1 only).
+N > 1 (weak scaling, B per GPU fixed): envs are sharded by env_id_base.  Headline: the only exchange is the RCCL
+gather of replay rows sampled from each rank's chunk (``SampledTransitionGather``); the policy-in-the-loop extra
+measures north_star's collective, the FULL gather of every transition to the root's ring
+(``FullTransitionGather``), and reports bytes per env-step and GB/s per xGMI link.
+
+Extra objects: ``roofline`` (HIP-event timed launches vs the 8 TB/s HBM peak; algorithmic bytes 678 B/env-step;
+counter traffic and the VALU issue share from the committed rocprofv3 summaries) and ``cpu_baseline`` (the
+upstream-structured scalar NumPy oracle on one host core, bounded sample; rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,8 +39,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s copy ceiling)
+STUB = bool(os.environ.get('PW_BENCH_STUB'))  # tests only: gloo + a no-op "kernel" (tests/test_bench_launcher.py)
 
 
+# ------------------------------------------------------------------------------------------------------------
+# CPU baseline legs (rank 0, N = 1 only; run BEFORE this process touches the GPU -- they fork workers)
+# ------------------------------------------------------------------------------------------------------------
 def cpu_baseline(seconds, n_agents):
     """Reference-style CPU step: the scalar NumPy float64 oracle (upstream loop structure) driven
     through the MultiAgentEnv list API exactly as experiments/run.py drives it, 1 core."""
@@ -54,7 +66,8 @@ def cpu_baseline(seconds, n_agents):
             break
     return dict(value=steps / el, unit='env-steps/s', cores=1, kind='port',
                 sample='%d env-steps (%d episodes of 25) of simple_spread N=%d, B=1, scalar NumPy float64 oracle '
-                       'via the MultiAgentEnv list API, %.1f s' % (steps, steps // 25, n_agents, el))
+                       '(restatement of the reference semantics, not the reference\'s code) via the MultiAgentEnv '
+                       'list API, %.1f s' % (steps, steps // 25, n_agents, el))
 
 
 def _cpu_worker(args):
@@ -62,14 +75,19 @@ def _cpu_worker(args):
     return cpu_baseline(seconds, n_agents)['value']
 
 
+def _host_workers():
+    """Worker count for the all-core legs: every core this process may run on, capped at one GPU's share of
+    the box (16).  Both figures are reported (BASELINE.md section 3 asks for os.cpu_count())."""
+    return max(1, min(len(os.sched_getaffinity(0)), 16))
+
+
 def cpu_baseline_all_cores(seconds, n_agents):
-    """the same scalar oracle replicated over every host core (independent envs)."""
+    """the same scalar oracle replicated over the host cores (independent envs)."""
     import multiprocessing as mp
-    # the GPU box reports every host core but grants one GPU's share (16); stay within it
-    n = max(1, min(len(os.sched_getaffinity(0)), 16))
+    n = _host_workers()
     with mp.get_context('fork').Pool(n) as pool:
         rates = pool.map(_cpu_worker, [(seconds, n_agents)] * n)
-    return dict(value=float(sum(rates)), unit='env-steps/s', cores=n,
+    return dict(value=float(sum(rates)), unit='env-steps/s', cores=n, os_cpu_count=os.cpu_count(),
                 sample='%d processes x %.0f s of the same workload' % (n, seconds))
 
 
@@ -93,59 +111,142 @@ def _c_worker(args):
 
 
 def c_oracle_all_cores(B, n_agents):
-    """The plain-C float32 restatement (the strongest CPU form in this repo: batched, compiled, no Python in the
-    loop) on every host core this process may use: what a multi-core CPU port of the same arithmetic delivers."""
+    """The plain-C float32 restatement (batched, compiled, no Python in the loop; it stands in for BASELINE.md's
+    "vectorised NumPy [B,N] oracle" B2 and is stronger than it) on the host cores."""
     import multiprocessing as mp
-    n = max(1, min(len(os.sched_getaffinity(0)), 16))
+    n = _host_workers()
     with mp.get_context('fork').Pool(n) as pool:
         rates = pool.map(_c_worker, [(B, n_agents)] * n)
-    return dict(value=float(sum(rates)), unit='env-steps/s', cores=n,
+    return dict(value=float(sum(rates)), unit='env-steps/s', cores=n, os_cpu_count=os.cpu_count(),
                 sample='%d processes x 25 batched steps of B=%d' % (n, B))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# self-launch of the N rank processes
+# ------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n_ranks, argv):
+    """``python bench.py --gpus N`` from a plain shell: start N fresh rank processes under torch.distributed.run
+    (children of this process, which has not imported torch nor made any GPU call) and return their exit code."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_ranks),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL needs it on this host driver
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# tests only: a rollout "env" that launches nothing (PW_BENCH_STUB=1), so that the launcher, the rank plumbing,
+# both exchanges and the JSON line run on CPU with gloo.  Its line says data = "stub".
+# ------------------------------------------------------------------------------------------------------------
+class _StubEnv(object):
+    def __init__(self, B, N, rank):
+        import torch
+        self.num_envs, self.n, self.num_landmarks, self.obs_dim = B, N, N, 4 + 2 * N
+        self.max_episode_len, self.bytes_per_env_step, self.rank = 25, 57 * N + 8 * N + 8 * N * N, rank
+        self._torch = torch
+
+    def reset(self):
+        return self._torch.zeros(self.num_envs, self.n, self.obs_dim)
+
+    def alloc_outputs(self, T, coll=False):
+        t, B, N, D = self._torch, self.num_envs, self.n, self.obs_dim
+        out = dict(obs=t.zeros(T, B, N, D), final_obs=t.zeros(T, B, N, D), rew=t.zeros(T, B, N),
+                   rew_shared=t.zeros(T, B), done=t.zeros(T, B, N, dtype=t.bool), terminal=t.zeros(T, B, dtype=t.bool))
+        out['terminal'][24::25] = True
+        return out
+
+    def plan_rollout(self, actions, out):
+        def launch():
+            time.sleep(2e-4)
+        return launch
+
+    def stub_policy_chunk(self, out, k):
+        """Stands in for pw_policy_rollout writing a chunk's outputs (recognisable values)."""
+        out['obs'].fill_(float(1000 * self.rank + k))
+        out['rew_shared'].fill_(float(k))
+        out['act'].fill_(k % 5)
+        out['terminal'].zero_()
+        out['terminal'][24::25] = True
+        if out.get('final_obs') is not None:
+            out['final_obs'].fill_(-float(1000 * self.rank + k))
+
+
+def _profile_lookup(scenario, N, B):
+    """Counter-side figures of the dominant kernel from the committed rocprofv3 summaries (profiles/): HBM traffic
+    per ENV-STEP (FETCH_SIZE + WRITE_SIZE passes, per the MI355X guide) and the VALU issue share (SQ counters).
+    PMC counters cannot be read from inside this process; bench scales the per-env-step figure to its launch."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_summary.json')), reverse=True):
+        try:
+            sm = json.load(open(f))
+        except Exception:
+            continue
+        w = sm.get('workload', {})
+        if w.get('scenario') == scenario and w.get('N') == N and w.get('B') == B and 'traffic_bytes_per_env_step' in sm:
+            best = dict(sm, _file=os.path.relpath(f, ROOT))
+            break
+    return best
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20000,
-                    help='timed batched env steps (40 launches of --chunk; ~20 ms, so that the closing barrier of an N-GPU run '
-                         'is a small part of the timed region)')
-    ap.add_argument('--warmup', type=int, default=500)
+    ap.add_argument('--steps', type=int, default=40,
+                    help='timed bench steps = pw_rollout launches of --chunk batched env steps each')
+    ap.add_argument('--warmup', type=int, default=4, help='untimed launches of the same size')
     ap.add_argument('--envs', type=int, default=4096, help='B per GPU')
     ap.add_argument('--agents', type=int, default=6)
-    ap.add_argument('--chunk', type=int, default=500,
-                    help='steps per pw_rollout launch (20 episodes; the per-launch cost, ~9 us of launch gap + tail, is '
-                         '7 %% of a 100-step launch and 1.5 %% of a 500-step one)')
+    ap.add_argument('--chunk', type=int, default=1000,
+                    help='batched env steps per pw_rollout launch (40 episodes; the per-launch cost, ~7 us of launch gap '
+                         '+ tail, is 0.7 %% of a 1000-step launch)')
     ap.add_argument('--scenario', default='simple_spread')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--batch-size', type=int, default=1024, help='replay rows gathered per exchange (N > 1)')
-    ap.add_argument('--exchange-steps', type=int, default=500,
-                    help='batched steps between RCCL exchanges of --batch-size sampled rows.  500 steps = ~0.6 ms: '
-                         '~1700 fresh minibatches/s at the root, an order of magnitude above what one learner '
-                         '(optimize() on 1024 transitions, ddpg_gumbel_fix.py:131) can consume')
+    ap.add_argument('--batch-size', type=int, default=1024, help='replay rows gathered per sampled exchange (N > 1)')
+    ap.add_argument('--policy-steps', type=int, default=1000, help='batched env steps of the policy-in-the-loop extra')
+    ap.add_argument('--policy-chunk', type=int, default=100, help='steps per pw_policy_rollout launch')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
 
     # CPU baseline first, on rank 0 at N = 1 only, BEFORE this process touches the GPU (it forks workers)
     cpu_line = None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.scenario == 'simple_spread':
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.scenario == 'simple_spread' and not STUB:
         cpu_line = cpu_baseline(args.cpu_seconds, args.agents)
         cpu_line['c_oracle_f32_1core_env_steps_per_s'] = c_oracle_rate(args.envs, args.agents)
         cpu_line['all_cores'] = cpu_baseline_all_cores(min(6.0, args.cpu_seconds), args.agents)
         cpu_line['c_oracle_f32_all_cores'] = c_oracle_all_cores(args.envs, args.agents)
+        cpu_line['os_cpu_count'] = os.cpu_count()
 
     import torch
     import torch.distributed as dist
-    from multiagent_rl_amd.env import BatchedParticleEnv
 
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)' %
-                         (args.gpus, args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    if STUB:
+        dev = torch.device('cpu')
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+
+    def sync():
+        if not STUB:
+            torch.cuda.synchronize()
+
     use_dist = world > 1 or bool(os.environ.get('PW_BENCH_FORCE_DIST'))  # the latter: 1-rank RCCL rehearsal
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -153,47 +254,52 @@ def main():
         # RCCL's streams in their own (high-priority) hardware queue: the exchange then overlaps the next rollout
         # launch instead of sitting in front of it in the main stream's queue (profiles/README.md, timeline)
         os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if STUB:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    B, N, K, W, T = args.envs, args.agents, args.steps, args.warmup, max(1, args.chunk)
-    kw = dict(num_agents=N) if args.scenario == 'simple_spread' else dict(num_adversaries=4, num_good=2)
-    env = BatchedParticleEnv(args.scenario, B, max_episode_len=25, auto_reset=True, seed=12345678,
-                             env_id_base=rank * B, **kw)
+    B, N, K, W, T = args.envs, args.agents, max(1, args.steps), max(0, args.warmup), max(2, args.chunk)
+    if STUB:
+        env = _StubEnv(B, N, rank)
+    else:
+        from multiagent_rl_amd.env import BatchedParticleEnv
+        kw = dict(num_agents=N) if args.scenario == 'simple_spread' else dict(num_adversaries=4, num_good=2)
+        env = BatchedParticleEnv(args.scenario, B, max_episode_len=25, auto_reset=True, seed=12345678,
+                                 env_id_base=rank * B, **kw)
     N, D = env.n, env.obs_dim
     gen = torch.Generator(device=dev)
     gen.manual_seed(12345678 + rank)
 
-    def make_chunks(total):
-        return [min(T, total - s) for s in range(0, total, T)]
-
-    RING = 4  # output buffers of 4 launches, reused round-robin (a launch's outputs are consumed -- here: sampled by
-    #           the exchange right after it -- long before 3 more launches have run)
-
-    def alloc(total):
-        rows = min(total, RING * T)
-        acts = torch.randint(0, 5, (rows, B, N), generator=gen, device=dev, dtype=torch.int32)
-        outs = env.alloc_outputs(rows, coll=False)
-        return acts, outs
-
-    def plan(acts, outs, chunks):
-        """pw_step_io structs bound once per ring slot (as a C host would); the timed loop only launches."""
-        plans, cache = [], {}
-        for i, n in enumerate(chunks):
-            s = (i % RING) * T
-            if (s, n) not in cache:
-                view = {k: v[s:s + n] for k, v in outs.items()}
-                cache[(s, n)] = (env.plan_rollout(acts[s:s + n], view), view, acts[s:s + n])
-            plans.append(cache[(s, n)])
-        return plans
+    # Output buffers of RING launches, reused round-robin (a launch's outputs are consumed -- here: sampled by the
+    # exchange right after it -- long before RING - 1 more launches have run).  ~1 GB per 1000-step launch at C2.
+    RING = max(1, min(4, K))
+    acts = torch.randint(0, 5, (RING * T, B, N), generator=gen, device=dev, dtype=torch.int32)
+    outs = env.alloc_outputs(RING * T, coll=False)
+    slots = []
+    for i in range(RING):
+        view = {k: v[i * T:(i + 1) * T] for k, v in outs.items()}
+        a = acts[i * T:(i + 1) * T]
+        slots.append((env.plan_rollout(a, view), view, a))  # pw_step_io bound once per slot, as a C host would
 
     exchange_state = {'error': None}
+    shard = None
+    if use_dist:
+        if STUB:
+            from tests.dist_standins import CpuSampledGather as Gather
+        else:
+            from multiagent_rl_amd.dist import SampledTransitionGather as Gather
+        # one exchange per launch: --batch-size rows in all, drawn afresh from each rank's latest chunk
+        shard = Gather(env, args.batch_size, rank, world, dev, every=1,
+                       **({} if STUB else dict(side_stream=not os.environ.get('PW_BENCH_NO_SIDE_STREAM'))))
 
-    def run(plans, events=None, shard=None):
-        # ONE HIP-event pair brackets all launches of the timed region on the launch stream (a pair per
-        # launch would put two extra packets between dependent kernels and slow what it measures)
+    def run(n_launches, first, events=None):
+        # ONE HIP-event pair brackets all launches of the timed region on the launch stream (a pair per launch
+        # would put two extra packets between dependent kernels and slow what it measures)
         if events is not None:
             events[0].record()
-        for launch, view, a in plans:
+        for i in range(n_launches):
+            launch, view, a = slots[(first + i) % RING]
             launch()
             if shard is not None and exchange_state['error'] is None:
                 try:
@@ -208,36 +314,26 @@ def main():
             except Exception as e:
                 exchange_state['error'] = repr(e)[:200]
 
-    shard = None
-    if use_dist:
-        from multiagent_rl_amd.dist import SampledTransitionGather
-        # one exchange per update_rate (100) env-steps, the learner's cadence (rls/arglist.py:18)
-        shard = SampledTransitionGather(env, args.batch_size, rank, world, dev, every=max(1, args.exchange_steps // T),
-                                        side_stream=not os.environ.get('PW_BENCH_NO_SIDE_STREAM'))
-
     env.reset()
-    if W > 0:
-        wa, wo = alloc(W)
-        wplans = plan(wa, wo, make_chunks(W))
-        run(wplans, shard=shard)
-        if shard is not None:
-            shard.prime(wplans[0][1], wplans[0][2])
-        del wa, wo, wplans
-    acts, outs = alloc(K)
-    chunks = make_chunks(K)
-    plans = plan(acts, outs, chunks)
-    events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    run(W, 0)
+    if shard is not None:
+        try:
+            shard.prime(slots[0][1], slots[0][2])
+        except Exception as e:
+            exchange_state['error'] = repr(e)[:200]
+        shard.exchanges = shard.rows_ingested = 0  # report the timed region's exchanges only (nothing is pending)
+    events = None if STUB else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
-    torch.cuda.synchronize()
+    sync()
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
-    run(plans, events, shard)
-    torch.cuda.synchronize()
+    run(K, W, events)
+    sync()
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
 
     if use_dist:
@@ -245,101 +341,191 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel: pw_rollout_kernel<spread, local>; HIP events on the launch stream
-    # average launch duration = event-bracketed time of all launches / number of launches (includes the
-    # inter-launch gaps, so it is an upper bound of the kernel's own duration; rocprofv3 gives that one)
-    launch_ms = events[0].elapsed_time(events[1]) / len(chunks)
-    steps_per_launch = K / len(chunks)
-    bytes_per_launch = env.bytes_per_env_step * B * steps_per_launch
+    # dominant kernel; HIP events on the launch stream.  Average launch duration = event-bracketed time of the K
+    # launches / K (includes the inter-launch gaps, so it is an upper bound of the kernel's own duration; the
+    # committed rocprofv3 kernel trace gives that one and must agree)
+    launch_ms = (events[0].elapsed_time(events[1]) if events else elapsed * 1e3) / K
+    env_steps_per_launch = B * T
+    bytes_per_launch = float(env.bytes_per_env_step) * env_steps_per_launch
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
 
-    # HBM traffic per launch: PMC counters cannot be collected from inside this process; use the committed
-    # rocprofv3 --pmc summary of this exact workload (profiles/, collected per the MI355X guide) if present.
-    traffic, traffic_src = None, None
-    try:
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_summary.json')), reverse=True):
-            sm = json.load(open(f))
-            cfgw = sm.get('bench', {}).get('config', {}).get('workload', '')
-            if 'traffic_bytes_per_launch' in sm and ('N=%d ' % N) in cfgw and ('B=%d ' % B) in cfgw and \
-                    ('%d steps per pw_rollout' % T) in cfgw and args.scenario in cfgw:
-                traffic, traffic_src = sm['traffic_bytes_per_launch'], os.path.relpath(f, ROOT)
-                break
-    except Exception:
-        pass
+    prof = _profile_lookup(args.scenario, N, B)
+    traffic = frac_by_traffic = None
+    issue = None
+    if prof is not None:
+        traffic = prof['traffic_bytes_per_env_step'] * env_steps_per_launch
+        frac_by_traffic = traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        if 'valu_issue_share' in prof:
+            issue = dict(valu_issue_share=prof['valu_issue_share'], valu_insts_per_wave_step=prof.get('valu_insts_per_wave_step'),
+                         clocks_per_wave_step=prof.get('clocks_per_wave_step'), source=prof.get('sq_source'))
 
-    finite = bool(torch.isfinite(outs['obs']).all().item()) and (K < 25 or bool(outs['terminal'][24].all().item()))
-    steps_per_launch_f = K / len(chunks)
+    # the last timed launch went to slot (W + K - 1) % RING; an env terminates at its 25th, 50th, ... step, and the
+    # W + K launches ran T steps each from a fresh reset: step index s of that launch is global step
+    # (W + K - 1) * T + s
+    last_view = slots[(W + K - 1) % RING][1]
+    s_term = (-((W + K - 1) * T + 1)) % 25
+    finite = bool(torch.isfinite(last_view['obs']).all().item())
+    if s_term < T and not STUB:
+        finite = finite and bool(last_view['terminal'][s_term].all().item())
 
-    # Reported next to the headline ("report policy-in-the-loop separately"): the same env with the
-    # reference's actor architecture in the loop -- policy forward + Gumbel sampling + pw_step + replay append +
-    # episode bookkeeping per step, captured in one hipGraph.  N = 1 only; never part of `value`.
+    # ---- policy in the loop ("report policy-in-the-loop separately"; never part of `value`) ----
     policy_line = None
-    if world == 1 and rank == 0 and args.scenario == 'simple_spread' and not os.environ.get('PW_BENCH_NO_POLICY'):
+    if args.scenario == 'simple_spread' and not os.environ.get('PW_BENCH_NO_POLICY'):
         try:
-            from multiagent_rl_amd.policy import ActorNetwork, FusedActor
-            from multiagent_rl_amd.replay_buffer import ReplayBuffer
-            from multiagent_rl_amd.rollout import BatchedRollout
-            del outs, acts, plans
-            torch.cuda.empty_cache()
-            torch.manual_seed(12345678)
-            penv = BatchedParticleEnv('simple_spread', B, num_agents=N, max_episode_len=25, auto_reset=True,
-                                      seed=12345678)
-            ro = BatchedRollout(penv, FusedActor(ActorNetwork(penv.obs_dim, 5).to(dev).eval(), seed=12345678),
-                                ReplayBuffer(1e6, N, penv.obs_dim))
-            # (a) ONE launch per 100 steps: pw_policy_rollout (policy + sampling + env step resident on the CU, the
-            #     transitions written straight into the device replay ring, episode bookkeeping in the same kernel)
-            ro.collect_one_launch(100, chunk=100)
-            torch.cuda.synchronize()
-            tp = time.perf_counter()
-            ro.collect_one_launch(1000, chunk=100)
-            torch.cuda.synchronize()
-            tp = time.perf_counter() - tp
-            policy_line = dict(value=B * 1000 / tp, unit='env-steps/s', us_per_step=tp / 1000 * 1e6, steps=1000,
-                               policy='FusedActor (reference ActorNetwork: Linear-BiLSTM-Linear, random init) + Gumbel sampling',
-                               loop='100-step chunks, one launch each: pw_policy_rollout (actor + sampling + env step + device '
-                                    'replay append + episode stats)')
-            # (b) the per-step form: actor, env step, replay append + bookkeeping = 3 launches per step in a hipGraph
-            ro.capture(2)
-            ro.collect(50)
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            ro.collect(500)
-            torch.cuda.synchronize()
-            tg = time.perf_counter() - tg
-            policy_line['three_launches_per_step_hipgraph'] = dict(value=B * 500 / tg, us_per_step=tg / 500 * 1e6)
+            del outs, acts, slots, last_view
+            if not STUB:
+                torch.cuda.empty_cache()
+            policy_line = policy_in_loop(args, env if STUB else None, rank, world, dev, use_dist, sync)
         except Exception as e:  # the headline must not depend on this extra
-            policy_line = dict(error=repr(e)[:200])
+            policy_line = dict(error=repr(e)[:300])
 
     if rank == 0:
-        value = world * B * K / elapsed
+        value = world * B * T * K / elapsed
+        if args.scenario == 'simple_spread' and N == 6 and env.num_landmarks == 6:
+            kernel = 'pw_spread_duo_kernel<6,6,true>'
+        else:
+            kernel = 'pw_rollout (%s N=%d)' % (args.scenario, N)
         line = {
             'metric': 'env-steps/sec, simple_spread N=6 x B envs, 1/2/4/8 MI355X',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed * 1e3 / K, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'stub (tests only: no kernel ran)' if STUB else 'synthetic',
             'config': {'workload': '%s N=%d L=%d, B=%d envs per GPU (global %d), local obs D=%d, episode 25 with '
-                                   'auto-reset, uniform int32 action indices, %d steps per pw_rollout launch'
-                                   % (args.scenario, N, env.num_landmarks, B, world * B, D, T),
+                                   'auto-reset, uniform int32 action indices; 1 bench step = 1 pw_rollout launch = %d '
+                                   'batched env steps; %d launches timed after %d warm-up launches'
+                                   % (args.scenario, N, env.num_landmarks, B, world * B, D, T, K, W),
+                       'env_steps_per_step': world * B * T, 'batched_env_steps_per_launch': T,
+                       'batched_env_steps_timed': K * T, 'us_per_batched_env_step': elapsed * 1e6 / (K * T),
                        'global_batch': world * B, 'parallelism': 'env-shard x%d' % world,
                        'exchange': None if shard is None else dict(
-                           kind='RCCL all_gather of %d sampled transition rows per rank every %d steps into the root replay ring'
-                                % (shard.R, shard.every * T), exchanges=shard.exchanges,
-                           rows_ingested_root=shard.rows_ingested, error=exchange_state['error']),
-                       'outputs_finite': finite},
+                           kind='RCCL all_gather of %d freshly sampled transition rows per rank after every launch '
+                                '(%d batched steps) into the root replay ring' % (shard.R, T),
+                           exchanges=shard.exchanges, rows_ingested_root=shard.rows_ingested,
+                           error=exchange_state['error']),
+                       'outputs_finite': finite, 'timed_region_s': elapsed},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'algorithmic_bytes_per_launch': bytes_per_launch,
-                         'kernel': 'pw_spread_duo_kernel<6,6,true>' if (args.scenario == 'simple_spread' and N == 6) else 'pw_rollout', 'launch_ms': launch_ms,
-                         'bytes_per_env_step': env.bytes_per_env_step, 'env_steps_per_launch': B * steps_per_launch},
+                         'frac': achieved / HBM_PEAK_GBPS,
+                         'traffic': traffic, 'frac_by_traffic': frac_by_traffic,
+                         'traffic_source': None if prof is None else
+                         '%s: %.1f B/env-step (FETCH_SIZE + WRITE_SIZE passes of a %s-step launch) x %d env-steps'
+                         % (prof['_file'], prof['traffic_bytes_per_env_step'],
+                            prof.get('workload', {}).get('steps_per_launch'), env_steps_per_launch),
+                         'issue': issue,
+                         'algorithmic_bytes_per_launch': bytes_per_launch, 'kernel': kernel, 'launch_ms': launch_ms,
+                         'bytes_per_env_step': env.bytes_per_env_step, 'env_steps_per_launch': env_steps_per_launch,
+                         'note': 'achieved = 678 B x env-steps per launch / launch_ms (SURVEY 8(d) algorithmic bytes); the '
+                                 'T-step fused launch keeps state in registers, so counter traffic is BELOW that; at '
+                                 'B=4096 the kernel is bound by one wave\'s dependent chain, not by HBM (DESIGN.md 4)'},
         }
         if world == 1:
             line['cpu_baseline'] = cpu_line
-            line['policy_in_loop'] = policy_line
+        line['policy_in_loop'] = policy_line
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
+    """The same env with the reference's actor architecture in the loop: ``pw_policy_rollout`` = policy forward +
+    Gumbel sampling + env step + auto-reset for a whole chunk in ONE launch.
+    N = 1: transitions go straight into the device replay ring from the kernel (``pw_rollout_sink``).
+    N > 1: north_star's collective -- every rank's chunk travels to the root's ring (``FullTransitionGather``)."""
+    import torch
+    import torch.distributed as dist
+    B, N = args.envs, args.agents
+    Tp, steps = max(2, args.policy_chunk), max(args.policy_chunk, args.policy_steps)
+    n_chunks = steps // Tp
+    if stub_env is None:
+        from multiagent_rl_amd.env import BatchedParticleEnv
+        from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+        from multiagent_rl_amd.replay_buffer import ReplayBuffer
+        from multiagent_rl_amd.rollout import BatchedRollout
+        torch.manual_seed(12345678)  # same weights on every rank
+        penv = BatchedParticleEnv('simple_spread', B, num_agents=N, max_episode_len=25, auto_reset=True,
+                                  seed=12345678, env_id_base=rank * B)
+        actor = FusedActor(ActorNetwork(penv.obs_dim, 5).to(dev).eval(), seed=12345678 + rank)
+    else:
+        penv, actor = stub_env, None
+    label = 'FusedActor (reference ActorNetwork: Linear-BiLSTM-Linear, random init) + Gumbel sampling'
+
+    if not use_dist:
+        ro = BatchedRollout(penv, actor, ReplayBuffer(1e6, N, penv.obs_dim))
+        ro.collect_one_launch(Tp, chunk=Tp)
+        sync()
+        tp = time.perf_counter()
+        ro.collect_one_launch(n_chunks * Tp, chunk=Tp)
+        sync()
+        tp = time.perf_counter() - tp
+        line = dict(value=B * n_chunks * Tp / tp, unit='env-steps/s', us_per_step=tp / (n_chunks * Tp) * 1e6,
+                    steps=n_chunks * Tp, policy=label,
+                    loop='%d-step chunks, one launch each: pw_policy_rollout (actor + sampling + env step + device '
+                         'replay append + episode stats)' % Tp)
+        # the per-step form: actor, env step, replay append + bookkeeping = 3 launches per step in a hipGraph
+        ro.capture(2)
+        ro.collect(50)
+        sync()
+        tg = time.perf_counter()
+        ro.collect(500)
+        sync()
+        tg = time.perf_counter() - tg
+        line['three_launches_per_step_hipgraph'] = dict(value=B * 500 / tg, us_per_step=tg / 500 * 1e6)
+        return line
+
+    if stub_env is None:
+        from multiagent_rl_amd.dist import FullTransitionGather as Full
+    else:
+        from tests.dist_standins import CpuFullGather as Full
+    full = Full(penv, Tp, rank, world, dev)
+    err = None
+    obs0 = penv.reset()
+
+    def one_chunk(k, obs0):
+        out = full.outputs()
+        if actor is not None:
+            actor.rollout(penv, Tp, out)
+        else:
+            penv.stub_policy_chunk(out, k)
+            time.sleep(2e-4)
+        full(obs0)
+        return out['obs'][Tp - 1]  # the next chunk's obs0: a view into the block that is now travelling (read-only)
+
+    try:
+        full.prime()
+        obs0 = one_chunk(0, obs0)
+        full.finish()
+        if full.memory is not None and hasattr(full.memory, 'clear'):
+            full.memory.clear()
+        full.rows_ingested = 0
+        sync()
+        dist.barrier()
+        sync()
+        tp = time.perf_counter()
+        for k in range(n_chunks):
+            obs0 = one_chunk(1 + k, obs0)
+        full.finish()
+        sync()
+        dist.barrier()
+        sync()
+        tp = time.perf_counter() - tp
+    except Exception as e:
+        err = repr(e)[:300]
+        tp = float('nan')
+    t = torch.tensor([tp], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tp = float(t.item())
+    total = world * B * n_chunks * Tp
+    per_link = full.lay.total_bytes * n_chunks / tp / 1e9 if tp == tp else None
+    return dict(value=total / tp, unit='env-steps/s', us_per_step=tp / (n_chunks * Tp) * 1e6, steps=n_chunks * Tp,
+                policy=label,
+                loop='%d-step chunks, one pw_policy_rollout launch each per rank, outputs written into the wire block' % Tp,
+                gather=dict(kind='FULL gather: every transition of every rank to the root replay ring '
+                                 '(pw_chunk_wire_finalize -> grouped RCCL send/recv peer->root -> pw_replay_add_wire), '
+                                 'double-buffered, one chunk late',
+                            bytes_per_env_step=full.bytes_per_env_step, bytes_per_chunk_per_rank=full.lay.total_bytes,
+                            GBps_per_link=per_link, GBps_root_ingest=None if per_link is None else per_link * (world - 1),
+                            exchanges=full.exchanges, transitions_ingested_root=full.rows_ingested,
+                            expected_transitions=total, error=err))
 
 
 if __name__ == '__main__':

@@ -233,6 +233,37 @@ int pw_exchange(const pw_replay_store *st, int64_t start, int32_t R_in, const fl
                 int32_t B, int32_t N, int32_t D, const int32_t *sel_t, const int32_t *sel_e, int32_t R_out,
                 float *rows_out, void *stream);
 
+/* ---- full gather of transitions to the learner rank (north_star: "RCCL-over-xGMI gather of transitions into
+ * rls/replay_buffer"; consumer experiments/run.py:20-21,52) ------------------------------------------------------
+ * One WIRE BLOCK per rank per T-step rollout chunk carries EVERY transition of the chunk once: the observation
+ * is sent once per step (next_obs of step t is obs of step t+1), plus the pre-reset observation only for the steps
+ * that ended an episode (run.py:52 stores new_obs_n BEFORE env.reset(), :60).  Planes, 256-B aligned:
+ *   obs0 [B,N,D] f32        observation the policy acted on at step 0
+ *   obs [T,B,N,D] f32       post-step (post-reset) observations -- the rollout kernels write them HERE, no copy
+ *   final_rows [F,B,N,D] f32  pre-reset observation of env e's k-th episode end inside the chunk,
+ *                           F = ceil(T / max_episode_len) (0 when episodes never end)
+ *   rew_shared [T,B] f32    written in place by the rollout as well
+ *   act [T,B,N] u8          action index
+ *   fin_slot [T,B] u8       k where step (t, e) ended an episode, 0xFF elsewhere
+ * = N*D*4 + N + 5 bytes per env-step (C2: 395 B) + (1 + F) observation batches per chunk (C2,
+ * T = 100: 414 B/env-step in all).
+ * The collective itself is RCCL, driven by the host: direct peer -> root sends, one block per peer per chunk. */
+typedef struct pw_chunk_wire {
+    int32_t T, B, N, D, F, reserved;
+    size_t obs0, obs, final_rows, rew_shared, act, fin_slot; /* byte offsets into the block */
+    size_t total_bytes;
+} pw_chunk_wire;
+int pw_chunk_wire_layout(int32_t T, int32_t B, int32_t N, int32_t D, int32_t max_episode_len, pw_chunk_wire *out);
+/* Sender, after the chunk's rollout wrote obs / rew_shared into the block: fills obs0, final_rows, act, fin_slot
+ * from obs0 [B,N,D], the rollout's dense final_obs [T,B,N,D] (may be NULL when F = 0), terminal [T,B] and
+ * act [T,B,N] int32.  One launch. */
+int pw_chunk_wire_finalize(const pw_chunk_wire *w, void *wire, const float *obs0, const float *final_obs,
+                           const uint8_t *terminal, const int32_t *act, void *stream);
+/* Root: ReplayBuffer.add() of the block's T*B transitions; transition (t, e) goes to ring slot
+ * (start + t*B + e) % capacity -- the order T pw_replay_add calls would have used -- bit-identical to
+ * pw_replay_add_rollout on the sender's buffers.  One launch. */
+int pw_replay_add_wire(const pw_replay_store *st, int64_t start, const pw_chunk_wire *w, const void *wire, void *stream);
+
 /* Episode bookkeeping of the rollout loop (experiments/run.py:55-65) over B envs in one launch:
  * episode_return[b] += rew_shared[b]; where terminal[b]: *finished_sum += return (double),
  * *finished_count += 1, return cleared.  Deterministic (single workgroup, fixed-order reduction). */

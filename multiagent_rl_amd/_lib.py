@@ -57,6 +57,11 @@ class PwReplayStore(C.Structure):
                 ('act', C.c_void_p), ('capacity', C.c_int64), ('num_agents', C.c_int32), ('obs_dim', C.c_int32)]
 
 
+class PwChunkWire(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('T', 'B', 'N', 'D', 'F', 'reserved')] + \
+               [(n, C.c_size_t) for n in ('obs0', 'obs', 'final_rows', 'rew_shared', 'act', 'fin_slot', 'total_bytes')]
+
+
 # name -> (restype, argtypes): every symbol include/pworld.h declares
 SIGNATURES = {
     'pw_version': (C.c_int, []),
@@ -87,6 +92,9 @@ SIGNATURES = {
     'pw_replay_add_packed': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     'pw_exchange': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.c_int32, C.c_void_p, C.POINTER(PwStepIO), C.c_int32,
                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'pw_chunk_wire_layout': (C.c_int, [C.c_int32] * 5 + [C.POINTER(PwChunkWire)]),
+    'pw_chunk_wire_finalize': (C.c_int, [C.POINTER(PwChunkWire)] + [C.c_void_p] * 6),
+    'pw_replay_add_wire': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.POINTER(PwChunkWire), C.c_void_p, C.c_void_p]),
     'pw_dense': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                           C.c_void_p]),
     'pw_actor_front_pack_floats': (C.c_size_t, [C.c_int32]),

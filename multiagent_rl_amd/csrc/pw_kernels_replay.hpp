@@ -319,3 +319,89 @@ __global__ void pw_exchange_kernel(const pw_replay_store st, const int64_t start
 }
 
 }  // namespace
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Full gather of transitions: the chunk wire block (include/pworld.h, pw_chunk_wire).
+// ------------------------------------------------------------------------------------------
+struct WirePtrs {
+    float *obs0, *obs, *final_rows, *rew_shared;
+    uint8_t *act, *fin_slot;
+};
+__host__ __device__ inline WirePtrs wire_ptrs(const pw_chunk_wire &w, void *wire)
+{
+    unsigned char *b = static_cast<unsigned char *>(wire);
+    WirePtrs p;
+    p.obs0 = reinterpret_cast<float *>(b + w.obs0);
+    p.obs = reinterpret_cast<float *>(b + w.obs);
+    p.final_rows = reinterpret_cast<float *>(b + w.final_rows);
+    p.rew_shared = reinterpret_cast<float *>(b + w.rew_shared);
+    p.act = b + w.act;
+    p.fin_slot = b + w.fin_slot;
+    return p;
+}
+
+// Sender side.  Workgroups [0, row_blocks): thread = (env, observation column), walking the env's T steps in
+// order: the k-th episode end's pre-reset row goes to final_rows[k][env] and column 0 records k in fin_slot.
+// The remaining workgroups narrow the int32 action indices to bytes (grid-stride).
+__global__ void __launch_bounds__(256) pw_chunk_wire_finalize_kernel(const pw_chunk_wire w, void *wire, const float *obs0,
+                                                                     const float *final_obs, const uint8_t *terminal,
+                                                                     const int32_t *act, const unsigned row_blocks)
+{
+    const WirePtrs p = wire_ptrs(w, wire);
+    const int ND = w.N * w.D;
+    const size_t per_step = (size_t)w.B * ND;
+    if (blockIdx.x < row_blocks) {
+        const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= per_step) return;
+        const size_t e = i / ND, c = i - e * ND;
+        p.obs0[i] = obs0[i];
+        int k = 0;
+        for (int t = 0; t < w.T; ++t) {
+            const size_t te = (size_t)t * w.B + e;
+            const bool term = terminal[te] != 0 && final_obs != nullptr && k < w.F;
+            if (term) p.final_rows[(size_t)k * per_step + i] = final_obs[(size_t)t * per_step + i];
+            if (c == 0) p.fin_slot[te] = term ? (uint8_t)k : (uint8_t)0xFF;
+            k += term ? 1 : 0;
+        }
+        return;
+    }
+    const size_t total = (size_t)w.T * w.B * w.N;
+    const unsigned nb = gridDim.x - row_blocks;
+    for (size_t i = (size_t)(blockIdx.x - row_blocks) * blockDim.x + threadIdx.x; i < total; i += (size_t)nb * blockDim.x)
+        p.act[i] = (uint8_t)act[i];
+}
+
+// Root side: the copy half of pw_replay_add_rollout_kernel reading a wire block.  V = floats per thread
+// (4 when N*D is a multiple of 4: 16-byte loads and stores; the planes are 256-B aligned, ring rows 16-B).
+template <int V>
+__global__ void __launch_bounds__(256) pw_replay_add_wire_kernel(const pw_replay_store st, const int64_t start,
+                                                                 const pw_chunk_wire w, const void *wire)
+{
+    typedef float vec_t __attribute__((ext_vector_type(V)));
+    const WirePtrs p = wire_ptrs(w, const_cast<void *>(wire));
+    const int ND = w.N * w.D, N = w.N, NDV = ND / V;
+    const size_t per_step = (size_t)w.B * NDV, total = (size_t)w.T * per_step;
+    const vec_t *obs0 = reinterpret_cast<const vec_t *>(p.obs0), *obs = reinterpret_cast<const vec_t *>(p.obs);
+    const vec_t *fin = reinterpret_cast<const vec_t *>(p.final_rows);
+    vec_t *r_obs = reinterpret_cast<vec_t *>(st.obs), *r_next = reinterpret_cast<vec_t *>(st.next_obs);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / per_step, rem = i - t * per_step, e = rem / NDV, c = rem - e * NDV;
+        const size_t te = t * w.B + e;
+        const size_t slot = (size_t)((start + (int64_t)te) % st.capacity);
+        r_obs[slot * NDV + c] = t == 0 ? obs0[rem] : obs[i - per_step];
+        const unsigned fs = p.fin_slot[te];
+        r_next[slot * NDV + c] = fs != 0xFFu ? fin[(size_t)fs * per_step + rem] : obs[i];
+        for (int q = 0; q < V; ++q) {
+            const size_t cc = c * V + q;
+            if (cc < (size_t)N) st.act[slot * N + cc] = p.act[te * N + cc];
+        }
+        if (c == 0) {
+            st.rew[slot] = p.rew_shared[te];
+            st.done[slot] = 0.0f;
+        }
+    }
+}
+
+}  // namespace

@@ -795,6 +795,84 @@ int pw_exchange(const pw_replay_store *st, int64_t start, int32_t R_in, const fl
     return PW_OK;
 }
 
+namespace {
+void fill_wire(int32_t T, int32_t B, int32_t N, int32_t D, int32_t F, pw_chunk_wire *out)
+{
+    std::memset(out, 0, sizeof(*out));
+    out->T = T; out->B = B; out->N = N; out->D = D; out->F = F;
+    const size_t row = (size_t)B * N * D * sizeof(float);
+    size_t off = 0;
+    auto plane = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    out->obs0 = plane(row);
+    out->obs = plane((size_t)T * row);
+    out->final_rows = plane((size_t)F * row);
+    out->rew_shared = plane((size_t)T * B * sizeof(float));
+    out->act = plane((size_t)T * B * N);
+    out->fin_slot = plane((size_t)T * B);
+    out->total_bytes = off;
+}
+
+int check_wire(const pw_chunk_wire *w, const void *wire)
+{
+    if (!w || !wire) return fail(PW_EINVAL, "null argument");
+    if (w->T < 1 || w->B < 1 || w->N < 1 || w->D < 1 || w->F < 0 || w->F > 254) return fail(PW_EINVAL, "bad wire layout");
+    pw_chunk_wire ref;  // offsets are not trusted blindly: they must be the ones pw_chunk_wire_layout produces
+    fill_wire(w->T, w->B, w->N, w->D, w->F, &ref);
+    if (ref.obs0 != w->obs0 || ref.obs != w->obs || ref.final_rows != w->final_rows || ref.rew_shared != w->rew_shared ||
+        ref.act != w->act || ref.fin_slot != w->fin_slot || ref.total_bytes != w->total_bytes)
+        return fail(PW_EINVAL, "wire layout was not produced by pw_chunk_wire_layout");
+    if (reinterpret_cast<uintptr_t>(wire) & 255) return fail(PW_EINVAL, "wire block must be 256-byte aligned");
+    return PW_OK;
+}
+}  // namespace
+
+int pw_chunk_wire_layout(int32_t T, int32_t B, int32_t N, int32_t D, int32_t max_episode_len, pw_chunk_wire *out)
+{
+    if (!out) return fail(PW_EINVAL, "null argument");
+    if (T < 1 || B < 1 || N < 1 || D < 1 || max_episode_len < 0) return fail(PW_EINVAL, "bad sizes");
+    const int64_t F = max_episode_len > 0 ? ((int64_t)T + max_episode_len - 1) / max_episode_len : 0;
+    if (F > 254) return fail(PW_EINVAL, "more than 254 episode ends per env and chunk: use shorter chunks");
+    fill_wire(T, B, N, D, (int32_t)F, out);
+    return PW_OK;
+}
+
+int pw_chunk_wire_finalize(const pw_chunk_wire *w, void *wire, const float *obs0, const float *final_obs,
+                           const uint8_t *terminal, const int32_t *act, void *stream)
+{
+    if (int rc = check_wire(w, wire)) return rc;
+    if (!obs0 || !terminal || !act) return fail(PW_EINVAL, "null argument");
+    const size_t per_step = (size_t)w->B * w->N * w->D;
+    const unsigned row_blocks = (unsigned)((per_step + 255) / 256);
+    size_t act_blocks = ((size_t)w->T * w->B * w->N + 255) / 256;
+    if (act_blocks > 2048) act_blocks = 2048;
+    hipLaunchKernelGGL(pw_chunk_wire_finalize_kernel, dim3(row_blocks + (unsigned)act_blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *w, wire, obs0, final_obs, terminal, act, row_blocks);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_replay_add_wire(const pw_replay_store *st, int64_t start, const pw_chunk_wire *w, const void *wire, void *stream)
+{
+    if (!st) return fail(PW_EINVAL, "null argument");
+    if (int rc = check_wire(w, wire)) return rc;
+    if (st->num_agents != w->N || st->obs_dim != w->D) return fail(PW_EINVAL, "ring / wire shape mismatch");
+    if (st->capacity < 1 || (int64_t)w->T * w->B > st->capacity || start < 0)
+        return fail(PW_EINVAL, "bad ring arguments (the chunk must fit the ring)");
+    const int ND = w->N * w->D;
+    const bool vec = ND % 4 == 0 && ((reinterpret_cast<uintptr_t>(st->obs) | reinterpret_cast<uintptr_t>(st->next_obs)) & 15) == 0;
+    const size_t total = (size_t)w->T * w->B * (vec ? ND / 4 : ND);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (vec)
+        hipLaunchKernelGGL(pw_replay_add_wire_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           *st, start, *w, wire);
+    else
+        hipLaunchKernelGGL(pw_replay_add_wire_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           *st, start, *w, wire);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
 int pw_bilstm_forward(const float *G, const float *w_hh_fw, const float *w_hh_bw, int32_t B, int32_t N,
                       int32_t relu_out, float *H, void *stream)
 {

@@ -74,7 +74,7 @@ class SampledTransitionGather(object):
         self.calls = 0
         self.exchanges = 0
         self.rows_ingested = 0
-        self._sel = {}
+        self._gen = None
         self._seed = seed
         self.send = [torch.zeros(self.R, self.W, dtype=torch.float32, device=self.device) for _ in range(2)]
         # every rank receives the (small) batch: one all_gather kernel has far less host and launch
@@ -100,14 +100,18 @@ class SampledTransitionGather(object):
         return ReplayBuffer(int(1e6), self.N, self.D, device=self.device)
 
     def _selection(self, T):
-        if T not in self._sel:
-            g = torch.Generator()
-            g.manual_seed(self._seed * 7919 + self.rank)
-            lo = 1 if T > 1 else 0
-            sel_t = torch.randint(lo, max(T, lo + 1), (self.R,), generator=g, dtype=torch.int32)
-            sel_e = torch.randint(0, self.B, (self.R,), generator=g, dtype=torch.int32)
-            self._sel[T] = (sel_t.to(self.device), sel_e.to(self.device))
-        return self._sel[T]
+        """A FRESH uniform draw of R (t, e) cells per exchange (t >= 1: the observation acted on at t is the
+        chunk's obs[t-1]), from a generator on the exchange's device seeded once with (seed, rank) -- no host
+        round trip, and consecutive exchanges ship different episode phases / env indices."""
+        if T < 2:
+            raise ValueError('SampledTransitionGather needs chunks of T >= 2 steps (the observation acted on at '
+                             't = 0 is not part of the chunk)')
+        if self._gen is None:
+            self._gen = torch.Generator(device=self.device)
+            self._gen.manual_seed(self._seed * 7919 + self.rank)
+        sel_t = torch.randint(1, T, (self.R,), generator=self._gen, dtype=torch.int32, device=self.device)
+        sel_e = torch.randint(0, self.B, (self.R,), generator=self._gen, dtype=torch.int32, device=self.device)
+        return sel_t, sel_e
 
     def _pack(self, out, actions, sel_t, sel_e, rows):
         lib = _lib.load()
@@ -161,16 +165,15 @@ class SampledTransitionGather(object):
         if self.calls % self.every:
             return
         T = int(actions.shape[0])
-        sel_t, sel_e = self._selection(T)
         slot = self.exchanges & 1
         if self.side is None:
-            self._exchange(out, actions, sel_t, sel_e, slot)
+            self._exchange(out, actions, *self._selection(T), slot)
         else:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(self.device))  # after this chunk's rollout kernel
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ready)
-                self._exchange(out, actions, sel_t, sel_e, slot)
+                self._exchange(out, actions, *self._selection(T), slot)
         self.exchanges += 1
 
     def _exchange(self, out, actions, sel_t, sel_e, slot):
@@ -225,3 +228,159 @@ class SampledTransitionGather(object):
             with torch.cuda.stream(self.side):
                 self._complete()
             torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
+class FullTransitionGather(object):
+    """north_star's collective: EVERY transition of every rank's rollout chunk lands in the learner rank's replay
+    ring (the reference keeps one buffer that sees every env-step: experiments/run.py:20-21,52).
+
+    Sized for the policy-in-the-loop rollout (``pw_policy_rollout``: ~2e8 env-steps/s per GPU), where a full gather
+    fits xGMI: 395 B per env-step (+ (1 + F)/T observation batches per chunk) is 70-90 GB/s per peer against
+    ~153 GB/s per link; the synthetic-action headline (4e9 env-steps/s per GPU = 1.6 TB/s per peer) keeps
+    ``SampledTransitionGather``.
+
+    Per chunk and rank ONE wire block (``pw_chunk_wire``): the rollout kernel writes ``obs`` / ``rew_shared``
+    straight into the block (``outputs(slot)``: zero-copy), ``pw_chunk_wire_finalize`` (one launch) adds the
+    observation acted on at step 0, the pre-reset rows of the steps that ended an episode, the byte-wide actions and
+    the episode-end map; the blocks travel as direct peer -> root sends (grouped isend/irecv = RCCL send/recv in one
+    group: all seven inbound xGMI links of the root at once, not a ring), double-buffered, completed one chunk late
+    so the transfer overlaps the next chunk's rollout; the root appends block after block IN RANK ORDER with
+    ``pw_replay_add_wire`` (one launch per block): exchange x, rank r, step t, env e -> ring slot
+    ``(x*world + r)*T*B + t*B + e``.
+
+    Usage per chunk:  ``out = g.outputs()``; ``policy.rollout(env, T, out)``; ``g(obs0)``; at the end ``g.finish()``.
+    """
+
+    def __init__(self, env, T, rank, world, device, memory=None, group=None, capacity=int(1e6)):
+        from ._lib import PwChunkWire
+        self.rank, self.world, self.device, self.group = rank, world, torch.device(device), group
+        self.B, self.N, self.D, self.T = env.num_envs, env.n, env.obs_dim, int(T)
+        self.max_episode_len = int(env.cfg.max_episode_len) if hasattr(env, 'cfg') else int(env.max_episode_len)
+        self.lay = self._layout(PwChunkWire)
+        nbytes = self.lay.total_bytes
+        dev = self.device
+        self.wire = [torch.zeros(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.recv = None
+        if rank == 0:
+            self.recv = [[None] + [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(1, world)]
+                         for _ in range(2)]
+        B, N, D = self.B, self.N, self.D
+        # the rollout's outputs that do NOT travel as they are (finalize condenses them into the block)
+        self.side = dict(final_obs=torch.empty(self.T, B, N, D, dtype=torch.float32, device=dev) if self.lay.F else None,
+                         terminal=torch.zeros(self.T, B, dtype=torch.bool, device=dev),
+                         act=torch.zeros(self.T, B, N, dtype=torch.int32, device=dev),
+                         rew=torch.empty(self.T, B, N, dtype=torch.float32, device=dev),
+                         done=torch.zeros(self.T, B, N, dtype=torch.bool, device=dev))
+        self.memory = memory
+        self.capacity = int(capacity)
+        if rank == 0 and self.memory is None:
+            self.memory = self._make_memory()
+        self.exchanges = 0
+        self.rows_ingested = 0
+        self._pending = None
+
+    # -- layout / views
+    def _layout(self, PwChunkWire):
+        lay = PwChunkWire()
+        check(_lib.load().pw_chunk_wire_layout(self.T, self.B, self.N, self.D, self.max_episode_len, C.byref(lay)))
+        return lay
+
+    def _view(self, block, off, shape, dtype):
+        n = 1
+        for x in shape:
+            n *= x
+        itemsize = torch.empty((), dtype=dtype).element_size()
+        return block[off:off + n * itemsize].view(dtype).view(*shape)
+
+    def views(self, block):
+        """Typed views of one wire block (a uint8 tensor of ``lay.total_bytes``)."""
+        lay, T, B, N, D = self.lay, self.T, self.B, self.N, self.D
+        return dict(obs0=self._view(block, lay.obs0, (B, N, D), torch.float32),
+                    obs=self._view(block, lay.obs, (T, B, N, D), torch.float32),
+                    final_rows=self._view(block, lay.final_rows, (max(lay.F, 0), B, N, D), torch.float32),
+                    rew_shared=self._view(block, lay.rew_shared, (T, B), torch.float32),
+                    act=self._view(block, lay.act, (T, B, N), torch.uint8),
+                    fin_slot=self._view(block, lay.fin_slot, (T, B), torch.uint8))
+
+    def outputs(self, slot=None):
+        """The [T, ...] output dict for this chunk's rollout launch (``FusedActor.rollout(env, T, out)`` /
+        ``BatchedParticleEnv.rollout``): obs and rew_shared are views INTO the wire block."""
+        slot = self.exchanges & 1 if slot is None else slot
+        v = self.views(self.wire[slot])
+        out = dict(obs=v['obs'], rew_shared=v['rew_shared'], terminal=self.side['terminal'], act=self.side['act'],
+                   rew=self.side['rew'], done=self.side['done'])
+        if self.side['final_obs'] is not None:
+            out['final_obs'] = self.side['final_obs']
+        return out
+
+    @property
+    def bytes_per_env_step(self):
+        return self.lay.total_bytes / float(self.T * self.B)
+
+    # -- overridable pieces (the CPU gloo test substitutes torch stand-ins for the two HIP launches)
+    def _make_memory(self):
+        from .replay_buffer import ReplayBuffer
+        return ReplayBuffer(self.capacity, self.N, self.D, device=self.device)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _finalize(self, block, obs0):
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        assert obs0.is_contiguous() and obs0.dtype == torch.float32 and tuple(obs0.shape) == (self.B, self.N, self.D)
+        check(_lib.load().pw_chunk_wire_finalize(C.byref(self.lay), p(block), p(obs0), p(self.side['final_obs']),
+                                                 p(self.side['terminal']), p(self.side['act']), self._stream()))
+
+    def _ingest(self, block):
+        m = self.memory
+        check(_lib.load().pw_replay_add_wire(C.byref(m._store), m._next_idx, C.byref(self.lay),
+                                             C.c_void_p(block.data_ptr()), self._stream()))
+        n = self.T * self.B
+        m._next_idx = (m._next_idx + n) % m._maxsize
+        m._len = min(m._len + n, m._maxsize)
+
+    # -- the exchange
+    def _post(self, slot):
+        """Direct peer -> root transfers of this chunk's blocks, asynchronous."""
+        if self.world == 1:
+            return []
+        if self.rank == 0:
+            ops = [dist.P2POp(dist.irecv, self.recv[slot][r], r, group=self.group) for r in range(1, self.world)]
+        else:
+            ops = [dist.P2POp(dist.isend, self.wire[slot], 0, group=self.group)]
+        return dist.batch_isend_irecv(ops)
+
+    def _complete(self):
+        if self._pending is None:
+            return
+        works, slot = self._pending
+        for w in works:
+            if not w.is_completed():
+                w.wait()  # NCCL: orders the current stream after the transfer; does not block the host
+        if self.rank == 0:
+            for r in range(self.world):  # rank order => deterministic ring layout
+                self._ingest(self.wire[slot] if r == 0 else self.recv[slot][r])
+                self.rows_ingested += self.T * self.B
+        self._pending = None
+
+    def __call__(self, obs0):
+        """After the chunk's rollout launch (same stream): condense, complete the PREVIOUS chunk's transfer and
+        append it at the root, then start this chunk's transfer."""
+        slot = self.exchanges & 1
+        self._finalize(self.wire[slot], obs0)
+        self._complete()
+        self._pending = (self._post(slot), slot)
+        self.exchanges += 1
+
+    def prime(self):
+        """One untimed exchange of whatever the blocks hold: RCCL sets up its peer channels lazily (milliseconds)."""
+        ex, ing = self.exchanges, self.rows_ingested
+        self._pending = (self._post(0), 0)
+        works, _ = self._pending
+        for w in works:
+            w.wait()
+        self._pending = None
+        self.exchanges, self.rows_ingested = ex, ing
+
+    def finish(self):
+        self._complete()

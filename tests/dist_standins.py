@@ -1,0 +1,88 @@
+"""Test infrastructure (never imported by the product): torch restatements of the HIP launches of
+multiagent_rl_amd.dist, so that the exchange choreography can run with the gloo backend on CPU tensors
+(tests/test_dist_gloo.py, tests/test_bench_launcher.py via ``PW_BENCH_STUB=1``).  The GPU parity of the real
+launches against these same functions is in tests/test_gpu_engine.py."""
+import torch
+
+from multiagent_rl_amd.dist import FullTransitionGather, SampledTransitionGather
+
+
+class HostRing(object):
+    """Tuple ring in the reference's order (rls/replay_buffer.py:30-37), unbounded: what the root ingested."""
+
+    def __init__(self):
+        self.rows = []          # SampledTransitionGather: packed row blocks
+        self.transitions = []   # FullTransitionGather: dicts of [T*B, ...] tensors, one per ingested block
+
+    def __len__(self):
+        return sum(t['rew'].shape[0] for t in self.transitions) + sum(r.shape[0] for r in self.rows)
+
+    def clear(self):
+        self.rows, self.transitions = [], []
+
+
+def pack_reference(out, actions, sel_t, sel_e):
+    """Row layout of include/pworld.h: [obs ND | next_obs ND | act N | rew | done]."""
+    t, e = sel_t.long(), sel_e.long()
+    obs = out['obs'][t - 1, e].reshape(len(t), -1)
+    nxt = torch.where(out['terminal'][t, e].bool()[:, None, None], out['final_obs'][t, e], out['obs'][t, e])
+    return torch.cat([obs, nxt.reshape(len(t), -1), actions[t, e].float(), out['rew_shared'][t, e][:, None],
+                      torch.zeros(len(t), 1)], dim=1)
+
+
+class CpuSampledGather(SampledTransitionGather):
+    def _make_memory(self):
+        return HostRing()
+
+    def _pack(self, out, actions, sel_t, sel_e, rows):
+        rows.copy_(pack_reference(out, actions, sel_t, sel_e))
+
+    def _ingest(self, rows):
+        self.memory.rows.append(rows.clone())
+
+
+def wire_finalize_reference(g, block, obs0):
+    """pw_chunk_wire_finalize: obs0, the k-th episode end's pre-reset row per env, byte actions, episode-end map."""
+    v = g.views(block)
+    T, B, F = g.T, g.B, g.lay.F
+    v['obs0'].copy_(obs0)
+    term, fin = g.side['terminal'].bool(), g.side['final_obs']
+    k = torch.zeros(B, dtype=torch.long)
+    for t in range(T):
+        m = term[t] & (k < F) if fin is not None else torch.zeros(B, dtype=torch.bool)
+        v['fin_slot'][t] = torch.where(m, k, torch.full_like(k, 255)).to(torch.uint8)
+        e = torch.nonzero(m).flatten()
+        if e.numel():
+            v['final_rows'][k[e], e] = fin[t, e]
+        k = k + m.long()
+    v['act'].copy_(g.side['act'].to(torch.uint8))
+
+
+def wire_transitions_reference(g, block):
+    """pw_replay_add_wire: the block's T*B transitions in (t, e) order as the reference's tuple fields."""
+    v = g.views(block)
+    T, B, N, D = g.T, g.B, g.N, g.D
+    obs = torch.cat([v['obs0'][None], v['obs'][:-1]], 0)
+    fs = v['fin_slot'].long()
+    nxt = v['obs'].clone()
+    t, e = torch.nonzero(fs != 255, as_tuple=True)
+    if t.numel():
+        nxt[t, e] = v['final_rows'][fs[t, e], e]
+    return dict(obs=obs.reshape(T * B, N, D).clone(), next_obs=nxt.reshape(T * B, N, D),
+                act=v['act'].reshape(T * B, N).clone(), rew=v['rew_shared'].reshape(T * B).clone(),
+                done=torch.zeros(T * B))
+
+
+class CpuFullGather(FullTransitionGather):
+    def _layout(self, PwChunkWire):
+        # the layout arithmetic is host code of libpworld (no GPU needed)
+        return super()._layout(PwChunkWire)
+
+    def _make_memory(self):
+        return HostRing()
+
+    def _finalize(self, block, obs0):
+        wire_finalize_reference(self, block, obs0)
+
+    def _ingest(self, block):
+        self.memory.transitions.append(wire_transitions_reference(self, block))

@@ -1,0 +1,82 @@
+"""CPU: ``python bench.py --gpus 2 --steps K --warmup W`` from a plain shell starts its own rank processes
+(torch.distributed.run children of a parent that never imports torch) and rank 0 prints ONE JSON line -- the
+driver's command line, exercised with ``PW_BENCH_STUB=1`` (gloo, a rollout "env" that launches nothing and torch
+stand-ins for the HIP launches of the exchanges; the line says ``data: stub``).  What this covers is the launcher,
+the rank plumbing, both exchanges' choreography inside bench.py and the shape of the line; the kernels are
+covered by the -m gpu tests."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None, timeout=240):
+    env = dict(os.environ, PW_BENCH_STUB='1', PYTHONPATH=ROOT)
+    env.pop('RANK', None)
+    env.pop('WORLD_SIZE', None)
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    return p, lines
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.skipif(torch.cuda.device_count() > 0, reason='CPU-container test (stub kernel, gloo)')
+def test_bench_gpus2_self_launch_prints_one_line():
+    p, lines = _run(['--gpus', '2', '--steps', '20', '--warmup', '5', '--envs', '8', '--agents', '3', '--chunk', '50',
+                     '--batch-size', '8', '--policy-steps', '100', '--policy-chunk', '50'])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 20 and line['warmup'] == 5 and line['scaling'] == 'weak'
+    assert line['data'].startswith('stub')
+    cfg = line['config']
+    assert cfg['batched_env_steps_per_launch'] == 50 and cfg['batched_env_steps_timed'] == 1000
+    assert cfg['env_steps_per_step'] == 2 * 8 * 50 and cfg['global_batch'] == 16
+    assert '50 batched env steps' in cfg['workload'] and '20 launches timed' in cfg['workload']
+    ex = cfg['exchange']
+    assert ex['error'] is None and ex['exchanges'] == 20 and ex['rows_ingested_root'] == 20 * 8
+    assert abs(line['value'] - 2 * 8 * 50 * 20 / cfg['timed_region_s']) < 1e-6 * line['value']
+    assert abs(line['ms_per_step'] - cfg['timed_region_s'] * 1e3 / 20) < 1e-9
+    g = line['policy_in_loop']['gather']
+    assert g['error'] is None and g['transitions_ingested_root'] == g['expected_transitions'] == 2 * 8 * 100
+    assert abs(g['bytes_per_env_step'] - g['bytes_per_chunk_per_rank'] / (50 * 8)) < 1e-9
+    assert 'cpu_baseline' not in line  # N = 1 only
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.skipif(torch.cuda.device_count() > 0, reason='CPU-container test (stub kernel, gloo)')
+def test_bench_under_torchrun_env_does_not_relaunch():
+    """Started by the driver's own torch.distributed.run (RANK set): no second launcher, one rank = one process."""
+    p, lines = _run(['--gpus', '1', '--steps', '3', '--warmup', '1', '--envs', '4', '--agents', '3', '--chunk', '25',
+                     '--policy-steps', '50', '--policy-chunk', '25'],
+                    extra_env=dict(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', PW_BENCH_FORCE_DIST='1',
+                                   MASTER_ADDR='127.0.0.1', MASTER_PORT='29577'))
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 1 and line['config']['exchange']['exchanges'] == 3
+    assert line['policy_in_loop']['gather']['transitions_ingested_root'] == 4 * 50
+
+
+def test_self_launch_command_line():
+    """The child command is torch.distributed.run on 127.0.0.1 with the same arguments; built without torch."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+    real = subprocess.call
+    try:
+        subprocess.call = lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 7
+        rc = bench.self_launch(4, ['--gpus', '4', '--steps', '20', '--warmup', '5'])
+    finally:
+        subprocess.call = real
+    cmd = seen['cmd']
+    assert rc == 7 and cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-6:] == ['--gpus', '4', '--steps', '20', '--warmup', '5'] and cmd[-7].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'

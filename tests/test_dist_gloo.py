@@ -1,7 +1,12 @@
-"""CPU, world_size 2, gloo: the multi-GPU exchange choreography of multiagent_rl_amd.dist
-(double-buffered async gather of sampled transition rows into the root's ring, rank-ordered
-ingest, one-exchange-late completion) and the env-id sharding arithmetic.  The two HIP launches
-(pack / ring append) are replaced by torch stand-ins here; their GPU parity is in test_gpu_engine.py."""
+"""CPU, world_size 2, gloo: the multi-GPU exchange choreography of multiagent_rl_amd.dist and the env-id
+sharding arithmetic.
+  * FullTransitionGather -- north_star's collective: every transition of both ranks lands in the root's ring in
+    rank order with the PRE-reset next observation (experiments/run.py:52 vs :60);
+  * SampledTransitionGather -- the decimated form the synthetic-action headline uses (double-buffered async
+    gather of freshly sampled rows, rank-ordered ingest, one-exchange-late completion);
+  * broadcast_actor -- the learner's weights back to the rollout ranks.
+The HIP launches (pack / finalize / ring append) are replaced by the torch restatements of tests/dist_standins.py
+here; their GPU parity against the same restatements is in test_gpu_engine.py."""
 import os
 import socket
 
@@ -11,38 +16,15 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from multiagent_rl_amd.dist import SampledTransitionGather, broadcast_actor, row_width, shard_env_ids
+from multiagent_rl_amd.dist import broadcast_actor, row_width, shard_env_ids
+from tests.dist_standins import CpuFullGather, CpuSampledGather, pack_reference
 
 B, N, D, T = 8, 3, 10, 5
+EP = 3  # episode length of the full-gather test: chunks of T = 5 steps see 1 or 2 episode ends per env
 
 
 class _Env(object):
-    num_envs, n, obs_dim = B, N, D
-
-
-class _HostRing(object):
-    def __init__(self):
-        self.rows = []
-
-
-class _CpuGather(SampledTransitionGather):
-    def _make_memory(self):
-        return _HostRing()
-
-    def _pack(self, out, actions, sel_t, sel_e, rows):
-        rows.copy_(pack_reference(out, actions, sel_t, sel_e))
-
-    def _ingest(self, rows):
-        self.memory.rows.append(rows.clone())
-
-
-def pack_reference(out, actions, sel_t, sel_e):
-    """Row layout of include/pworld.h: [obs ND | next_obs ND | act N | rew | done]."""
-    t, e = sel_t.long(), sel_e.long()
-    obs = out['obs'][t - 1, e].reshape(len(t), -1)
-    nxt = torch.where(out['terminal'][t, e].bool()[:, None, None], out['final_obs'][t, e], out['obs'][t, e])
-    return torch.cat([obs, nxt.reshape(len(t), -1), actions[t, e].float(), out['rew_shared'][t, e][:, None],
-                      torch.zeros(len(t), 1)], dim=1)
+    num_envs, n, obs_dim, max_episode_len = B, N, D, EP
 
 
 def chunk(rank, k):
@@ -55,17 +37,50 @@ def chunk(rank, k):
     return out, acts
 
 
+def full_chunk(rank, k, step0):
+    """A rollout chunk as the env would produce it: env e's episode clock starts at (e % EP) so that episode ends
+    are NOT in lockstep; terminal every EP steps."""
+    g = torch.Generator()
+    g.manual_seed(77 + 1000 * rank + k)
+    out = dict(obs=torch.randn(T, B, N, D, generator=g), final_obs=torch.randn(T, B, N, D, generator=g),
+               rew_shared=torch.randn(T, B, generator=g),
+               act=torch.randint(0, 5, (T, B, N), generator=g, dtype=torch.int32))
+    t = torch.arange(T)[:, None] + step0
+    e = torch.arange(B)[None, :]
+    out['terminal'] = ((t + e) % EP) == EP - 1
+    return out
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    gat = _CpuGather(_Env(), batch_size=8, rank=rank, world=world, device='cpu', every=2, seed=3)
+
+    # ---- full gather: 3 chunks per rank
+    full = CpuFullGather(_Env(), T, rank, world, 'cpu')
+    assert full.lay.F == 2 and full.lay.total_bytes % 256 == 0
+    obs0 = torch.full((B, N, D), float(rank))
+    for k in range(3):
+        src = full_chunk(rank, k, k * T)
+        out = full.outputs()
+        for name in ('obs', 'rew_shared', 'terminal', 'act', 'final_obs'):
+            out[name].copy_(src[name])          # "the rollout kernel wrote its outputs"
+        full(obs0)
+        obs0 = src['obs'][T - 1].clone()
+    full.finish()
+    dist.barrier()
+
+    # ---- sampled gather
+    gat = CpuSampledGather(_Env(), batch_size=8, rank=rank, world=world, device='cpu', every=2, seed=3)
     assert gat.R == 4 and gat.W == row_width(N, D)
     for k in range(6):
         out, acts = chunk(rank, k)
         gat(out, acts)
     gat.finish()
+    with pytest.raises(ValueError):
+        gat._selection(1)       # a one-step chunk does not hold the observation acted on
     dist.barrier()
-    # learner -> rollout ranks: the actor's parameters as one flat broadcast
+
+    # ---- learner -> rollout ranks: the actor's parameters as one flat broadcast
     from multiagent_rl_amd.policy import ActorNetwork
     torch.manual_seed(100 + rank)                       # every rank starts from different weights
     actor = ActorNetwork(D, 5)
@@ -75,9 +90,10 @@ def _worker(rank, world, port, q):
     same = all(torch.equal(a, b) for a, b in zip(actor.state_dict().values(), want.state_dict().values()))
     assert same and n_moved == sum(p.numel() for p in want.parameters())
     if rank == 0:
-        q.put((gat.exchanges, gat.rows_ingested, [r.numpy() for r in gat.memory.rows]))
+        ring = [{k: v.numpy() for k, v in tr.items()} for tr in full.memory.transitions]
+        q.put((gat.exchanges, gat.rows_ingested, [r.numpy() for r in gat.memory.rows], full.rows_ingested, ring))
     else:
-        q.put((gat.exchanges, gat.rows_ingested, None))
+        q.put((gat.exchanges, gat.rows_ingested, None, full.rows_ingested, None))
     dist.destroy_process_group()
 
 
@@ -89,10 +105,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.timeout(120)
-@pytest.mark.skipif(torch.cuda.device_count() > 0, reason='CPU-container test: it spawns (execs) worker processes, '
-                    'which a process that may have initialised the GPU must not do')
-def test_sampled_transition_gather_world2():
+@pytest.fixture(scope='module')
+def world2():
+    if torch.cuda.device_count() > 0:
+        pytest.skip('CPU-container test: it spawns (execs) worker processes, which a process that may have '
+                    'initialised the GPU must not do')
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -104,24 +121,62 @@ def test_sampled_transition_gather_world2():
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    root = [r for r in res if r[2] is not None][0]
-    exchanges, ingested, rows = root
+    return world, [r for r in res if r[2] is not None][0]
+
+
+@pytest.mark.timeout(120)
+def test_full_transition_gather_world2(world2):
+    """Every transition of both ranks, in (exchange, rank, step, env) order, next_obs = the pre-reset row."""
+    world, root = world2
+    ingested, ring = root[3], root[4]
+    assert ingested == 3 * world * T * B and len(ring) == 3 * world
+    i = 0
+    n_final = 0
+    for k in range(3):
+        for r in range(world):
+            src = full_chunk(r, k, k * T)
+            obs0 = torch.full((B, N, D), float(r)) if k == 0 else full_chunk(r, k - 1, (k - 1) * T)['obs'][T - 1]
+            want_obs = torch.cat([obs0[None], src['obs'][:-1]], 0).reshape(T * B, N, D)
+            want_next = torch.where(src['terminal'][:, :, None, None], src['final_obs'], src['obs']).reshape(T * B, N, D)
+            got = ring[i]
+            np.testing.assert_array_equal(got['obs'], want_obs.numpy())
+            np.testing.assert_array_equal(got['next_obs'], want_next.numpy())
+            np.testing.assert_array_equal(got['act'], src['act'].reshape(T * B, N).numpy().astype(np.uint8))
+            np.testing.assert_array_equal(got['rew'], src['rew_shared'].reshape(T * B).numpy())
+            assert not got['done'].any()
+            n_final += int(src['terminal'].sum())
+            i += 1
+    assert n_final > 0 and n_final < 3 * world * T * B  # both kinds of rows were exercised
+
+
+@pytest.mark.timeout(120)
+def test_sampled_transition_gather_world2(world2):
+    world, root = world2
+    exchanges, ingested, rows = root[:3]
     assert exchanges == 3 and ingested == 3 * world * 4 and len(rows) == 3
     rows = [part for r in rows for part in np.split(r, world)]
-    # expected: exchange x happens on chunks 1, 3, 5 (every=2); rank order inside an exchange
-    want = []
+    # expected: exchange x happens on chunks 1, 3, 5 (every=2); rank order inside an exchange; every exchange
+    # draws a FRESH selection from the rank's generator (consecutive draws of one seeded stream)
+    gens = []
+    for r in range(world):
+        g = torch.Generator()
+        g.manual_seed(3 * 7919 + r)
+        gens.append(g)
+    want, sels = [], []
     for k in (1, 3, 5):
         for r in range(world):
-            g = torch.Generator()
-            g.manual_seed(3 * 7919 + r)
-            sel_t = torch.randint(1, T, (4,), generator=g, dtype=torch.int32)
-            sel_e = torch.randint(0, B, (4,), generator=g, dtype=torch.int32)
+            sel_t = torch.randint(1, T, (4,), generator=gens[r], dtype=torch.int32)
+            sel_e = torch.randint(0, B, (4,), generator=gens[r], dtype=torch.int32)
+            sels.append((r, sel_t.tolist(), sel_e.tolist()))
             out, acts = chunk(r, k)
             want.append(pack_reference(out, acts, sel_t, sel_e).numpy())
     for got, w in zip(rows, want):
         np.testing.assert_array_equal(got, w)
     # terminal rows take the pre-reset observation
     assert all((w[:, :N * D] != w[:, N * D:2 * N * D]).any() for w in want)
+    # the selection changes from exchange to exchange
+    r0 = [s[1:] for s in sels if s[0] == 0]
+    assert r0[0] != r0[1] and r0[1] != r0[2]
 
 
 def test_shard_env_ids():

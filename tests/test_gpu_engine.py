@@ -65,7 +65,7 @@ def test_add_batch_ring_and_pre_reset_next_obs():
 
 
 def test_pack_transitions_and_packed_ingest():
-    from tests.test_dist_gloo import pack_reference
+    from tests.dist_standins import pack_reference
     from multiagent_rl_amd.dist import SampledTransitionGather
     from multiagent_rl_amd.env import BatchedParticleEnv
     env = BatchedParticleEnv('simple_spread', 64, num_agents=3, max_episode_len=5, auto_reset=True)
@@ -75,7 +75,7 @@ def test_pack_transitions_and_packed_ingest():
     out = env.rollout(acts)
     gat = SampledTransitionGather.__new__(SampledTransitionGather)   # single process: no process group needed
     gat.rank, gat.world, gat.device, gat.B, gat.N, gat.D = 0, 1, torch.device('cuda', 0), 64, 3, env.obs_dim
-    gat.R, gat._sel, gat._seed = 40, {}, 1
+    gat.R, gat._gen, gat._seed = 40, None, 1
     sel_t, sel_e = gat._selection(T)
     rows = torch.zeros(40, 2 * 3 * env.obs_dim + 3 + 2, device='cuda')
     gat._pack(out, acts, sel_t, sel_e, rows)
@@ -96,7 +96,7 @@ def test_pack_transitions_and_packed_ingest():
 
 def test_fused_exchange_launch_equals_pack_then_ingest():
     """pw_exchange (one launch: append previous rows + pack new rows) == pw_replay_add_packed + pw_pack_transitions."""
-    from tests.test_dist_gloo import pack_reference
+    from tests.dist_standins import pack_reference
     from multiagent_rl_amd.dist import SampledTransitionGather
     from multiagent_rl_amd.env import BatchedParticleEnv
     env = BatchedParticleEnv('simple_spread', 128, num_agents=6, max_episode_len=7, auto_reset=True)
@@ -105,7 +105,7 @@ def test_fused_exchange_launch_equals_pack_then_ingest():
     out = env.rollout(acts)
     g = SampledTransitionGather.__new__(SampledTransitionGather)
     g.rank, g.world, g.device, g.B, g.N, g.D = 0, 1, torch.device('cuda', 0), 128, 6, env.obs_dim
-    g.R, g._sel, g._seed = 96, {}, 5
+    g.R, g._gen, g._seed = 96, None, 5
     g.memory = g._make_memory()
     sel_t, sel_e = g._selection(20)
     W = 2 * 6 * env.obs_dim + 6 + 2
@@ -538,3 +538,93 @@ def test_add_rollout_equals_a_loop_of_add_batch():
         assert torch.equal(x[:n], y[:n])
     assert torch.equal(ret, ro.episode_return) and int(fc.item()) == int(ro.finished_episodes.item()) == B
     assert abs(fs.item() - ro.finished_return_sum.item()) < 1e-9 * abs(fs.item())
+
+
+@pytest.mark.parametrize('B,N,T,ep', [(300, 3, 31, 25), (4096, 6, 100, 25), (77, 6, 26, 7), (50, 5, 12, 0), (64, 2, 9, 1)])
+def test_chunk_wire_finalize_and_add_wire_equal_add_rollout(B, N, T, ep):
+    """The full-gather path on one GPU: the rollout writes obs / rew_shared INTO the wire block, pw_chunk_wire_finalize
+    condenses the rest, pw_replay_add_wire appends the block -- the ring must equal pw_replay_add_rollout on the
+    sender's dense outputs bit for bit (incl. a wrap of the ring end), and the block must equal the torch
+    restatement the gloo test uses (tests/dist_standins.py).  ep = 0: episodes never end (F = 0)."""
+    from tests.dist_standins import wire_finalize_reference, wire_transitions_reference
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.dist import FullTransitionGather
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    torch.manual_seed(3)
+    env = make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=ep, seed=5)
+    D = env.obs_dim
+    cap = T * B * 3 + 17
+    mem = ReplayBuffer(cap, N, D)
+    mem._next_idx = mem._len = cap - 5                        # the first chunk wraps around the ring end
+    full = FullTransitionGather(env, T, 0, 1, torch.device('cuda', 0), memory=mem)
+    assert full.lay.F == (0 if ep == 0 else -(-T // ep))
+    assert abs(full.bytes_per_env_step - full.lay.total_bytes / (T * B)) < 1e-9
+    want = ReplayBuffer(cap, N, D)
+    want._next_idx = want._len = cap - 5
+    for rb in (mem, want):                                    # 17 slots stay unwritten: make them comparable
+        for plane in (rb.obs, rb.next_obs, rb.act, rb.rew, rb.done):
+            plane.zero_()
+    obs0 = env.reset()
+    # desynchronise the episode clocks so that episode ends are not in lockstep
+    if ep > 1:
+        st = env.get_state()
+        env.set_state(st['pos'], st['vel'], st['landmarks'],
+                      ep_step=(torch.arange(B, device='cuda') % ep).int(), ep_count=st['ep_count'])
+    for k in range(3):
+        acts = torch.randint(0, 5, (T, B, N), device='cuda', dtype=torch.int32)
+        out = full.outputs()
+        out['act'].copy_(acts)
+        env.rollout(acts, out={n_: v for n_, v in out.items() if n_ != 'act'})
+        block = full.wire[full.exchanges & 1]
+        dense = {n_: v.clone() for n_, v in out.items()}
+        full(obs0)
+        # the block equals the CPU restatement of finalize
+        cpu = FullTransitionGather.__new__(FullTransitionGather)
+        cpu.__dict__.update(T=T, B=B, N=N, D=D, lay=full.lay,
+                            side={n_: (None if v is None else v.cpu()) for n_, v in full.side.items()})
+        ref_block = block.cpu().clone()
+        for name in ('obs0', 'final_rows', 'act', 'fin_slot'):
+            cpu.views(ref_block)[name].zero_()
+        wire_finalize_reference(cpu, ref_block, obs0.cpu())
+        got_v, ref_v = full.views(block), cpu.views(ref_block)
+        for name in ('obs0', 'act', 'fin_slot'):
+            assert torch.equal(got_v[name].cpu(), ref_v[name]), name
+        fs = ref_v['fin_slot'].long()
+        tt, ee = torch.nonzero(fs != 255, as_tuple=True)
+        if tt.numel():
+            assert torch.equal(got_v['final_rows'].cpu()[fs[tt, ee], ee], ref_v['final_rows'][fs[tt, ee], ee])
+        assert (fs != 255).equal(dense['terminal'].cpu() & (ep > 0))
+        want.add_rollout(obs0, dense)
+        tr = wire_transitions_reference(cpu, block.cpu())
+        assert torch.equal(tr['next_obs'].reshape(T, B, N, D),
+                           torch.where(dense['terminal'][:, :, None, None], dense['final_obs'], dense['obs']).cpu()
+                           if ep > 0 else dense['obs'].cpu())
+        obs0 = dense['obs'][T - 1]
+    full.finish()
+    assert full.rows_ingested == 3 * T * B and mem._next_idx == want._next_idx and len(mem) == len(want) == cap
+    for x, y in ((mem.obs, want.obs), (mem.next_obs, want.next_obs), (mem.act, want.act), (mem.rew, want.rew)):
+        assert torch.equal(x, y)
+    lo, n = (cap - 5) % cap, 3 * T * B
+    idx = [(lo + i) % cap for i in range(0, n, max(1, n // 999))]
+    assert not mem.sample_index(idx)[4].any()
+
+
+def test_wire_functions_reject_foreign_layouts():
+    import ctypes as C
+    from multiagent_rl_amd import _lib
+    lib = _lib.load()
+    lay = _lib.PwChunkWire()
+    assert lib.pw_chunk_wire_layout(10, 8, 3, 10, 25, C.byref(lay)) == 0 and lay.F == 1
+    assert lib.pw_chunk_wire_layout(1000, 8, 3, 10, 2, C.byref(lay)) < 0      # 500 episode ends per env: too many
+    assert lib.pw_chunk_wire_layout(10, 8, 3, 10, 25, C.byref(lay)) == 0
+    block = torch.zeros(lay.total_bytes, dtype=torch.uint8, device='cuda')
+    bad = _lib.PwChunkWire.from_buffer_copy(lay)
+    bad.obs = lay.obs + 256
+    z = torch.zeros(8 * 3 * 10, device='cuda')
+    term, act = torch.zeros(10, 8, dtype=torch.uint8, device='cuda'), torch.zeros(10, 8, 3, dtype=torch.int32, device='cuda')
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    assert lib.pw_chunk_wire_finalize(C.byref(bad), p(block), p(z), None, p(term), p(act), None) < 0
+    assert b'pw_chunk_wire_layout' in lib.pw_last_error()
+    assert lib.pw_chunk_wire_finalize(C.byref(lay), C.c_void_p(block.data_ptr() + 4), p(z), None, p(term), p(act), None) < 0
+    assert lib.pw_chunk_wire_finalize(C.byref(lay), p(block), p(z), None, p(term), p(act), None) == 0
+    torch.cuda.synchronize()
