@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define PW_VERSION 100 /* 0.1.0 */
+#define PW_VERSION 101 /* 0.1.1: pw_replay_store grew act_heads / per_agent / head_width; wire-block entry points */
 #define PW_MAX_AGENTS 64
 #define PW_MAX_LANDMARKS 64
 
@@ -175,16 +175,26 @@ size_t pw_algorithmic_bytes_per_env_step(const pw_handle *h);
 
 /* ---- device replay ring (rls/replay_buffer.py:9-91 ReplayBuffer) -----------------
  * Storage is caller-owned SoA: obs/next_obs [cap,N,D] f32, act [cap,N] u8 index,
- * rew [cap] f32 (shared reward), done [cap] f32. */
+ * rew [cap] f32 (shared reward), done [cap] f32.
+ * Variants (zero = the plain ring above, so a memset struct keeps its old meaning):
+ *   act_heads = 2: act is [cap,N,2] u8 = (movement, communication symbol) -- the MultiDiscrete action of
+ *     experiments/run.py:39-41; head_width = {5, dim_c} sizes the one-hot rows pw_replay_gather returns
+ *     (head_width[0] = 0 means 5);
+ *   per_agent = 1: rew and done are [cap,N] f32 -- the BiCNet tuple of experiments/run_BIC.py:46,50.
+ * pw_replay_add and pw_replay_gather serve every variant; the chunk / tail / packed / wire entry points and the
+ * pw_policy_rollout sink take the plain ring only (PW_EINVAL otherwise). */
 typedef struct pw_replay_store {
     float *obs, *next_obs, *rew, *done;
     uint8_t *act;
     int64_t capacity;
     int32_t num_agents, obs_dim;
+    int32_t act_heads, per_agent;
+    int32_t head_width[2];
 } pw_replay_store;
 
 /* add(): append B transitions at ring positions (start + i) % capacity.
- * next_obs row i comes from final_obs where terminal[i] != 0 (and final_obs != NULL). */
+ * next_obs row i comes from final_obs where terminal[i] != 0 (and final_obs != NULL).
+ * act_idx is [B,N] int32 ([B,N,2] when st->act_heads = 2); rew_shared / done are [B] ([B,N] when st->per_agent). */
 int pw_replay_add(const pw_replay_store *st, int64_t start, const int64_t *start_dev /* device, or NULL */,
                   int32_t B, const float *obs, const int32_t *act_idx, const float *rew_shared,
                   const float *next_obs, const float *final_obs, const uint8_t *terminal,
@@ -195,7 +205,8 @@ int pw_replay_add(const pw_replay_store *st, int64_t start, const int64_t *start
  * *counter = (*counter + delta) % modulo (modulo <= 0: no wrap). */
 int pw_counter_add(int64_t *counter, int64_t delta, int64_t modulo, void *stream);
 /* sample_index() / _encode_sample(): gather rows idx[0..b) into dense batch tensors;
- * out_act is one-hot f32 [b,N,5] exactly as the reference's trainer consumes it. */
+ * out_act is one-hot f32 [b,N,5] exactly as the reference's trainer consumes it ([b,N,head_width[0]+head_width[1]]
+ * for a two-head ring); out_rew / out_done are [b] ([b,N] for a per-agent ring).  (Declared below.) */
 /* pw_replay_add + pw_episode_stats in ONE launch (the last launch of a captured rollout step).  The ring
  * position comes from `start` or, if non-NULL, *start_dev; (position + B) % capacity is written to
  * *next_start_dev (optional; must not alias start_dev: double-buffer the cursor) and *step_counter (optional,

@@ -54,7 +54,8 @@ class PwRolloutSink(C.Structure):
 
 class PwReplayStore(C.Structure):
     _fields_ = [('obs', C.c_void_p), ('next_obs', C.c_void_p), ('rew', C.c_void_p), ('done', C.c_void_p),
-                ('act', C.c_void_p), ('capacity', C.c_int64), ('num_agents', C.c_int32), ('obs_dim', C.c_int32)]
+                ('act', C.c_void_p), ('capacity', C.c_int64), ('num_agents', C.c_int32), ('obs_dim', C.c_int32),
+                ('act_heads', C.c_int32), ('per_agent', C.c_int32), ('head_width', C.c_int32 * 2)]
 
 
 class PwChunkWire(C.Structure):

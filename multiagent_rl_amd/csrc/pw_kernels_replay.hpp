@@ -17,12 +17,17 @@ __global__ void pw_counter_add_kernel(int64_t *counter, const int64_t delta, con
     *counter = v;
 }
 
+// Ring variants (pw_replay_store.act_heads / per_agent): H action indices per agent (MultiDiscrete: movement and
+// communication symbol, experiments/run.py:39-41) and per-agent reward / done planes (the BiCNet tuple,
+// experiments/run_BIC.py:46,50).  H = 1, per_agent = 0 is the plain ring.
+__device__ __forceinline__ int store_heads(const pw_replay_store &st) { return st.act_heads > 1 ? 2 : 1; }
+
 __global__ void pw_replay_add_kernel(const pw_replay_store st, int64_t start, const int64_t *start_dev, const int B,
                                      const float *obs, const int32_t *act_idx, const float *rew_shared,
                                      const float *next_obs, const float *final_obs, const uint8_t *terminal,
                                      const float *done)
 {
-    const int ND = st.num_agents * st.obs_dim, N = st.num_agents;
+    const int ND = st.num_agents * st.obs_dim, N = st.num_agents, NH = N * store_heads(st);
     const size_t total = (size_t)B * ND;
     if (start_dev) start = *start_dev;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -31,8 +36,13 @@ __global__ void pw_replay_add_kernel(const pw_replay_store st, int64_t start, co
         st.obs[slot * ND + c] = obs[i];
         const bool fin = final_obs && terminal && terminal[e];
         st.next_obs[slot * ND + c] = fin ? final_obs[i] : next_obs[i];
-        if (c < (size_t)N) st.act[slot * N + c] = (uint8_t)act_idx[e * N + c];
-        if (c == 0) {
+        if (c < (size_t)NH) st.act[slot * NH + c] = (uint8_t)act_idx[e * NH + c];  // ND >= 2N always (obs_dim >= 2)
+        if (st.per_agent) {
+            if (c < (size_t)N) {
+                st.rew[slot * N + c] = rew_shared[e * N + c];
+                st.done[slot * N + c] = done ? done[e * N + c] : 0.0f;
+            }
+        } else if (c == 0) {
             st.rew[slot] = rew_shared[e];
             st.done[slot] = done ? done[e] : 0.0f;
         }
@@ -209,18 +219,27 @@ __global__ void pw_replay_gather_kernel(const pw_replay_store st, const int64_t 
                                         float *out_obs, float *out_act, float *out_rew, float *out_next_obs,
                                         float *out_done)
 {
-    const int ND = st.num_agents * st.obs_dim, N = st.num_agents;
+    const int ND = st.num_agents * st.obs_dim, N = st.num_agents, H = store_heads(st);
+    const int W0 = st.head_width[0] > 0 ? st.head_width[0] : 5, W1 = H == 2 ? st.head_width[1] : 0, W = W0 + W1;
     const size_t total = (size_t)b * ND;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i / ND, c = i - e * ND;
         const size_t slot = (size_t)idx[e];
         if (out_obs) out_obs[i] = st.obs[slot * ND + c];
         if (out_next_obs) out_next_obs[i] = st.next_obs[slot * ND + c];
-        if (out_act && c < (size_t)N * 5) {  // ND >= 5N always (obs_dim >= 6)
-            const size_t ag = c / 5, kk = c - ag * 5;
-            out_act[e * N * 5 + c] = st.act[slot * N + ag] == kk ? 1.0f : 0.0f;
+        if (c < (size_t)N) {
+            if (out_act) {  // the one-hot rows the reference stored: [head 0 | head 1] per agent (run.py:38-41)
+                const int a0 = st.act[(slot * N + c) * H], a1 = H == 2 ? st.act[(slot * N + c) * H + 1] : -1;
+                float *row = out_act + (e * N + c) * W;
+                for (int k = 0; k < W0; ++k) row[k] = a0 == k ? 1.0f : 0.0f;
+                for (int k = 0; k < W1; ++k) row[W0 + k] = a1 == k ? 1.0f : 0.0f;
+            }
+            if (st.per_agent) {
+                if (out_rew) out_rew[e * N + c] = st.rew[slot * N + c];
+                if (out_done) out_done[e * N + c] = st.done[slot * N + c];
+            }
         }
-        if (c == 0) {
+        if (c == 0 && !st.per_agent) {
             if (out_rew) out_rew[e] = st.rew[slot];
             if (out_done) out_done[e] = st.done[slot];
         }

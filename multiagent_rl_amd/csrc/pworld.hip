@@ -652,13 +652,25 @@ int pw_counter_add(int64_t *counter, int64_t delta, int64_t modulo, void *stream
     return PW_OK;
 }
 
+namespace {
+// The chunk / tail / packed / wire entry points and the rollout sink write the plain ring layout only.
+int plain_ring_only(const pw_replay_store *st, const char *who)
+{
+    if (st && (st->act_heads > 1 || st->per_agent))
+        return fail(PW_EINVAL, std::string(who) + ": two-head / per-agent rings are served by pw_replay_add and pw_replay_gather only");
+    return PW_OK;
+}
+}  // namespace
+
 int pw_replay_add(const pw_replay_store *st, int64_t start, const int64_t *start_dev, int32_t B, const float *obs,
                   const int32_t *act_idx, const float *rew_shared, const float *next_obs, const float *final_obs,
                   const uint8_t *terminal, const float *done, void *stream)
 {
     if (!st || !obs || !act_idx || !rew_shared || !next_obs) return fail(PW_EINVAL, "null argument");
     if (st->capacity < 1 || B < 1 || B > st->capacity || start < 0) return fail(PW_EINVAL, "bad ring arguments");
-    if (st->obs_dim < 5) return fail(PW_EINVAL, "obs_dim must be >= 5");
+    if (st->obs_dim < 2) return fail(PW_EINVAL, "obs_dim must be >= 2");
+    if (st->act_heads < 0 || st->act_heads > 2 || (st->act_heads == 2 && (st->head_width[0] < 0 || st->head_width[1] < 1)))
+        return fail(PW_EINVAL, "bad act_heads / head_width");
     const size_t total = (size_t)B * st->num_agents * st->obs_dim;
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -677,6 +689,7 @@ int pw_replay_add_tail(const pw_replay_store *st, int64_t start, const int64_t *
     if (!st || !obs || !act_idx || !rew_shared || !next_obs || !terminal || !episode_return || !finished_sum ||
         !finished_count)
         return fail(PW_EINVAL, "null argument");
+    if (int rc = plain_ring_only(st, "pw_replay_add_tail")) return rc;
     if (st->capacity < 1 || B < 1 || B > st->capacity || start < 0) return fail(PW_EINVAL, "bad ring arguments");
     if (st->obs_dim < 5) return fail(PW_EINVAL, "obs_dim must be >= 5");
     if (start_dev && next_start_dev == start_dev)
@@ -698,6 +711,7 @@ int pw_replay_add_rollout(const pw_replay_store *st, int64_t start, int32_t B, i
                           int64_t *finished_count, void *scratch, void *stream)
 {
     if (!st || !obs0 || !io || !act || !io->obs || !io->rew_shared || !io->terminal) return fail(PW_EINVAL, "null argument");
+    if (int rc = plain_ring_only(st, "pw_replay_add_rollout")) return rc;
     if (st->capacity < 1 || B < 1 || T < 1 || (int64_t)B * T > st->capacity || start < 0)
         return fail(PW_EINVAL, "bad ring arguments (the chunk must fit the ring)");
     if (st->obs_dim < 5) return fail(PW_EINVAL, "obs_dim must be >= 5");
@@ -731,7 +745,9 @@ int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b, f
 {
     if (!st || !idx) return fail(PW_EINVAL, "null argument");
     if (b < 1) return fail(PW_EINVAL, "batch must be >= 1");
-    if (st->obs_dim < 5) return fail(PW_EINVAL, "obs_dim must be >= 5");
+    if (st->obs_dim < 2) return fail(PW_EINVAL, "obs_dim must be >= 2");
+    if (st->act_heads < 0 || st->act_heads > 2 || (st->act_heads == 2 && (st->head_width[0] < 0 || st->head_width[1] < 1)))
+        return fail(PW_EINVAL, "bad act_heads / head_width");
     const size_t total = (size_t)b * st->num_agents * st->obs_dim;
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -759,6 +775,7 @@ int pw_pack_transitions(const pw_step_io *io, int32_t B, int32_t N, int32_t D, c
 int pw_replay_add_packed(const pw_replay_store *st, int64_t start, int32_t R, const float *rows, void *stream)
 {
     if (!st || !rows) return fail(PW_EINVAL, "null argument");
+    if (int rc = plain_ring_only(st, "pw_replay_add_packed")) return rc;
     if (st->capacity < 1 || R < 1 || R > st->capacity || start < 0) return fail(PW_EINVAL, "bad ring arguments");
     const size_t total = (size_t)R * (2 * (size_t)st->num_agents * st->obs_dim + st->num_agents + 2);
     size_t blocks = (total + 255) / 256;
@@ -775,6 +792,7 @@ int pw_exchange(const pw_replay_store *st, int64_t start, int32_t R_in, const fl
 {
     const bool ingest = st && rows_in && R_in > 0;
     const bool pack = io && rows_out && R_out > 0;
+    if (int rc = plain_ring_only(st, "pw_exchange")) return rc;
     if (!ingest && !pack) return fail(PW_EINVAL, "nothing to do");
     if (ingest && (st->capacity < 1 || R_in > st->capacity || start < 0)) return fail(PW_EINVAL, "bad ring arguments");
     if (pack && (!sel_t || !sel_e || !io->obs || !io->act_idx || !io->rew_shared || B < 1 || N < 1 || D < 1))
@@ -854,6 +872,7 @@ int pw_chunk_wire_finalize(const pw_chunk_wire *w, void *wire, const float *obs0
 int pw_replay_add_wire(const pw_replay_store *st, int64_t start, const pw_chunk_wire *w, const void *wire, void *stream)
 {
     if (!st) return fail(PW_EINVAL, "null argument");
+    if (int rc = plain_ring_only(st, "pw_replay_add_wire")) return rc;
     if (int rc = check_wire(w, wire)) return rc;
     if (st->num_agents != w->N || st->obs_dim != w->D) return fail(PW_EINVAL, "ring / wire shape mismatch");
     if (st->capacity < 1 || (int64_t)w->T * w->B > st->capacity || start < 0)
@@ -957,6 +976,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     if (!have_sink && (!act_out || !io->obs || !io->rew || !io->rew_shared || !io->done || !io->terminal))
         return fail(PW_EINVAL, "without a ring sink, act_out and the obs, rew, rew_shared, done, terminal outputs are required");
     if (sink) {
+        if (int rc = plain_ring_only(sink->ring, "pw_policy_rollout sink")) return rc;
         if (sink->ring && (sink->ring->num_agents != kp.N || sink->ring->obs_dim != kp.D || sink->ring->capacity < 1 ||
                            sink->ring_start < 0 || (int64_t)num_steps * kp.B > sink->ring->capacity))
             return fail(PW_EINVAL, "ring sink: shape mismatch or the chunk does not fit the ring");

@@ -15,6 +15,16 @@ Deliberate deviation: the reference's ``_encode_sample`` calls
 the intended NumPy-1 behaviour (``np.asarray``) is what is reproduced.
 Returned batches are float32 torch tensors on the device (the reference's
 trainer converts to float32 tensors right away, ddpg_gumbel_fix.py:121-127).
+
+Ring variants (what ``add`` receives decides, or pass them to the constructor):
+  * ``act_heads=(5, 10)`` -- MultiDiscrete scenarios: each agent's action is the concatenation of one one-hot
+    per head (experiments/run.py:39-41); the ring keeps one index per head and ``sample_index`` returns the
+    concatenated one-hot rows ``act[b, N, 15]`` the reference stored;
+  * ``per_agent=True`` -- the BiCNet tuple (experiments/run_BIC.py:46,50): per-agent ``rew[b, N]`` / ``done[b, N]``.
+The ring holds HARD one-hot actions as indices (what force_discrete_action / hard Gumbel-softmax produce); rows that
+are not one-hot per head, or whose lengths differ between agents, are rejected loudly instead of being squeezed
+through an argmax.  The object pickles (experiments/run.py:186-191 stores the memory in the test history): the
+filled slots travel as CPU arrays and the device storage is rebuilt on first use after loading.
 """
 import ctypes as C
 import random
@@ -31,15 +41,22 @@ def _ptr(t):
 
 
 class ReplayBuffer(object):
-    def __init__(self, size, num_agents=None, obs_dim=None, device=None):
+    def __init__(self, size, num_agents=None, obs_dim=None, device=None, act_heads=None, per_agent=None):
         """size: max number of transitions (``ReplayBuffer(size=1e+6)``, experiments/run.py:20).
-        Storage is allocated on the first add (when N and D are known) unless given here."""
+        Storage is allocated on the first add (when N and D are known) unless given here.
+        ``act_heads``: sizes of the action heads, ``(5,)`` (default) or ``(5, dim_c)``; ``per_agent``: per-agent
+        reward / done planes.  Left None they are taken from the first ``add`` (a scalar reward = shared)."""
         self._maxsize = int(size)
         self._next_idx = 0
         self._len = 0
         self._device = None if device is None else torch.device(device)
         self._store = None
         self._lib = None
+        self._host_state = None
+        self.act_heads = None if act_heads is None else tuple(int(h) for h in act_heads)
+        if self.act_heads is not None and (len(self.act_heads) not in (1, 2) or min(self.act_heads) < 1):
+            raise ValueError('act_heads must be one or two positive head sizes, got %r' % (act_heads,))
+        self.per_agent = None if per_agent is None else bool(per_agent)
         self.num_agents, self.obs_dim = num_agents, obs_dim
         if num_agents is not None and obs_dim is not None:
             self._allocate(num_agents, obs_dim)
@@ -53,16 +70,23 @@ class ReplayBuffer(object):
             self._device = torch.device('cuda', torch.cuda.current_device())
         cap, dev = self._maxsize, self._device
         self.num_agents, self.obs_dim = int(N), int(D)
+        if self.act_heads is None:
+            self.act_heads = (5,)
+        if self.per_agent is None:
+            self.per_agent = False
+        H = len(self.act_heads)
         self.obs = torch.empty(cap, N, D, dtype=torch.float32, device=dev)
         self.next_obs = torch.empty(cap, N, D, dtype=torch.float32, device=dev)
-        self.act = torch.empty(cap, N, dtype=torch.uint8, device=dev)
-        self.rew = torch.empty(cap, dtype=torch.float32, device=dev)
-        self.done = torch.empty(cap, dtype=torch.float32, device=dev)
+        self.act = torch.empty((cap, N) if H == 1 else (cap, N, H), dtype=torch.uint8, device=dev)
+        self.rew = torch.empty((cap, N) if self.per_agent else (cap,), dtype=torch.float32, device=dev)
+        self.done = torch.empty((cap, N) if self.per_agent else (cap,), dtype=torch.float32, device=dev)
         st = PwReplayStore()
         st.obs, st.next_obs, st.rew, st.done = (self.obs.data_ptr(), self.next_obs.data_ptr(),
                                                 self.rew.data_ptr(), self.done.data_ptr())
         st.act = self.act.data_ptr()
         st.capacity, st.num_agents, st.obs_dim = cap, N, D
+        st.act_heads, st.per_agent = H, int(self.per_agent)
+        st.head_width[0], st.head_width[1] = self.act_heads[0], (self.act_heads[1] if H == 2 else 0)
         self._store = st
         # device copies of _next_idx (hipGraph mode): cell [0] for add_batch(device_cursor=True); add_batch_tail
         # ping-pongs between [0] and [1] (it reads one cell in every workgroup and writes the other)
@@ -78,14 +102,80 @@ class ReplayBuffer(object):
         self._next_idx = 0
         self._len = 0
 
+    # -- pickling (experiments/run.py:186-191 puts the memory into the test history it pickles)
+    def __getstate__(self):
+        host = self._host_state
+        if self._store is not None:
+            sl = slice(0, self._len)  # add() fills slots [0, len) before it ever wraps
+            host = {k: getattr(self, k)[sl].cpu().numpy() for k in ('obs', 'next_obs', 'act', 'rew', 'done')}
+        return dict(maxsize=self._maxsize, next_idx=self._next_idx, len=self._len, num_agents=self.num_agents,
+                    obs_dim=self.obs_dim, act_heads=self.act_heads, per_agent=self.per_agent, planes=host)
+
+    def __setstate__(self, st):
+        self.__init__(st['maxsize'], act_heads=st['act_heads'], per_agent=st['per_agent'])
+        self._next_idx, self._len = st['next_idx'], st['len']
+        self.num_agents, self.obs_dim = st['num_agents'], st['obs_dim']
+        self._host_state = st['planes']   # uploaded by _ensure_device() on first use (unpickling needs no GPU)
+
+    def _ensure_device(self):
+        """Rebuild the device storage of an unpickled buffer."""
+        if self._store is None and self._host_state is not None:
+            host, self._host_state = self._host_state, None
+            self._allocate(self.num_agents, self.obs_dim)
+            for k, v in host.items():
+                getattr(self, k)[:v.shape[0]].copy_(torch.from_numpy(v))
+
+    def host_planes(self):
+        """The filled part of the ring as CPU arrays: {obs, next_obs, act, rew, done} (works without a GPU for an
+        unpickled buffer)."""
+        return self.__getstate__()['planes']
+
     # -- rls/replay_buffer.py:30-37
+    def _action_indices(self, action):
+        """list of N one-hot rows -> int32 [N] (one head) or [N, 2]; rejects what the index ring cannot hold."""
+        rows = [np.asarray(a, dtype=np.float64).reshape(-1) for a in action]
+        widths = sorted(set(r.size for r in rows))
+        if len(widths) != 1:
+            raise ValueError('ReplayBuffer: agents have action vectors of different lengths %s (e.g. '
+                             'simple_speaker_listener); the device ring needs one shape per agent -- use a host '
+                             'memory for this scenario' % (widths,))
+        w = widths[0]
+        if self.act_heads is None:
+            self.act_heads = (w,)
+        if sum(self.act_heads) != w:
+            raise ValueError('ReplayBuffer: action vectors have length %d but act_heads=%r' % (w, self.act_heads))
+        a = np.stack(rows)
+        out, lo = [], 0
+        for h in self.act_heads:
+            part = a[:, lo:lo + h]
+            onehot = ((part == 0) | (part == 1)).all() and (part.sum(-1) == 1).all()
+            if not onehot:
+                hint = ' (a %d-wide row with two ones is a MultiDiscrete action: pass act_heads=(5, %d))' % (w, w - 5) \
+                    if len(self.act_heads) == 1 and w > 5 else ''
+                raise ValueError('ReplayBuffer: the device ring stores HARD one-hot actions as indices; got a row '
+                                 'that is not one-hot per head%s' % hint)
+            out.append(part.argmax(-1).astype(np.int32))
+            lo += h
+        return out[0] if len(out) == 1 else np.stack(out, -1)
+
     def add(self, obs_t, action, reward, obs_tp1, done):
-        """One transition in the reference's host format: lists of N arrays (D,), list of N
-        one-hot (5,) arrays, float, lists of N arrays, float."""
+        """One transition in the reference's host format: lists of N arrays (D,), list of N one-hot action rows
+        ((5,), or the concatenated heads of a MultiDiscrete action), reward float (or list of N: the BiCNet tuple),
+        lists of N arrays, done float (or list of N)."""
         obs = torch.as_tensor(np.stack([np.asarray(o, dtype=np.float32) for o in obs_t]))[None]
         nxt = torch.as_tensor(np.stack([np.asarray(o, dtype=np.float32) for o in obs_tp1]))[None]
-        act = torch.as_tensor(np.stack([np.asarray(a) for a in action]).argmax(-1).astype(np.int32))[None]
-        self.add_batch(obs, act, torch.tensor([float(reward)]), nxt, done=torch.tensor([float(done)]))
+        act = torch.as_tensor(self._action_indices(action))[None]
+        per_agent = np.ndim(reward) > 0
+        if self.per_agent is None:
+            self.per_agent = per_agent
+        if per_agent != self.per_agent or (np.ndim(done) > 0) != self.per_agent:
+            raise ValueError('ReplayBuffer: this ring holds %s rewards / dones' %
+                             ('per-agent (BiCNet)' if self.per_agent else 'one shared scalar'))
+        rew = torch.as_tensor(np.asarray(reward, dtype=np.float32).reshape(1, -1) if per_agent
+                              else np.asarray([float(reward)], dtype=np.float32))
+        dn = torch.as_tensor(np.asarray(done, dtype=np.float32).reshape(1, -1) if per_agent
+                             else np.asarray([float(done)], dtype=np.float32))
+        self.add_batch(obs, act, rew, nxt, done=dn)
 
     def sync_cursor(self):
         """Copy the host ring position to the device cursor (call before capturing a graph)."""
@@ -105,10 +195,17 @@ class ReplayBuffer(object):
         device memory by the captured launches; the caller accounts for it with ``note_graph_adds``
         (``advance_cursor=False``: the caller advances ``_cursor`` itself, e.g. in pw_rollout_tail)."""
         B, N, D = obs.shape
+        self._ensure_device()
         if self._store is None:
             self._device = obs.device if obs.is_cuda and self._device is None else self._device
+            if self.act_heads is None and act_idx.dim() == 3:
+                raise ValueError('ReplayBuffer: [B,N,2] action indices need act_heads=(5, dim_c) at construction')
             self._allocate(N, D)
         assert (N, D) == (self.num_agents, self.obs_dim) and B <= self._maxsize
+        H = len(self.act_heads)
+        assert tuple(act_idx.shape) == ((B, N) if H == 1 else (B, N, H)), 'action indices must be [B,N] or [B,N,2] (two heads)'
+        assert tuple(rew_shared.shape) == ((B, N) if self.per_agent else (B,)), 'reward must be [B] ([B,N] per-agent ring)'
+        assert done is None or tuple(done.shape) == tuple(rew_shared.shape)
         dev = self._device
         f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
         obs, next_obs, final_obs = f32(obs), f32(next_obs), f32(final_obs)
@@ -136,6 +233,7 @@ class ReplayBuffer(object):
         int64, e.g. the policy's Philox step) is incremented by the same launch; the caller accounts for the
         adds with ``note_graph_adds``.  All tensors must already be float32 / int32 / uint8 device tensors."""
         B, N, D = obs.shape
+        self._ensure_device()
         if self._store is None:
             self._device = obs.device if self._device is None else self._device
             self._allocate(N, D)
@@ -163,6 +261,7 @@ class ReplayBuffer(object):
         does the chunk's episode-return bookkeeping in the same launch."""
         from ._lib import PwStepIO
         T, B, N, D = out['obs'].shape
+        self._ensure_device()
         if self._store is None:
             self._device = obs0.device if self._device is None else self._device
             self._allocate(N, D)
@@ -198,11 +297,13 @@ class ReplayBuffer(object):
 
     # -- rls/replay_buffer.py:39-49, 59-60
     def _encode_sample(self, idxes):
+        self._ensure_device()
         idx = torch.as_tensor(list(idxes) if not torch.is_tensor(idxes) else idxes, dtype=torch.int64,
                               device=self._device).contiguous()
         b, N, D, dev = idx.numel(), self.num_agents, self.obs_dim, self._device
-        out = (torch.empty(b, N, D, device=dev), torch.empty(b, N, 5, device=dev), torch.empty(b, device=dev),
-               torch.empty(b, N, D, device=dev), torch.empty(b, device=dev))
+        rd = (b, N) if self.per_agent else (b,)
+        out = (torch.empty(b, N, D, device=dev), torch.empty(b, N, sum(self.act_heads), device=dev),
+               torch.empty(rd, device=dev), torch.empty(b, N, D, device=dev), torch.empty(rd, device=dev))
         check(self._lib.pw_replay_gather(C.byref(self._store), _ptr(idx), b, _ptr(out[0]), _ptr(out[1]),
                                          _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), self._stream()))
         return out

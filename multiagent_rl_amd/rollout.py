@@ -42,6 +42,15 @@ def run_test(env, actor, critic, Trainer, scenario_name=None, action_type='Discr
                  evaluate=True, per_agent_transition=False)
 
 
+def _action_heads(env, action_type):
+    """Head sizes of one agent's action, read the way main.py:51-58 reads them: ``space.n`` for Discrete,
+    ``space.high - space.low + 1`` for MultiDiscrete.  (Agents whose spaces differ make ReplayBuffer.add raise.)"""
+    space = env.action_space[0]
+    if action_type == 'MultiDiscrete' and hasattr(space, 'high'):
+        return tuple(int(h - l + 1) for h, l in zip(space.high, space.low))
+    return (int(space.n),) if hasattr(space, 'n') else None
+
+
 def _loop(env, actor, critic, Trainer, scenario_name, action_type, cnt, arglist, memory, out_dir, log,
           evaluate, per_agent_transition):
     cfg = _default_arglist if arglist is None else arglist
@@ -51,7 +60,7 @@ def _loop(env, actor, critic, Trainer, scenario_name, action_type, cnt, arglist,
     log('action shape: ', env.action_space)
     if memory is None:
         from .replay_buffer import ReplayBuffer
-        memory = ReplayBuffer(size=1e+6)
+        memory = ReplayBuffer(size=1e+6, act_heads=_action_heads(env, action_type), per_agent=per_agent_transition)
     learner = Trainer(actor, critic, memory, action_type=action_type)
     if evaluate:
         learner.load_models(getattr(cfg, 'appx', '') + scenario_name + '_fin_' + str(cnt))
@@ -125,8 +134,8 @@ class BatchedRollout(object):
     Per step: ``actions = policy(obs)`` -> ``env.step(actions)`` (one fused launch) ->
     ``memory.add_batch(...)`` with the reference's transition tuple (obs, action, shared reward,
     next obs BEFORE reset, done) -- the same bookkeeping as run.py:44-65, vectorised over B.
-    (The device replay ring stores single-head action indices; MultiDiscrete rollouts run with
-    ``memory=None`` or their own sink.)
+    (MultiDiscrete rollouts -- actions [B,N,2] -- need a ring built with ``act_heads=(5, dim_c)``; they take the
+    per-step ``add_batch`` path.)
     Episode returns are accumulated on the device; nothing is read back inside ``collect``.
     """
 
@@ -158,7 +167,8 @@ class BatchedRollout(object):
 
     def _sink(self, obs, actions, out, parity=None, step_counter=None):
         """Replay append + episode-return bookkeeping: ONE launch when there is a device ring."""
-        if self.memory is not None and actions.dtype == torch.int32 and out.get('final_obs') is not None:
+        if self.memory is not None and actions.dtype == torch.int32 and actions.dim() == 2 and \
+                out.get('final_obs') is not None:
             self.memory.add_batch_tail(obs, actions, out['rew_shared'], out['obs'], out['final_obs'], out['terminal'],
                                        self.episode_return, self.finished_return_sum, self.finished_episodes,
                                        step_counter=step_counter, parity=parity)

@@ -628,3 +628,141 @@ def test_wire_functions_reject_foreign_layouts():
     assert lib.pw_chunk_wire_finalize(C.byref(lay), C.c_void_p(block.data_ptr() + 4), p(z), None, p(term), p(act), None) < 0
     assert lib.pw_chunk_wire_finalize(C.byref(lay), p(block), p(z), None, p(term), p(act), None) == 0
     torch.cuda.synchronize()
+
+
+def test_run_test_on_hip_env_with_device_ring_pickles_history(tmp_path):
+    """rollout.run_test (experiments/run.py:106-200) on the HIP MultiAgentEnv with the DEFAULT memory -- the device
+    ReplayBuffer -- reproduces the reference's evaluation call trace (event kinds, shapes, dtypes; values to float32
+    accuracy) and pickles the history WITH the memory inside (run.py:186-191); the pickle loads back and serves the
+    same samples."""
+    import pickle
+    from multiagent_rl_amd import make_env, rollout
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    gold = json.load(open(os.path.join(GOLD_DIR, 'run_test_trace.json')))
+
+    class Args(object):
+        is_training, display = True, False
+    for k, v in gold['arglist'].items():
+        setattr(Args, k, v)
+    np.random.seed(12345679)
+    env = RecordingEnv(make_env('simple_spread', n=4))
+    np.random.seed(12345679)
+    StubTrainer.trace = env.trace
+    hist = rollout.run_test(env, None, None, StubTrainer, 'simple_spread', 'Discrete', cnt=1, arglist=Args,
+                            out_dir=str(tmp_path), log=lambda *a: None)
+
+    def skeleton(x):
+        if isinstance(x, dict):
+            return {k: skeleton(v) for k, v in x.items() if k not in ('sum', 'value')}
+        if isinstance(x, list):
+            return [skeleton(v) for v in x]
+        return x
+    assert skeleton(json.loads(json.dumps(env.trace))) == skeleton(gold['trace'])
+    assert env.trace[1] == ['load_models', 'pfx/simple_spread_fin_1'] and not any(e[0] == 'save_models' for e in env.trace)
+    np.testing.assert_allclose(hist['reward_episodes'], gold['reward_episodes'], rtol=1e-4, atol=1e-3)
+    mem = hist['memory']
+    assert isinstance(mem, ReplayBuffer) and len(mem) == gold['memory_len'] and sorted(os.listdir(tmp_path)) == gold['files']
+    with open(os.path.join(str(tmp_path), gold['files'][0]), 'rb') as fp:
+        back = pickle.load(fp)
+    assert sorted(back.keys()) == gold['history_keys']
+    m2 = back['memory']
+    assert len(m2) == len(mem) and m2._next_idx == mem._next_idx and m2._store is None   # no GPU touched by loading
+    planes = m2.host_planes()
+    assert planes['obs'].shape == (len(mem), 4, mem.obs_dim) and planes['act'].shape == (len(mem), 4)
+    idx = list(range(0, len(mem), 3))
+    for a, b in zip(mem.sample_index(idx), m2.sample_index(idx)):
+        assert torch.equal(a, b)
+    m2.add(*[[np.zeros(mem.obs_dim)] * 4, [np.eye(5)[1]] * 4, 0.5, [np.ones(mem.obs_dim)] * 4, 0.0])   # still a ring
+    assert len(m2) == len(mem) + 1
+
+
+def test_device_ring_multidiscrete_and_bicnet_variants(tmp_path):
+    """The transitions run() stores for MultiDiscrete scenarios (15-wide concatenated one-hots, run.py:39-41,52) and
+    for BiCNet (per-agent rew_n / done_n, run_BIC.py:46,50) go through the DEFAULT device memory and come back from
+    sample_index exactly as the reference's tuple ring would return them."""
+    import pickle
+    from multiagent_rl_amd import make_env, rollout
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    gold = json.load(open(os.path.join(GOLD_DIR, 'run_multidiscrete_trace.json')))
+
+    class Args(object):
+        is_training, display = True, False
+    for k, v in gold['arglist'].items():
+        setattr(Args, k, v)
+
+    class Spy(StubTrainer):                      # keeps what add() received, next to the device ring
+        def __init__(self, actor, critic, memory, action_type='Discrete'):
+            super().__init__(actor, critic, memory, action_type)
+            self.log, inner = [], memory.add
+
+            def add(*a):
+                self.log.append(a)
+                inner(*a)
+            memory.add = add
+    np.random.seed(12345680)
+    env = RecordingEnv(make_env('simple_reference'))
+    Spy.trace = env.trace
+    rollout.run(env, None, None, Spy, 'simple_reference', 'MultiDiscrete', cnt=2, arglist=Args,
+                out_dir=str(tmp_path), log=lambda *a: None)
+    tr, mem = Spy.last.log, Spy.last.memory
+    assert isinstance(mem, ReplayBuffer) and mem.act_heads == (5, 10) and not mem.per_agent and len(mem) == len(tr) > 20
+    o, a, r, n, d = mem.sample_index(list(range(len(tr))))
+    assert a.shape == (len(tr), 2, 15) and r.shape == (len(tr),)
+    np.testing.assert_array_equal(a.cpu().numpy(), np.array([np.stack(t[1]) for t in tr], dtype=np.float32))
+    np.testing.assert_allclose(o.cpu().numpy(), np.array([np.stack(t[0]) for t in tr]), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(n.cpu().numpy(), np.array([np.stack(t[3]) for t in tr]), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(r.cpu().numpy(), np.array([t[2] for t in tr]), rtol=1e-6)
+    m2 = pickle.loads(pickle.dumps(mem))
+    assert m2.act_heads == (5, 10) and torch.equal(m2.sample_index([0, 5, 7])[1], a[[0, 5, 7]])
+
+    # BiCNet tuple
+    gold = json.load(open(os.path.join(GOLD_DIR, 'run_trace.json')))
+    for k, v in gold['arglist'].items():
+        setattr(Args, k, v)
+    np.random.seed(12345678)
+    env = RecordingEnv(make_env('simple_spread'))
+    Spy.trace = env.trace
+    rollout.run(env, None, None, Spy, 'simple_spread', 'Discrete', cnt=0, arglist=Args, out_dir=None,
+                log=lambda *a: None, per_agent_transition=True)
+    tr, mem = Spy.last.log, Spy.last.memory
+    assert mem.per_agent and mem.act_heads == (5,) and len(mem) == 75
+    o, a, r, n, d = mem.sample_index(list(range(75)))
+    assert r.shape == d.shape == (75, 3) and a.shape == (75, 3, 5)
+    np.testing.assert_allclose(r.cpu().numpy(), np.array([t[2] for t in tr]), rtol=1e-6)
+    np.testing.assert_array_equal(d.cpu().numpy(), np.array([t[4] for t in tr], dtype=np.float32))
+    np.testing.assert_array_equal(a.cpu().numpy(), np.array([np.stack(t[1]) for t in tr], dtype=np.float32))
+
+    # what the index ring cannot hold is refused loudly, never squeezed through an argmax
+    rb = ReplayBuffer(8)
+    two = [np.concatenate([np.eye(5)[1], np.eye(10)[3]])] * 2
+    with pytest.raises(ValueError, match='act_heads'):
+        rb.add([np.zeros(21)] * 2, two, 0.0, [np.zeros(21)] * 2, 0.0)                 # 15-wide rows, heads not given
+    with pytest.raises(ValueError, match='different lengths'):
+        ReplayBuffer(8).add([np.zeros(11)] * 2, [np.eye(3)[0], np.eye(5)[0]], 0.0, [np.zeros(11)] * 2, 0.0)
+    with pytest.raises(ValueError, match='one-hot'):
+        ReplayBuffer(8).add([np.zeros(10)] * 3, [np.full(5, 0.2)] * 3, 0.0, [np.zeros(10)] * 3, 0.0)   # soft action
+    ok = ReplayBuffer(8, act_heads=(5, 10))
+    ok.add([np.zeros(21)] * 2, two, 0.0, [np.zeros(21)] * 2, 0.0)
+    with pytest.raises(ValueError, match='shared scalar'):
+        ok.add([np.zeros(21)] * 2, two, [0.0, 1.0], [np.zeros(21)] * 2, [0.0, 0.0])
+
+
+def test_batched_rollout_multidiscrete_feeds_a_two_head_ring():
+    """simple_reference, B envs: the two-head FusedActor's [B,N,2] actions go into a ring built with act_heads=(5,10)."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    from multiagent_rl_amd.rollout import BatchedRollout
+    torch.manual_seed(0)
+    B = 128
+    env = make_batched_env('simple_reference', B, auto_reset=True, max_episode_len=25, seed=3)
+    actor = ActorNetwork(env.obs_dim, [5, 10]).cuda().eval()
+    mem = ReplayBuffer(B * 40, 2, env.obs_dim, act_heads=(5, 10))
+    ro = BatchedRollout(env, FusedActor(actor, seed=4), mem)
+    first = ro.obs.clone()
+    ro.collect(30)
+    assert len(mem) == 30 * B and ro.stats()['episodes'] == B
+    o, a, r, n, d = mem.sample_index(list(range(B)))
+    assert torch.equal(o, first) and a.shape == (B, 2, 15)
+    assert (a[..., :5].sum(-1) == 1).all() and (a[..., 5:].sum(-1) == 1).all() and not d.any()
+    assert mem.act.shape == (B * 40, 2, 2) and int(mem.act[:30 * B, :, 1].max()) > 4      # symbols use the 10-wide head
