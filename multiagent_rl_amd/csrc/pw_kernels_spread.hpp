@@ -255,6 +255,7 @@ struct StreamParams {
     const int32_t *act;
     float *obs, *final_obs, *rew, *rew_shared;
     uint8_t *done, *terminal;
+    uint64_t *coll;  // [T,B,N] collision masks; written only by the COLL instantiations
 };
 
 template <int LT>
@@ -281,6 +282,77 @@ __device__ __forceinline__ void stream_write_obs(float *__restrict__ o, const in
     }
 }
 
+// Observation rows of ALL the wave's envs as ONE contiguous block.  A wave's lanes own consecutive rows
+// (row = first row of the workgroup + lane), so its rows x D floats are contiguous in the obs plane; instead of
+// every lane storing its own row (16 B per lane at a stride of D floats: each store instruction touches `rows`
+// different cache lines with a quarter line each, and the write path is what bounds the large-B / large-N regimes,
+// profiles/r2_regimes.txt), lane l of store instruction s writes chunk q = l + 64 s of the block: 64 lanes x 16 B =
+// 1 KiB contiguous per instruction.  Chunk q belongs to row r = q / CH, column group c = q % CH (CH = D / 4):
+// c = 0 is {vel, pos}, c >= 1 the two landmarks 2c-2, 2c-1 relative to the row's agent.  s_row[r] = {px, py, vx, vy}
+// of the wave's row r (every lane publishes its own first), s_lm the wave's landmarks [e_local * L + l].
+// Odd L: the same with 8-byte chunks (CH = D / 2: vel | pos | one landmark each).  The values are the ones
+// stream_write_obs computes (same subtractions), only the lane that stores them differs.
+template <int NT, int LT>
+__device__ __forceinline__ void stream_write_obs_block(float *__restrict__ blk, const int rows, const int lane,
+                                                       const float4 *s_row, const float2 *s_lm)
+{
+    static_assert(NT > 0 && LT > 0, "compile-time N and L only");
+    constexpr int D = 4 + 2 * LT;
+    constexpr bool WIDE = LT % 2 == 0;           // 16-byte chunks; odd L: 8-byte chunks
+    constexpr int CH = WIDE ? D / 4 : D / 2;     // chunks per row
+    constexpr int UNR = CH < 4 ? CH : 4;         // chunks in flight per lane: their LDS reads share one wait
+    constexpr int DR = 64 / CH, DC = 64 % CH;    // chunk q + 64 is DR rows further and DC column groups to the right
+    const int total = rows * CH;
+    // (row, column group) of this lane's chunk, advanced incrementally: no division inside the loop, and nothing
+    // for the compiler to hoist into dozens of loop-invariant registers (which cost the N = 48 kernel its occupancy)
+    int r = lane / CH, c = lane - r * CH;
+#pragma unroll 1
+    for (int q0 = lane; q0 - lane < total; q0 += 64 * UNR) {  // wave-uniform trip count
+        float4 st[UNR], lm[UNR];
+        int cc[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int rr = r < rows ? r : 0;  // lanes past the block read row 0 (they store nothing)
+            cc[u] = c;
+            st[u] = s_row[rr];
+            const int e = rr / NT;
+            if (WIDE) {
+                lm[u] = *reinterpret_cast<const float4 *>(s_lm + e * LT + (c > 0 ? 2 * c - 2 : 0));
+            } else {
+                const float2 l1 = s_lm[e * LT + (c > 1 ? c - 2 : 0)];
+                lm[u] = make_float4(l1.x, l1.y, 0.0f, 0.0f);
+            }
+            r += DR; c += DC;
+            if (c >= CH) { c -= CH; r += 1; }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int q = q0 + 64 * u;
+            if (WIDE) {
+                const float4 o = cc[u] == 0 ? make_float4(st[u].z, st[u].w, st[u].x, st[u].y)
+                                            : make_float4(lm[u].x - st[u].x, lm[u].y - st[u].y, lm[u].z - st[u].x, lm[u].w - st[u].y);
+                if (q < total) reinterpret_cast<float4 *>(blk)[q] = o;
+            } else {
+                const float2 o = cc[u] == 0 ? make_float2(st[u].z, st[u].w)
+                                 : cc[u] == 1 ? make_float2(st[u].x, st[u].y)
+                                              : make_float2(lm[u].x - st[u].x, lm[u].y - st[u].y);
+                if (q < total) reinterpret_cast<float2 *>(blk)[q] = o;
+            }
+        }
+    }
+}
+
+// Store instructions per step of stream_write_obs_block at the default packing of large batches (pw_create:
+// 8 envs per wave at N = 6, 16 at N = 3, 64 / N otherwise); 0 when N / L are runtime values.
+template <int NT, int LT>
+constexpr int obs_block_stores()
+{
+    if (NT <= 0 || LT <= 0) return 0;
+    const int rows = (NT == 6 ? 8 : NT == 3 ? 16 : 64 / NT) * NT;
+    const int ch = LT % 2 == 0 ? (4 + 2 * LT) / 4 : (4 + 2 * LT) / 2;
+    return (rows * ch + 63) / 64;
+}
+
 template <int NT, typename MaskT>
 __device__ __forceinline__ void stream_partner_pass(const int N, const int a, const float2 *pp, float px, float py,
                                                     float olx, float oly, float coll_thr2, float near_thr2,
@@ -301,14 +373,16 @@ __device__ __forceinline__ void stream_partner_pass(const int N, const int a, co
     }
 }
 
-template <int NT, int LT, bool UNIT_MASS>
+template <int NT, int LT, bool UNIT_MASS, bool COLL = false, bool BLOCK = false>
 __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamParams A, const int T)
 {
     using MaskT = typename std::conditional<(NT > 0 && NT <= 32), uint32_t, uint64_t>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int N = NT ? NT : A.N, L = LT ? LT : A.L, D = 4 + 2 * L;
     float2 *s_pos = reinterpret_cast<float2 *>(smem_raw);  // [64]
-    float2 *s_lm = s_pos + kWave;                          // [epw * L]
+    float4 *s_row = reinterpret_cast<float4 *>(s_pos + kWave);  // [64] {pos, vel} per row, for the block-wise obs stores
+    float2 *s_lm = reinterpret_cast<float2 *>(s_row + kWave);   // [epw * L]
+    const int rows_here = (A.B - (int)blockIdx.x * A.epw < A.epw ? A.B - (int)blockIdx.x * A.epw : A.epw) * N;
 
     int e_local = (int)threadIdx.x / N;
     int a = (int)threadIdx.x - e_local * N;
@@ -344,7 +418,7 @@ __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamPar
     // + the observation row.  An explicit vmcnt(K) at the end of the step tells the compiler's
     // waitcnt pass that the prefetched load has retired while the K stores stay in flight (it is
     // a hint only: the compiler still inserts any wait it cannot prove redundant).
-    constexpr int kStoresPerStep = LT > 0 ? 4 + (LT % 2 == 0 ? 1 + LT / 2 : 2 + LT) : 0;
+    constexpr int kStoresPerStep = LT > 0 ? 4 + (COLL ? 1 : 0) + (BLOCK ? obs_block_stores<NT, LT>() : (LT % 2 == 0 ? 1 + LT / 2 : 2 + LT)) : 0;
     constexpr int kVm = kStoresPerStep < 63 ? kStoresPerStep : 63;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): enter the loop with nothing pending
     PW_STAMP_DECL;
@@ -394,6 +468,7 @@ __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamPar
         PW_STAMP(4);
         A.rew[tBN + g] = r;
         A.done[tBN + g] = 0;
+        if (COLL) A.coll[tBN + g] = (uint64_t)coll;  // is_collision bits of the state this step produced (pre-reset)
         A.rew_shared[(size_t)t * A.B + env] = acc;
         ep_step += 1;
         const bool term = A.max_episode_len > 0 && ep_step >= A.max_episode_len;
@@ -413,11 +488,16 @@ __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamPar
             s_pos[base + a] = make_float2(px, py);
         }
         // (lanes whose env did not reset wait here for the ones that did: one wave, reconverged)
+        if (BLOCK) s_row[base + a] = make_float4(px, py, vx, vy);
         wave_lds_sync();
         if (A.auto_reset && __any(term))
             stream_partner_pass<NT, MaskT>(N, a, pp, px, py, olx, oly, A.coll_thr2, A.near_thr2, coll, near, best);
         PW_STAMP(5);
-        stream_write_obs<LT>(A.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+        if constexpr (BLOCK)
+            stream_write_obs_block<NT, LT>(A.obs + (tBN + (size_t)blockIdx.x * A.epw * N) * D, rows_here, (int)threadIdx.x,
+                                           s_row, s_lm);
+        else
+            stream_write_obs<LT>(A.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
         PW_STAMP(6);
         if (LT > 0) __builtin_amdgcn_s_waitcnt((kVm & 0xF) | 0x0F70 | ((kVm >> 4) << 14));  // vmcnt(kVm)
         PW_STAMP(7);
@@ -469,7 +549,7 @@ __device__ __forceinline__ MaskT duo_near_pass(const int N, const int a, const f
     return near & ~((MaskT)1 << a);
 }
 
-template <int NT, int LT, bool UNIT_MASS>
+template <int NT, int LT, bool UNIT_MASS, bool COLL = false, bool BLOCK = false>
 __global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamParams A, const int T)
 {
     using MaskT = typename std::conditional<(NT > 0 && NT <= 32), uint32_t, uint64_t>::type;
@@ -479,9 +559,15 @@ __global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamPa
     float2 *s_lm = reinterpret_cast<float2 *>(s_ring + 3 * kWave);    // [epw * L]      (wave O only)
     float *s_min = reinterpret_cast<float *>(s_lm + A.epw * L);       // [64] per-landmark min dist (O)
     float *s_rew = s_min + kWave;                                     // [64] per-agent reward      (O)
+    // [64] {pos, vel} of every row after the step (post-reset where the env reset), for O's block-wise obs stores;
+    // 16-byte aligned: 3*64*16 + epw*L*8 + 512 bytes precede it and epw*L*8 is a multiple of 16 when L is even
+    // (odd L: the block writer reads it as float4 too, so pad)
+    float4 *s_row = reinterpret_cast<float4 *>(smem_raw + ((3 * kWave * sizeof(float4) + (size_t)A.epw * L * sizeof(float2) +
+                                                            2 * kWave * sizeof(float) + 15) & ~(size_t)15));
 
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = (int)threadIdx.x & 63;
+    const int rows_here = (A.B - (int)blockIdx.x * A.epw < A.epw ? A.B - (int)blockIdx.x * A.epw : A.epw) * N;
     int e_local = lane / N;
     int a = lane - e_local * N;
     int env = blockIdx.x * A.epw + e_local;
@@ -559,7 +645,7 @@ __global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamPa
             oly = A.lm_y[(size_t)env * L + la];
             lmv[la] = make_float2(olx, oly);
         }
-        constexpr int kStoresPerStep = LT > 0 ? 4 + (LT % 2 == 0 ? 1 + LT / 2 : 2 + LT) : 0;
+        constexpr int kStoresPerStep = LT > 0 ? 4 + (COLL ? 1 : 0) + (BLOCK ? obs_block_stores<NT, LT>() : (LT % 2 == 0 ? 1 + LT / 2 : 2 + LT)) : 0;
         constexpr int kVm = kStoresPerStep < 63 ? kStoresPerStep : 63;
         PW_STAMP_DECL;
         for (int t = 0; t < T; ++t) {
@@ -599,6 +685,7 @@ __global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamPa
             PW_STAMP(1);
             A.rew[tBN + g] = r;
             A.done[tBN + g] = 0;
+            if (COLL) A.coll[tBN + g] = (uint64_t)coll;
             A.rew_shared[(size_t)t * A.B + env] = acc;
             ep_step += 1;
             const bool term = A.max_episode_len > 0 && ep_step >= A.max_episode_len;
@@ -617,8 +704,12 @@ __global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamPa
                 px = fresh.x; py = fresh.y; vx = fresh.z; vy = fresh.w;
             }
             cur = nxt;
+            if (BLOCK) s_row[me] = make_float4(px, py, vx, vy);
             wave_lds_sync();
-            stream_write_obs<LT>(A.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+            if constexpr (BLOCK)
+                stream_write_obs_block<NT, LT>(A.obs + (tBN + (size_t)blockIdx.x * A.epw * N) * D, rows_here, lane, s_row, s_lm);
+            else
+                stream_write_obs<LT>(A.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
             PW_STAMP(2);
             if (LT > 0) __builtin_amdgcn_s_waitcnt((kVm & 0xF) | 0x0F70 | ((kVm >> 4) << 14));
             PW_STAMP(3);

@@ -32,6 +32,7 @@ struct TagParams {
     const int32_t *act;
     float *obs, *final_obs, *rew, *rew_shared;
     uint8_t *done, *terminal;
+    uint64_t *coll;  // [T,B,N] collision masks; written only by the COLL instantiations
 };
 
 __device__ __forceinline__ bool bits_near(float d2, float near_thr2)
@@ -68,7 +69,7 @@ __device__ __forceinline__ void tag_write_obs(float *__restrict__ o, const int N
 }
 
 // NT / AT / LT: compile-time N / A / L (0 / -1 / 0 = runtime)
-template <int NT, int AT, int LT, bool UNIT_MASS>
+template <int NT, int AT, int LT, bool UNIT_MASS, bool COLL = false>
 __global__ void __launch_bounds__(kWave) pw_tag_stream_kernel(const TagParams P, const int T)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(kWave) pw_tag_stream_kernel(const TagParams P,
 
     const float k = P.contact_margin, cf = P.contact_force, dt = P.dt, damp = P.damp, mass = P.mass;
     int act_next = P.act[g];
-    constexpr int kStoresPerStep = (NT > 0 && AT >= 0 && LT > 0) ? 4 + (4 + 2 * LT + 2 * (NT - 1) + 2 * (NT - AT)) / 2 : 0;
+    constexpr int kStoresPerStep = (NT > 0 && AT >= 0 && LT > 0) ? 4 + (COLL ? 1 : 0) + (4 + 2 * LT + 2 * (NT - 1) + 2 * (NT - AT)) / 2 : 0;
     constexpr int kVm = kStoresPerStep < 63 ? kStoresPerStep : 63;
     __builtin_amdgcn_s_waitcnt(0x0F70);
 
@@ -200,6 +201,7 @@ __global__ void __launch_bounds__(kWave) pw_tag_stream_kernel(const TagParams P,
         for (int i = 0; i < N; ++i) acc += s_rew[base + i];
         P.rew[tBN + g] = r;
         P.done[tBN + g] = 0;
+        if (COLL) P.coll[tBN + g] = coll;
         P.rew_shared[(size_t)t * P.B + env] = acc;
         ep_step += 1;
         const bool term = P.max_episode_len > 0 && ep_step >= P.max_episode_len;
@@ -245,7 +247,7 @@ __global__ void __launch_bounds__(kWave) pw_tag_stream_kernel(const TagParams P,
 // its own copy of the landmarks (both draw them from Philox at a reset), so the only cross-wave traffic is
 // the ring.  Used while the grid is small enough to be latency bound.
 // ------------------------------------------------------------------------------------------
-template <int NT, int AT, int LT, bool UNIT_MASS>
+template <int NT, int AT, int LT, bool UNIT_MASS, bool COLL = false>
 __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P, const int T)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -367,7 +369,7 @@ __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P
         const float cthr_adv = P.coll_thr2[cls][0], cthr_good = P.coll_thr2[cls][1];
         const uint64_t adv_bits = A >= 64 ? ~0ull : ((1ull << A) - 1ull);
         for (int l = a; l < L; l += N) lmv[l] = make_float2(P.lm_x[(size_t)env * L + l], P.lm_y[(size_t)env * L + l]);
-        constexpr int kStoresPerStep = (NT > 0 && AT >= 0 && LT > 0) ? 4 + (4 + 2 * LT + 2 * (NT - 1) + 2 * (NT - AT)) / 2 : 0;
+        constexpr int kStoresPerStep = (NT > 0 && AT >= 0 && LT > 0) ? 4 + (COLL ? 1 : 0) + (4 + 2 * LT + 2 * (NT - 1) + 2 * (NT - AT)) / 2 : 0;
         constexpr int kVm = kStoresPerStep < 63 ? kStoresPerStep : 63;
         // observation row from a ring slot ({pos, vel} of every agent of the env) + this wave's landmarks
         auto write_row = [&](float *o, const float4 *slot, float px, float py, float vx, float vy) {
@@ -427,6 +429,7 @@ __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P
             for (int i = 0; i < N; ++i) acc += s_rew[base + i];
             P.rew[tBN + g] = r;
             P.done[tBN + g] = 0;
+            if (COLL) P.coll[tBN + g] = coll;
             P.rew_shared[(size_t)t * P.B + env] = acc;
             ep_step += 1;
             const bool term = P.max_episode_len > 0 && ep_step >= P.max_episode_len;

@@ -218,13 +218,14 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
     }
     const dim3 grid((kp.B + kp.epw - 1) / kp.epw), block(kWave);
     const size_t shmem = smem_bytes(kp);
-    if (h->tag_fast && io->act_idx && io->obs && io->rew && io->rew_shared && io->done && io->terminal && !io->coll &&
+    if (h->tag_fast && io->act_idx && io->obs && io->rew && io->rew_shared && io->done && io->terminal &&
         (size_t)kp.B * kp.N * kp.D * sizeof(float) < (1ull << 31) && !std::getenv("PWORLD_NO_STREAM")) {
         TagParams A = h->tp;
         A.pos_x = kp.pos_x; A.pos_y = kp.pos_y; A.vel_x = kp.vel_x; A.vel_y = kp.vel_y;
         A.lm_x = kp.lm_x; A.lm_y = kp.lm_y; A.ep_step = kp.ep_step; A.ep_count = kp.ep_count;
         A.act = io->act_idx; A.obs = io->obs; A.final_obs = io->final_obs; A.rew = io->rew;
-        A.rew_shared = io->rew_shared; A.done = io->done; A.terminal = io->terminal;
+        A.rew_shared = io->rew_shared; A.done = io->done; A.terminal = io->terminal; A.coll = io->coll;
+        const bool wc = io->coll != nullptr;  // the optional collision-mask output: its own instantiations
         hipStream_t st = static_cast<hipStream_t>(stream);
         const size_t shm = 2 * kWave * sizeof(float2) + 3 * kWave * sizeof(float) + (size_t)kp.epw * kp.L * sizeof(float2);
         const bool um = kp.mass == 1.0f;
@@ -232,22 +233,25 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         const bool duo = (grid.x <= 1024 && !std::getenv("PWORLD_NO_DUO")) || std::getenv("PWORLD_FORCE_DUO");
         const size_t shm2 = 3 * kWave * sizeof(float4) + 3 * kWave * sizeof(float) + 2 * (size_t)kp.epw * kp.L * sizeof(float2);
         const dim3 block2(2 * kWave);
-#define PW_TAG_LAUNCH(n, a, l)                                                                              \
-    do {                                                                                                    \
-        if (duo) {                                                                                          \
-            if (um) hipLaunchKernelGGL((pw_tag_duo_kernel<n, a, l, true>), grid, block2, shm2, st, A, T);   \
-            else hipLaunchKernelGGL((pw_tag_duo_kernel<n, a, l, false>), grid, block2, shm2, st, A, T);     \
-        } else if (um) hipLaunchKernelGGL((pw_tag_stream_kernel<n, a, l, true>), grid, block, shm, st, A, T); \
-        else hipLaunchKernelGGL((pw_tag_stream_kernel<n, a, l, false>), grid, block, shm, st, A, T);        \
+#define PW_TAG_LAUNCH(n, a, l, c)                                                                              \
+    do {                                                                                                       \
+        if (duo) {                                                                                             \
+            if (um) hipLaunchKernelGGL((pw_tag_duo_kernel<n, a, l, true, c>), grid, block2, shm2, st, A, T);   \
+            else hipLaunchKernelGGL((pw_tag_duo_kernel<n, a, l, false, c>), grid, block2, shm2, st, A, T);     \
+        } else if (um) hipLaunchKernelGGL((pw_tag_stream_kernel<n, a, l, true, c>), grid, block, shm, st, A, T); \
+        else hipLaunchKernelGGL((pw_tag_stream_kernel<n, a, l, false, c>), grid, block, shm, st, A, T);        \
     } while (0)
-        if (kp.N == 6 && kp.A == 4 && kp.L == 2) PW_TAG_LAUNCH(6, 4, 2);        // BASELINE configs[2]
-        else if (kp.N == 4 && kp.A == 3 && kp.L == 2) PW_TAG_LAUNCH(4, 3, 2);   // canonical upstream roster
-        else PW_TAG_LAUNCH(0, -1, 0);
+        if (wc) {
+            if (kp.N == 6 && kp.A == 4 && kp.L == 2 && um) PW_TAG_LAUNCH(6, 4, 2, true);
+            else PW_TAG_LAUNCH(0, -1, 0, true);
+        } else if (kp.N == 6 && kp.A == 4 && kp.L == 2) PW_TAG_LAUNCH(6, 4, 2, false);   // BASELINE configs[2]
+        else if (kp.N == 4 && kp.A == 3 && kp.L == 2) PW_TAG_LAUNCH(4, 3, 2, false);      // canonical upstream roster
+        else PW_TAG_LAUNCH(0, -1, 0, false);
 #undef PW_TAG_LAUNCH
         PW_HIP_CHECK(hipGetLastError());
         return PW_OK;
     }
-    if (h->fast && io->act_idx && io->obs && io->rew && io->rew_shared && io->done && io->terminal && !io->coll &&
+    if (h->fast && io->act_idx && io->obs && io->rew && io->rew_shared && io->done && io->terminal &&
         (size_t)kp.B * kp.N * kp.D * sizeof(float) < (1ull << 31) && !std::getenv("PWORLD_NO_STREAM")) {
         StreamParams A;
         A.B = kp.B; A.N = kp.N; A.L = kp.L; A.epw = kp.epw;
@@ -260,23 +264,40 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         A.pos_x = kp.pos_x; A.pos_y = kp.pos_y; A.vel_x = kp.vel_x; A.vel_y = kp.vel_y;
         A.lm_x = kp.lm_x; A.lm_y = kp.lm_y; A.ep_step = kp.ep_step; A.ep_count = kp.ep_count;
         A.act = io->act_idx; A.obs = io->obs; A.final_obs = io->final_obs; A.rew = io->rew;
-        A.rew_shared = io->rew_shared; A.done = io->done; A.terminal = io->terminal;
+        A.rew_shared = io->rew_shared; A.done = io->done; A.terminal = io->terminal; A.coll = io->coll;
         hipStream_t st = static_cast<hipStream_t>(stream);
-        const size_t shm = (size_t)(kWave + kp.epw * kp.L) * sizeof(float2);
-        const int key = kp.N == kp.L ? kp.N : 0;
+        const size_t shm = (size_t)(kWave + kp.epw * kp.L) * sizeof(float2) + kWave * sizeof(float4);
         const bool um = kp.mass == 1.0f;
+        const bool wc = io->coll != nullptr;  // the optional collision-mask output: instantiated for N = 3, 6 and runtime N
+        // Observation rows stored row-per-lane, or as one contiguous block per wave (stream_write_obs_block): the
+        // block form is what the write path wants once the run is store-bound (B = 65536, N = 6: +58 %; N = 24 / 48 at
+        // B = 4096: +59 % / +47 %), but it lengthens the output wave's step, which latency-bound small grids pay for
+        // (C2: -5 %; N = 3, B = 16384: -38 %).  Measured crossover (profiles/r2_obs_block_threshold.txt): between 512
+        // and 820 workgroups for N = 6 ... 24, above 1024 for N = 3 (8-byte chunks).  PWORLD_OBS_BLOCK=0/1 overrides.
+        bool blk = kp.N == 3 ? grid.x > 3000 : grid.x > 700;
+        if (const char *e = std::getenv("PWORLD_OBS_BLOCK")) blk = std::atoi(e) != 0;
+        const int key = kp.N != kp.L ? 0 : (wc && !(um && (kp.N == 3 || kp.N == 6))) ? 0 : kp.N;
         // two cooperating waves per env group pay off while the chip is latency bound (few workgroups
         // per CU); once every SIMD holds several waves the single-wave kernel issues fewer instructions
         const bool duo = grid.x <= 8192 && !std::getenv("PWORLD_NO_DUO");
         if (duo || std::getenv("PWORLD_FORCE_DUO")) {
             const size_t shm2 = 3 * kWave * sizeof(float4) + (size_t)kp.epw * kp.L * sizeof(float2) +
-                                2 * kWave * sizeof(float);
+                                2 * kWave * sizeof(float) + 16 + kWave * sizeof(float4);
             const dim3 block2(2 * kWave);
+            if (wc) {
+                if (key == 3) hipLaunchKernelGGL((pw_spread_duo_kernel<3, 3, true, true>), grid, block2, shm2, st, A, T);
+                else if (key == 6) hipLaunchKernelGGL((pw_spread_duo_kernel<6, 6, true, true>), grid, block2, shm2, st, A, T);
+                else if (um) hipLaunchKernelGGL((pw_spread_duo_kernel<0, 0, true, true>), grid, block2, shm2, st, A, T);
+                else hipLaunchKernelGGL((pw_spread_duo_kernel<0, 0, false, true>), grid, block2, shm2, st, A, T);
+                PW_HIP_CHECK(hipGetLastError());
+                return PW_OK;
+            }
             switch (key) {
-#define PW_DUO_CASE(n)                                                                                       \
-    case n:                                                                                                  \
-        if (um) hipLaunchKernelGGL((pw_spread_duo_kernel<n, n, true>), grid, block2, shm2, st, A, T);        \
-        else hipLaunchKernelGGL((pw_spread_duo_kernel<n, n, false>), grid, block2, shm2, st, A, T);          \
+#define PW_DUO_CASE(n)                                                                                              \
+    case n:                                                                                                         \
+        if (um && blk) hipLaunchKernelGGL((pw_spread_duo_kernel<n, n, true, false, true>), grid, block2, shm2, st, A, T); \
+        else if (um) hipLaunchKernelGGL((pw_spread_duo_kernel<n, n, true>), grid, block2, shm2, st, A, T);          \
+        else hipLaunchKernelGGL((pw_spread_duo_kernel<n, n, false>), grid, block2, shm2, st, A, T);                 \
         break;
                 PW_DUO_CASE(3) PW_DUO_CASE(6) PW_DUO_CASE(9) PW_DUO_CASE(12) PW_DUO_CASE(24) PW_DUO_CASE(48)
 #undef PW_DUO_CASE
@@ -287,11 +308,20 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
             PW_HIP_CHECK(hipGetLastError());
             return PW_OK;
         }
+        if (wc) {
+            if (key == 3) hipLaunchKernelGGL((pw_spread_stream_kernel<3, 3, true, true>), grid, block, shm, st, A, T);
+            else if (key == 6) hipLaunchKernelGGL((pw_spread_stream_kernel<6, 6, true, true>), grid, block, shm, st, A, T);
+            else if (um) hipLaunchKernelGGL((pw_spread_stream_kernel<0, 0, true, true>), grid, block, shm, st, A, T);
+            else hipLaunchKernelGGL((pw_spread_stream_kernel<0, 0, false, true>), grid, block, shm, st, A, T);
+            PW_HIP_CHECK(hipGetLastError());
+            return PW_OK;
+        }
         switch (key) {
-#define PW_STREAM_CASE(n)                                                                                    \
-    case n:                                                                                                  \
-        if (um) hipLaunchKernelGGL((pw_spread_stream_kernel<n, n, true>), grid, block, shm, st, A, T);       \
-        else hipLaunchKernelGGL((pw_spread_stream_kernel<n, n, false>), grid, block, shm, st, A, T);         \
+#define PW_STREAM_CASE(n)                                                                                           \
+    case n:                                                                                                         \
+        if (um && blk) hipLaunchKernelGGL((pw_spread_stream_kernel<n, n, true, false, true>), grid, block, shm, st, A, T); \
+        else if (um) hipLaunchKernelGGL((pw_spread_stream_kernel<n, n, true>), grid, block, shm, st, A, T);         \
+        else hipLaunchKernelGGL((pw_spread_stream_kernel<n, n, false>), grid, block, shm, st, A, T);                \
         break;
             PW_STREAM_CASE(3) PW_STREAM_CASE(6) PW_STREAM_CASE(9) PW_STREAM_CASE(12) PW_STREAM_CASE(24) PW_STREAM_CASE(48)
 #undef PW_STREAM_CASE

@@ -7,7 +7,7 @@
 
 int main(int argc, char **argv)
 {
-    const int B = argc > 1 ? atoi(argv[1]) : 4096, N = 6, T = 25, reps = 40;
+    const int B = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 6, T = 25, reps = 40;
     pw_config cfg;
     pw_config_default(&cfg, PW_SIMPLE_SPREAD, B, N, -1, 0);
     cfg.auto_reset = 1;
@@ -42,7 +42,7 @@ int main(int argc, char **argv)
                             "obs row build + stores", "vmcnt(K) hint"};
     const char **names = duo ? names_duo : names_stream;
     double sum = 0; for (int i = 0; i < 8; ++i) sum += tot[i];
-    printf("B=%d: cycles per step (wave 0, incl. ~40/stamp overhead): %.0f\n", B, sum / ((reps - 5) * T));
+    printf("B=%d N=%d (%s kernel): cycles per step (wave 0, incl. ~40/stamp overhead): %.0f\n", B, N, duo ? "duo" : "stream", sum / ((reps - 5) * T));
     for (int i = 0; i < 8; ++i) printf("  %-36s %7.0f cycles  %5.1f%%\n", names[i], tot[i] / (double)((reps - 5) * T), 100.0 * tot[i] / sum);
     if (duo) {
         const char *on[4] = {"O: barrier wait (P behind)", "O: partner pass + reward + LDS exchanges",
