@@ -32,6 +32,8 @@ def main():
     ap.add_argument('--write')
     ap.add_argument('--kernel', default='pw_spread_stream_kernel')
     ap.add_argument('--bench')
+    ap.add_argument('--sq', nargs='*', default=[], help='directories of the SQ counter passes (SQ_INSTS_VALU, SQ_WAVES, '
+                                                       'SQ_WAVE_CYCLES, SQ_INSTS_LDS, SQ_INSTS_SALU, SQ_BUSY_CYCLES)')
     ap.add_argument('--out', default='profiles')
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -47,7 +49,9 @@ def main():
     if kt and a.bench:
         line = [l for l in open(a.bench).read().splitlines() if l.startswith('{')][-1]
         b = json.loads(line)
-        n_timed = max(1, round(b['steps'] * b['config']['global_batch'] / b['n_gpus'] / b['roofline']['env_steps_per_launch']))
+        # round 2 on: one bench step IS one launch; round-1 lines counted batched env steps
+        n_timed = b['steps'] if 'batched_env_steps_per_launch' in b['config'] else \
+            max(1, round(b['steps'] * b['config']['global_batch'] / b['n_gpus'] / b['roofline']['env_steps_per_launch']))
         durs = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp']))
                       for r in csv.DictReader(open(kt[0])) if a.kernel in r['Kernel_Name'])
         timed = [d for _, d in durs][-n_timed:]
@@ -66,6 +70,29 @@ def main():
         summ['bench'] = b
         summ['hip_event_launch_ms'] = b['roofline']['launch_ms']
         summ['rocprof_vs_hip_event'] = summ.get('timed_avg_ns', summ['avg_ns']) * 1e-6 / b['roofline']['launch_ms']
+    if a.bench:
+        # what bench.py looks up: the workload this profile belongs to, per-ENV-STEP traffic, the issue-side figures
+        cfg = b['config']
+        per_launch = b['roofline']['env_steps_per_launch']
+        summ['workload'] = dict(scenario='simple_spread' if 'simple_spread' in cfg['workload'] else 'simple_tag',
+                                N=int(cfg['workload'].split(' N=')[1].split(' ')[0]),
+                                B=int(cfg['global_batch'] // b['n_gpus']), steps_per_launch=cfg['batched_env_steps_per_launch'])
+        if 'traffic_bytes_per_launch' in summ:
+            # PMC passes ran the same launch size (bench --steps 4 --warmup 1: same --chunk)
+            summ['traffic_bytes_per_env_step'] = summ['traffic_bytes_per_launch'] / per_launch
+    if a.sq:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from pmc_table import table
+        t = {c: sum(v) / len(v) for (k, c), v in table(a.sq, a.kernel).items()}
+        summ['sq_counters_per_launch'] = t
+        if a.bench and all(k in t for k in ('SQ_INSTS_VALU', 'SQ_WAVES', 'SQ_WAVE_CYCLES')):
+            wave_steps = t['SQ_WAVES'] * summ['workload']['steps_per_launch']
+            summ['valu_insts_per_wave_step'] = t['SQ_INSTS_VALU'] / wave_steps
+            summ['clocks_per_wave_step'] = t['SQ_WAVE_CYCLES'] * 4.0 / wave_steps      # SQ cycle counters tick once per 4 clocks
+            # a wave64 VALU instruction occupies its SIMD's issue for 4 clocks
+            summ['valu_issue_share'] = 4.0 * summ['valu_insts_per_wave_step'] / summ['clocks_per_wave_step']
+            summ['sq_source'] = 'profiles/%s_summary.json (rocprofv3 --pmc SQ passes, mean over the launches of this kernel)' % a.tag
     json.dump(summ, open(os.path.join(a.out, '%s_summary.json' % a.tag), 'w'), indent=1)
     print(json.dumps(summ, indent=1)[:1500])
 
