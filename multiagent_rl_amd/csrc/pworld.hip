@@ -37,6 +37,7 @@
 #include "pw_kernels_generic.hpp"
 #include "pw_kernels_replay.hpp"
 #include "pw_kernels_policy.hpp"
+#include "pw_kernels_policy2.hpp"
 
 struct pw_handle {
     pw_config cfg;
@@ -764,8 +765,7 @@ int pw_replay_add_rollout(const pw_replay_store *st, int64_t start, int32_t B, i
 size_t pw_policy_rollout_scratch_bytes(const pw_handle *h)
 {
     if (!h) return 0;
-    const int E = 96 / h->kp.N < 16 ? 96 / h->kp.N : 16;
-    return (size_t)(2 * ((h->kp.B + E - 1) / E) + 1) * 8;
+    return (size_t)(2 * (size_t)h->kp.B + 1) * 8;  // one partial (sum, count) per workgroup; a workgroup holds >= 1 env
 }
 
 size_t pw_replay_add_rollout_scratch_bytes(int32_t B) { return (size_t)(2 * ((B + 255) / 256) + 1) * 8; }
@@ -1043,11 +1043,52 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         P.finished_count = sink->finished_count; P.scratch = static_cast<unsigned long long *>(sink->scratch);
     }
     const int S1C = (kp.D + 7) / 8, S1 = 4 * S1C;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // Two forms.  pw_policy_rollout_kernel: workgroup-wide phases, 16 envs per workgroup, LDS bounds the observation
+    // length (D <= 36).  pw_policy_rollout2_kernel (pw_kernels_policy2.hpp): role-specialised waves -- matrix cores and
+    // vector ALUs busy together, weights resident in registers -- with as many environments per workgroup as fit
+    // 160 KB of LDS, so it also serves long observation rows (D <= 64: N <= 30).  Measured at B = 4096
+    // (profiles/r2_policy_rollout.txt): N = 3: 15.4 vs 17.0 us/step; N = 6: 22.3 vs 23.4; N = 12: 69.1 vs 67.5; N = 16: 169 vs
+    // 120 -- so the second form runs where it wins (N <= 6) or where the first does not fit.  PWORLD_POLICY_V1 / PWORLD_POLICY_V2 override.
     const size_t shm = actor_lds_bytes(S1) + (size_t)kFusedRows * kp.D * sizeof(float) + kFusedRows * sizeof(int32_t) +
                        2 * kWave * sizeof(float2) + (size_t)a.E * kp.L * sizeof(float2) + 16 * (sizeof(double) + sizeof(int));
-    if (shm > 160 * 1024) return fail(PW_EINVAL, "observation too long for the one-launch rollout (LDS)");
+    const bool v1_fits = shm <= 160 * 1024;
+    bool use_v2 = !v1_fits || kp.N <= 6;
+    if (std::getenv("PWORLD_POLICY_V2")) use_v2 = true;
+    if (std::getenv("PWORLD_POLICY_V1") && v1_fits) use_v2 = false;
+    int E2 = 0;
+    if (use_v2) {
+        for (int e = a.E; e >= 1; --e)
+            if (roll2_lds_bytes(e, kp.N, kp.L, kp.D, S1) <= 160 * 1024) { E2 = e; break; }
+        if (E2 == 0 && !v1_fits) return fail(PW_EINVAL, "observation too long for the one-launch rollout (LDS)");
+    }
+    if (E2 > 0) {
+        a.E = E2;
+        const size_t shm2 = roll2_lds_bytes(E2, kp.N, kp.L, kp.D, S1);
+        const unsigned grid2 = (unsigned)((kp.B + E2 - 1) / E2);
+#define PW_R23(C, NT, SK)                                                                                                \
+    do {                                                                                                                 \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout2_kernel<C, NT, SK>),       \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL((pw_policy_rollout2_kernel<C, NT, SK>), dim3(grid2), dim3(512), shm2, st, P);                 \
+    } while (0)
+#define PW_R22(C, NT) do { if (sink) PW_R23(C, NT, true); else PW_R23(C, NT, false); } while (0)
+#define PW_R2(C) case C: PW_R22(C, 0); break;
+        if (kp.N == 6 && kp.L == 6) PW_R22(2, 6);        // BASELINE configs[1]: D = 16
+        else switch (S1C) {
+            PW_R2(1) PW_R2(2) PW_R2(3) PW_R2(4) PW_R2(5) PW_R2(6) PW_R2(7) PW_R2(8)
+        }
+#undef PW_R23
+#undef PW_R22
+#undef PW_R2
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
     const unsigned grid = (unsigned)((kp.B + a.E - 1) / a.E);
-    hipStream_t st = static_cast<hipStream_t>(stream);
 #define PW_PR3(C, NT, SK)                                                                                                \
     do {                                                                                                                 \
         static bool attr_set = false;                                                                                    \

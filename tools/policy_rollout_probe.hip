@@ -30,6 +30,7 @@ int main(int argc, char **argv)
     hipMalloc((void **)&io.rew, T * BN * 4); hipMalloc((void **)&io.rew_shared, (size_t)T * B * 4);
     hipMalloc((void **)&io.done, T * BN); hipMalloc((void **)&io.terminal, (size_t)T * B);
     pw_reset(h, nullptr, nullptr, nullptr);
+    { int dbg = argc > 2 ? atoi(argv[2]) : 0; hipMemcpyToSymbol(HIP_SYMBOL(g_pw_debug), &dbg, sizeof(dbg)); printf("debug mask %d\n", dbg); }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 2; ++i) if (pw_policy_rollout(h, frag, b1, bih, whf, whr, w2, b2, 1, 1, 0, nullptr, &io, act, T, nullptr, nullptr)) { printf("%s\n", pw_last_error()); return 1; }
     hipEventRecord(e0, 0);
@@ -39,11 +40,21 @@ int main(int argc, char **argv)
     printf("B=%d: %.2f us per step (%s)\n", B, ms * 1000.f / (5 * T), pw_last_error());
     unsigned long long s[16];
     hipMemcpyFromSymbol(s, HIP_SYMBOL(g_pw_stamps), sizeof(s));
-    const char *names[4] = {"actor pass", "barrier after actor", "env step (waves 0-1)", "barrier after env"};
-    double sum = 0; for (int i = 8; i < 12; ++i) sum += s[i];
-    for (int i = 0; i < 4; ++i) printf("  %-28s %9.0f cycles/step %5.1f%%\n", names[i], s[8 + i] / (double)T, 100.0 * s[8 + i] / sum);
-    printf("  total %.0f cycles/step\n", sum / T);
-    const char *an[8] = {"fill dir 0 + barrier", "stage 1", "fill dir 1 + barrier", "stage 2 MFMA", "barrier", "recurrence", "barrier", "head"};
-    for (int i = 0; i < 8; ++i) printf("    last actor pass: %-24s %8llu cycles\n", an[i], s[i]);
+    if (getenv("PWORLD_POLICY_V1")) {
+        const char *names[4] = {"actor pass", "barrier after actor", "env step (waves 0-1)", "barrier after env"};
+        double sum = 0; for (int i = 8; i < 12; ++i) sum += s[i];
+        for (int i = 0; i < 4; ++i) printf("  %-28s %9.0f cycles/step %5.1f%%\n", names[i], s[8 + i] / (double)T, 100.0 * s[8 + i] / sum);
+        printf("  total %.0f cycles/step\n", sum / T);
+        const char *an[8] = {"fill dir 0 + barrier", "stage 1", "fill dir 1 + barrier", "stage 2 MFMA", "barrier", "recurrence", "barrier", "head"};
+        for (int i = 0; i < 8; ++i) printf("    last actor pass: %-24s %8llu cycles\n", an[i], s[i]);
+    } else {
+        const char *mn[5] = {"matrix wave 0: stage 1 + stage 2 jobs", "  wait B1 (recurrences done)", "  head (B2, B3 inside)", "  env step", "  wait B4"};
+        const char *ln[5] = {"LSTM wave 4: waiting for row tiles", "  recurrence", "  wait B1", "  head (B2, B3 inside)", "  wait B4 (env step of waves 0-1)"};
+        double sm = 0, sl = 0; for (int i = 0; i < 5; ++i) { sm += s[i]; sl += s[8 + i]; }
+        for (int i = 0; i < 5; ++i) printf("  %-44s %9.0f cycles/step %5.1f%%\n", mn[i], s[i] / (double)T, 100.0 * s[i] / sm);
+        printf("  total %.0f cycles/step\n", sm / T);
+        for (int i = 0; i < 5; ++i) printf("  %-44s %9.0f cycles/step %5.1f%%\n", ln[i], s[8 + i] / (double)T, 100.0 * s[8 + i] / sl);
+        printf("  total %.0f cycles/step\n", sl / T);
+    }
     return 0;
 }
