@@ -348,8 +348,9 @@ typedef struct pw_rollout_sink {
  * act_out and obs, rew, rew_shared, done, terminal are required (final_obs optional); with one every output is
  * optional.  The Gumbel noise of step t is keyed (seed; step + t, row) exactly as pw_actor_fused / pw_actor_head, so
  * the results equal a loop of pw_actor_fused + pw_step (+ pw_replay_add_tail).
- * simple_spread fast-path configurations (local observation, homogeneous agents, L <= N), one 5-logit head;
- * weights as for pw_actor_fused. */
+ * simple_spread fast-path configurations (local observation, homogeneous agents, L <= N; observation rows up to
+ * D = 64, i.e. N <= 30) and simple_tag with homogeneous roles (9 <= D <= 48; good agents' rows zero-padded to D), one
+ * 5-logit head; weights as for pw_actor_fused. */
 int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
                       const float *w_hh_bw, const float *w2, const float *b2, int32_t relu_out, uint64_t seed,
                       uint64_t step, const int64_t *step_dev /* device, or NULL */, const pw_step_io *io,

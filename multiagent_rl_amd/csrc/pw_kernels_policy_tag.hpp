@@ -1,0 +1,285 @@
+// pw_kernels_policy_tag.hpp -- part of libpworld.so (one translation unit: csrc/pworld.hip includes it).
+// Policy-in-the-loop rollout for simple_tag (BASELINE configs[2]): pw_policy_rollout_kernel's structure (actor pass
+// of the whole workgroup, then the first waves advance the environments) with pw_tag_stream_kernel's arithmetic.
+#pragma once
+
+namespace {
+
+struct PolicyRolloutTagArgs {
+    ActorFusedArgs A;   // weights, B, N, D, E, heads, seed, step / step_dev (Philox step of the FIRST pass)
+    TagParams V;        // world constants (2x2 class tables), state planes, outputs (V.act unused)
+    int T;
+    int32_t *act_out;   // [T,B,N] sampled action indices (or NULL)
+    pw_replay_store ring;
+    int has_ring;
+    int64_t ring_start;
+    float *episode_return;
+    double *finished_sum;
+    int64_t *finished_count;
+    unsigned long long *scratch;
+};
+
+__host__ __device__ inline size_t policy_tag_lds_bytes(int S1, int D, int E, int L)
+{
+    return actor_lds_bytes(S1) + (size_t)kFusedRows * D * sizeof(float) + kFusedRows * sizeof(int32_t) +
+           4 * kWave * sizeof(float2) + (size_t)E * L * sizeof(float2) + 3 * 2 * kWave * sizeof(float) +
+           16 * (sizeof(double) + sizeof(int));
+}
+
+// One 5-logit head per agent: every agent of simple_tag takes the same five movement actions; the observation rows
+// of the good agents are zero-padded to the adversaries' width D (as every simple_tag kernel here writes them).
+template <int S1C, bool SINK>
+__global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const PolicyRolloutTagArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const ActorFusedArgs &A = P.A;
+    const TagParams &V = P.V;
+    const ActorLds S = actor_carve(smem_raw, 4 * S1C);
+    const int N = A.N, L = V.L, D = A.D, NA = V.A;
+    float *s_obs = reinterpret_cast<float *>(S.end);                       // [96][D] observation rows
+    int32_t *s_act = reinterpret_cast<int32_t *>(s_obs + kFusedRows * D);  // [96]
+    float2 *s_posb = reinterpret_cast<float2 *>(s_act + kFusedRows);       // [2 env waves][64]
+    float2 *s_velb = s_posb + 2 * kWave;                                   // [2][64]
+    float2 *s_lmb = s_velb + 2 * kWave;                                    // [E * L]
+    uint32_t *s_mlob = reinterpret_cast<uint32_t *>(s_lmb + A.E * L);      // [2][64] collision masks, low / high words
+    uint32_t *s_mhib = s_mlob + 2 * kWave;
+    float *s_rewb = reinterpret_cast<float *>(s_mhib + 2 * kWave);         // [2][64]
+    double *s_fs = reinterpret_cast<double *>(s_rewb + 2 * kWave);         // [16] (+ [16] ints)
+    int *s_fc = reinterpret_cast<int *>(s_fs + 16);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long env0 = (long)blockIdx.x * A.E;
+    const int envs_here = (int)((long)A.B - env0 < (long)A.E ? (long)A.B - env0 : (long)A.E);
+    const int rows_here = envs_here * N;
+    const long row_base = env0 * N;
+    const size_t BN = (size_t)A.B * N;
+
+    const int epw_max = A.E < kWave / N ? A.E : kWave / N;
+    const int waves_full = (A.E + epw_max - 1) / epw_max;
+    const int epw = (A.E + waves_full - 1) / waves_full;
+    const int n_env_waves = (envs_here + epw - 1) / epw;
+    const bool env_wave = wave < n_env_waves;
+    int e_loc = lane / N, a = lane - e_loc * N;
+    int el = wave * epw + e_loc;
+    const bool live = env_wave && e_loc < epw && el < envs_here;
+    if (!live) { e_loc = 0; a = 0; el = env_wave ? wave * epw : 0; }  // idle lanes shadow lane 0, store nothing
+    const int base = e_loc * N, me = base + a, r = el * N + a;
+    const long env = env0 + el;
+    const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
+    const int ew = env_wave ? wave : 0;
+    float2 *s_pos = s_posb + ew * kWave, *s_vel = s_velb + ew * kWave;
+    uint32_t *s_mlo = s_mlob + ew * kWave, *s_mhi = s_mhib + ew * kWave;
+    float *s_rew = s_rewb + ew * kWave;
+    const float2 *pp = s_pos + base, *vv = s_vel + base;
+    float2 *lmv = s_lmb + el * L;
+    const int cls = a >= NA ? 1 : 0;
+    const uint64_t env_id = V.env_id_base + (uint64_t)env;
+    const uint64_t adv_bits = NA >= 64 ? ~0ull : ((1ull << NA) - 1ull);
+    const float my_sens = V.sens[cls], my_fscale = V.fscale[cls], my_maxspeed = V.max_speed[cls];
+    const float dmin_adv = V.dist_min[cls][0], dmin_good = V.dist_min[cls][1], dmin_lm = V.dist_min_lm[cls];
+    const float cthr_adv = V.coll_thr2[cls][0], cthr_good = V.coll_thr2[cls][1];
+    const float nthr_adv = V.near_thr2[cls][0], nthr_good = V.near_thr2[cls][1], nthr_lm = V.near_thr2_lm[cls];
+
+    float px = 0.f, py = 0.f, vx = 0.f, vy = 0.f;
+    int ep_step = 0;
+    uint32_t ep_count = 0;
+    uint64_t coll = 0, near_a = 0, near_l = 0;
+    float ep_ret = 0.f;
+    double fin_sum = 0.0;
+    int fin_cnt = 0;
+    auto partner_pass = [&]() {
+        coll = 0; near_a = 0; near_l = 0;
+        for (int j = 0; j < N; ++j) {
+            const float2 q = pp[j];
+            const float dx = q.x - px, dy = q.y - py;
+            const float d2 = dx * dx + dy * dy;
+            const bool jg = j >= NA;
+            if (d2 < (jg ? cthr_good : cthr_adv)) coll |= 1ull << j;
+            if (bits_near(d2, jg ? nthr_good : nthr_adv)) near_a |= 1ull << j;
+        }
+        near_a &= ~(1ull << a);
+        for (int l = 0; l < L; ++l) {
+            const float2 q = lmv[l];
+            const float dx = q.x - px, dy = q.y - py;
+            if (bits_near(dx * dx + dy * dy, nthr_lm)) near_l |= 1ull << l;
+        }
+    };
+    if (env_wave) {
+        if (SINK && P.episode_return && live && a == 0) ep_ret = P.episode_return[env];
+        px = V.pos_x[g]; py = V.pos_y[g]; vx = V.vel_x[g]; vy = V.vel_y[g];
+        ep_step = V.ep_step[env];
+        ep_count = V.ep_count[env];
+        if (live)
+            for (int l = a; l < L; l += N) lmv[l] = make_float2(V.lm_x[(size_t)env * L + l], V.lm_y[(size_t)env * L + l]);
+        if (live) { s_pos[me] = make_float2(px, py); s_vel[me] = make_float2(vx, vy); }
+        wave_lds_sync();
+        partner_pass();
+        if (live) tag_write_obs<0, -1, 0>(s_obs + r * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+    }
+    const float k = V.contact_margin, cf = V.contact_force, dt = V.dt, damp = V.damp, mass = V.mass;
+    const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
+    wg_lds_barrier();
+
+    for (int t = 0; t < P.T; ++t) {
+        actor_forward_wg<S1C>(A, S, s_obs, rows_here, envs_here, row_base, t == 0, t == 0, step0 + (uint64_t)t, nullptr,
+                              s_act);
+        wg_lds_barrier();
+        if (env_wave) {
+            const size_t tBN = (size_t)t * BN;
+            const int ai = s_act[r];
+            size_t slot = 0;
+            if (SINK && P.has_ring) {  // the observation the policy acted on (still in LDS) -> ring.obs
+                slot = (size_t)((P.ring_start + (int64_t)t * A.B + env) % P.ring.capacity);
+                if (live) {
+                    const float2 *src = reinterpret_cast<const float2 *>(s_obs + r * D);
+                    float2 *dst = reinterpret_cast<float2 *>(P.ring.obs + (slot * N + a) * D);
+                    for (int c = 0; c < D / 2; ++c) dst[c] = src[c];
+                    P.ring.act[slot * N + a] = (uint8_t)ai;
+                }
+            }
+            float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
+            float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
+            ux *= my_sens; uy *= my_sens;
+            if (my_fscale != 1.0f) { ux = my_fscale * ux; uy = my_fscale * uy; }
+            float fx = ux + 0.0f, fy = uy + 0.0f;
+            // U5: near agents (ascending j), then near landmarks (ascending l): upstream's entity order
+            for (uint64_t m = live ? near_a : 0; m; m &= m - 1) {
+                const int j = __builtin_ctzll(m);
+                const float2 q = pp[j];
+                collision_force<true>(px, py, q.x, q.y, j >= NA ? dmin_good : dmin_adv, k, cf, fx, fy);
+            }
+            for (uint64_t m = live ? near_l : 0; m; m &= m - 1) {
+                const float2 q = lmv[__builtin_ctzll(m)];
+                collision_force<true>(px, py, q.x, q.y, dmin_lm, k, cf, fx, fy);
+            }
+            // U6 with the max_speed clamp
+            vx = vx * damp; vy = vy * damp;
+            vx = vx + (fx / mass) * dt;
+            vy = vy + (fy / mass) * dt;
+            if (my_maxspeed >= 0.0f) {
+                const float speed = sqrtf(vx * vx + vy * vy);
+                if (speed > my_maxspeed) {
+                    vx = vx / speed * my_maxspeed;
+                    vy = vy / speed * my_maxspeed;
+                }
+            }
+            px = px + vx * dt;
+            py = py + vy * dt;
+            wave_lds_sync();
+            if (live) { s_pos[me] = make_float2(px, py); s_vel[me] = make_float2(vx, vy); }
+            wave_lds_sync();
+            partner_pass();
+            // simple_tag.reward
+            if (live) { s_mlo[me] = (uint32_t)coll; s_mhi[me] = (uint32_t)(coll >> 32); }
+            wave_lds_sync();
+            float rw = 0.0f;
+            if (cls) {
+                for (int q = 0; q < NA; ++q)
+                    if ((coll >> q) & 1) rw -= 10.0f;
+                rw -= tag_bound(fabsf(px));
+                rw -= tag_bound(fabsf(py));
+            } else {
+                for (int gj = NA; gj < N; ++gj) {
+                    const uint64_t mg = ((uint64_t)s_mhi[base + gj] << 32) | s_mlo[base + gj];
+                    rw += 10.0f * (float)__builtin_popcountll(mg & adv_bits);
+                }
+            }
+            if (live) s_rew[me] = rw;
+            wave_lds_sync();
+            float acc = 0.0f;
+            for (int i = 0; i < N; ++i) acc += s_rew[base + i];
+            ep_step += 1;
+            const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
+            if (live) {
+                if (P.act_out) P.act_out[tBN + g] = ai;
+                if (V.rew) V.rew[tBN + g] = rw;
+                if (V.done) V.done[tBN + g] = 0;
+                if (a == 0) {
+                    if (V.rew_shared) V.rew_shared[(size_t)t * A.B + env] = acc;
+                    if (V.terminal) V.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+                }
+                if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
+                    tag_write_obs<0, -1, 0>(P.ring.next_obs + (slot * N + a) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                    if (a == 0) { P.ring.rew[slot] = acc; P.ring.done[slot] = 0.0f; }
+                }
+                if (SINK && a == 0 && P.episode_return) {
+                    const float rsum = ep_ret + acc;
+                    if (term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
+                    else ep_ret = rsum;
+                }
+            }
+            if (term && V.auto_reset) {  // same for every lane of an env
+                if (live && V.final_obs)
+                    tag_write_obs<0, -1, 0>(V.final_obs + (tBN + g) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                wave_lds_sync();
+                ep_count += 1;
+                ep_step = 0;
+                pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
+                vx = 0.f; vy = 0.f;
+                if (live)
+                    for (int l = a; l < L; l += N) {
+                        float x, y;
+                        pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)(N + l), -0.9f, 0.9f, &x, &y);
+                        lmv[l] = make_float2(x, y);
+                    }
+                if (live) { s_pos[me] = make_float2(px, py); s_vel[me] = make_float2(0.f, 0.f); }
+            }
+            wave_lds_sync();
+            if (V.auto_reset && __any(term)) partner_pass();
+            if (live) {
+                if (V.obs) tag_write_obs<0, -1, 0>(V.obs + (tBN + g) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                tag_write_obs<0, -1, 0>(s_obs + r * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+            }
+        } else if (t + 1 < P.T) {
+            const int nw = 8 - n_env_waves;
+            actor_fill_dir(A, S, 0, tid - n_env_waves * kWave, nw * kWave);
+        }
+        wg_lds_barrier();
+    }
+
+    if (live) {
+        V.pos_x[g] = px; V.pos_y[g] = py;
+        V.vel_x[g] = vx; V.vel_y[g] = vy;
+        for (int l = a; l < L; l += N) {
+            const float2 q = lmv[l];
+            V.lm_x[(size_t)env * L + l] = q.x;
+            V.lm_y[(size_t)env * L + l] = q.y;
+        }
+        if (a == 0) {
+            V.ep_step[env] = ep_step;
+            V.ep_count[env] = ep_count;
+            if (SINK && P.episode_return) P.episode_return[env] = ep_ret;
+        }
+    }
+    if (SINK && P.episode_return) {
+        wg_lds_barrier();
+        if (live && a == 0) { s_fs[el] = fin_sum; s_fc[el] = fin_cnt; }
+        wg_lds_barrier();
+        if (tid == 0) {
+            double ws = 0.0;
+            long long wc = 0;
+            for (int i = 0; i < envs_here; ++i) { ws += s_fs[i]; wc += s_fc[i]; }
+            double *part_sum = reinterpret_cast<double *>(P.scratch);
+            long long *part_cnt = reinterpret_cast<long long *>(P.scratch + gridDim.x);
+            unsigned long long *ticket = P.scratch + 2 * gridDim.x;
+            part_sum[blockIdx.x] = ws;
+            part_cnt[blockIdx.x] = wc;
+            __threadfence();
+            if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1) {
+                __threadfence();
+                double ssum = 0.0;
+                long long scnt = 0;
+                for (unsigned i = 0; i < gridDim.x; ++i) {
+                    ssum += __builtin_nontemporal_load(part_sum + i);
+                    scnt += __builtin_nontemporal_load(part_cnt + i);
+                }
+                *P.finished_sum += ssum;
+                *P.finished_count += scnt;
+                *ticket = 0;
+            }
+        }
+    }
+}
+
+}  // namespace

@@ -38,6 +38,7 @@
 #include "pw_kernels_replay.hpp"
 #include "pw_kernels_policy.hpp"
 #include "pw_kernels_policy2.hpp"
+#include "pw_kernels_policy_tag.hpp"
 
 struct pw_handle {
     pw_config cfg;
@@ -996,9 +997,10 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     if (!frag || !b1 || !b_ih || !w_hh_fw || !w_hh_bw || !w2 || !b2 || !io) return fail(PW_EINVAL, "null argument");
     if (num_steps < 1) return fail(PW_EINVAL, "num_steps must be >= 1");
     const KParams &kp = h->kp;
-    if (!h->fast)
+    const bool tag = h->cfg.scenario == PW_SIMPLE_TAG && h->tag_fast;
+    if (!h->fast && !tag)
         return fail(PW_EINVAL, "pw_policy_rollout serves the simple_spread fast-path configurations (local observation, "
-                               "homogeneous agents, L <= N)");
+                               "homogeneous agents, L <= N) and simple_tag with homogeneous roles");
     if (kp.N > 64 || kp.D > 64) return fail(PW_EINVAL, "N and the observation length must be <= 64");
     if (io->act_idx || io->act_vec || io->act_comm || io->coll)
         return fail(PW_EINVAL, "pw_policy_rollout produces the actions itself (act_out) and has no coll output");
@@ -1017,6 +1019,49 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
          reinterpret_cast<uintptr_t>(w_hh_fw) | reinterpret_cast<uintptr_t>(w_hh_bw) |
          (have_sink ? reinterpret_cast<uintptr_t>(sink->ring->next_obs) | reinterpret_cast<uintptr_t>(sink->ring->obs) : 0)) & 15)
         return fail(PW_EINVAL, "obs, final_obs, frag, w_hh and the ring planes must be 16-byte aligned");
+    if (tag) {
+        PolicyRolloutTagArgs Q;
+        std::memset(&Q, 0, sizeof(Q));
+        ActorFusedArgs &qa = Q.A;
+        qa.frag = frag; qa.b1 = b1; qa.bih = b_ih; qa.whh_f = w_hh_fw; qa.whh_r = w_hh_bw; qa.w2 = w2; qa.b2 = b2;
+        qa.B = kp.B; qa.N = kp.N; qa.D = kp.D; qa.relu_out = relu_out; qa.n_out0 = 5; qa.n_out1 = 0;
+        qa.E = 96 / kp.N < 16 ? 96 / kp.N : 16;
+        qa.seed = seed; qa.step = step; qa.step_dev = step_dev;
+        Q.V = h->tp;
+        TagParams &tv = Q.V;
+        tv.pos_x = kp.pos_x; tv.pos_y = kp.pos_y; tv.vel_x = kp.vel_x; tv.vel_y = kp.vel_y;
+        tv.lm_x = kp.lm_x; tv.lm_y = kp.lm_y; tv.ep_step = kp.ep_step; tv.ep_count = kp.ep_count;
+        tv.obs = io->obs; tv.final_obs = io->final_obs; tv.rew = io->rew; tv.rew_shared = io->rew_shared;
+        tv.done = io->done; tv.terminal = io->terminal;
+        Q.T = num_steps; Q.act_out = act_out;
+        if (have_sink) { Q.ring = *sink->ring; Q.has_ring = 1; Q.ring_start = sink->ring_start; }
+        if (sink && sink->episode_return) {
+            Q.episode_return = sink->episode_return; Q.finished_sum = sink->finished_sum;
+            Q.finished_count = sink->finished_count; Q.scratch = static_cast<unsigned long long *>(sink->scratch);
+        }
+        const int tS1C = (kp.D + 7) / 8;
+        const size_t tshm = policy_tag_lds_bytes(4 * tS1C, kp.D, qa.E, kp.L);
+        if (tshm > 160 * 1024 || tS1C < 2 || tS1C > 6)
+            return fail(PW_EINVAL, "simple_tag one-launch rollout: observation length must be in [9, 48] and fit the LDS");
+        const unsigned tgrid = (unsigned)((kp.B + qa.E - 1) / qa.E);
+        hipStream_t tst = static_cast<hipStream_t>(stream);
+#define PW_TG3(C, SK)                                                                                                    \
+    do {                                                                                                                 \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_tag_kernel<C, SK>),        \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL((pw_policy_rollout_tag_kernel<C, SK>), dim3(tgrid), dim3(512), tshm, tst, Q);                 \
+    } while (0)
+#define PW_TG(C) case C: if (sink) PW_TG3(C, true); else PW_TG3(C, false); break;
+        switch (tS1C) { PW_TG(2) PW_TG(3) PW_TG(4) PW_TG(5) PW_TG(6) }
+#undef PW_TG3
+#undef PW_TG
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
     PolicyRolloutArgs P;
     std::memset(&P, 0, sizeof(P));
     ActorFusedArgs &a = P.A;

@@ -256,7 +256,7 @@ class BatchedRollout(object):
         runs policy + sampling + env step for the whole chunk with observations / actions / world state resident on
         the CU, and writes the transitions straight into the replay ring and the episode statistics from the same
         kernel (``pw_rollout_sink``).  ``keep_outputs=True`` also materialises the chunk's [T, ...] step outputs
-        (``self.last_chunk``).  Needs a FusedActor and a simple_spread fast-path env; stores exactly what ``collect``
+        (``self.last_chunk``).  Needs a FusedActor and a simple_spread fast-path (or homogeneous-role simple_tag) env; stores exactly what ``collect``
         stores (statistics up to float64 summation order)."""
         assert self._graph is None and hasattr(self.policy, 'rollout')
         stats = (self.episode_return, self.finished_return_sum, self.finished_episodes)

@@ -778,3 +778,53 @@ def test_batched_rollout_multidiscrete_feeds_a_two_head_ring():
     assert torch.equal(o, first) and a.shape == (B, 2, 15)
     assert (a[..., :5].sum(-1) == 1).all() and (a[..., 5:].sum(-1) == 1).all() and not d.any()
     assert mem.act.shape == (B * 40, 2, 2) and int(mem.act[:30 * B, :, 1].max()) > 4      # symbols use the 10-wide head
+
+
+@pytest.mark.parametrize('B,adv,good,T', [(8192, 4, 2, 27), (100, 3, 1, 55), (37, 2, 3, 30)])
+def test_one_launch_policy_rollout_simple_tag_equals_the_step_loop(B, adv, good, T):
+    """BASELINE configs[2] with the policy in the loop: pw_policy_rollout on simple_tag (4 adversaries + 2 good agents,
+    B = 8192 at full size; the canonical 3+1; a 2+3 roster) vs the loop of FusedActor() + env.step(): identical
+    sampled actions, observations (ragged rows zero-padded), rewards, terminals, pre-reset observations, final state."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    from multiagent_rl_amd.rollout import BatchedRollout
+    torch.manual_seed(5)
+    mk = lambda: make_batched_env('simple_tag', B, num_adversaries=adv, num_good=good, auto_reset=True,  # noqa: E731
+                                  max_episode_len=25, seed=31)
+    env_a, env_b = mk(), mk()
+    N = adv + good
+    actor = ActorNetwork(env_a.obs_dim, 5).cuda().eval()
+    loop, one = FusedActor(actor, seed=9), FusedActor(actor, seed=9)
+    obs = env_a.reset()
+    env_b.reset()
+    want = dict(obs=[], act=[], rew=[], rew_shared=[], terminal=[], final_obs=[])
+    for t in range(T):
+        act = loop(obs)
+        obs, rew, done, info = env_a.step(act)
+        for k, v in (('obs', obs), ('act', act), ('rew', rew), ('rew_shared', info['rew_shared']),
+                     ('terminal', info['terminal']), ('final_obs', info['final_obs'])):
+            want[k].append(v.clone())
+    got = one.rollout(env_b, T)
+    for k in ('act', 'obs', 'rew', 'rew_shared', 'terminal'):
+        assert torch.equal(got[k], torch.stack(want[k])), k
+    term = got['terminal']
+    assert term.any() and torch.equal(got['final_obs'][term], torch.stack(want['final_obs'])[term])
+    sa, sb = env_a.get_state(), env_b.get_state()
+    for k in ('pos', 'vel', 'landmarks', 'ep_step', 'ep_count'):
+        assert torch.equal(sa[k], sb[k]), k
+    assert got['act'].shape == (T, B, N) and int(got['act'].max()) == 4 and got['rew'].abs().sum() > 0
+    # the ring sink: collect_one_launch == collect on the same scenario
+    if B <= 100:
+        res = []
+        for one_launch in (False, True):
+            env = mk()
+            mem = ReplayBuffer(B * 60, N, env.obs_dim)
+            ro = BatchedRollout(env, FusedActor(actor, seed=7), mem)
+            ro.collect_one_launch(40, chunk=17) if one_launch else ro.collect(40)
+            st = ro.stats()
+            res.append((mem.obs[:40 * B].clone(), mem.next_obs[:40 * B].clone(), mem.act[:40 * B].clone(),
+                        mem.rew[:40 * B].clone(), ro.episode_return.clone(), st['episodes'], st['mean_episode_reward']))
+        for x, y in zip(res[0][:5], res[1][:5]):
+            assert torch.equal(x, y)
+        assert res[0][5] == res[1][5] == B and abs(res[0][6] - res[1][6]) < 1e-9 * max(1.0, abs(res[0][6]))

@@ -19,10 +19,15 @@ ap.add_argument('--agents', default='6')
 ap.add_argument('--chunk', type=int, default=100)
 ap.add_argument('--steps', type=int, default=1000)
 ap.add_argument('--no-sink', action='store_true')
+ap.add_argument('--scenario', default='simple_spread', help="simple_spread, or simple_tag (4 adversaries + 2 good; --agents ignored)")
 a = ap.parse_args()
 for N in [int(x) for x in a.agents.split(',')]:
     torch.manual_seed(0)
-    env = BatchedParticleEnv('simple_spread', a.envs, num_agents=N, max_episode_len=25, auto_reset=True, seed=1)
+    if a.scenario == 'simple_tag':
+        env = BatchedParticleEnv('simple_tag', a.envs, num_adversaries=4, num_good=2, max_episode_len=25, auto_reset=True, seed=1)
+        N = env.n
+    else:
+        env = BatchedParticleEnv('simple_spread', a.envs, num_agents=N, max_episode_len=25, auto_reset=True, seed=1)
     actor = FusedActor(ActorNetwork(env.obs_dim, 5).cuda().eval(), seed=2)
     if a.no_sink:
         env.reset()
@@ -42,5 +47,5 @@ for N in [int(x) for x in a.agents.split(',')]:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     n = a.steps // a.chunk * a.chunk
-    print('B=%d N=%d D=%d %s: %.2f us/step  %.3e env-steps/s' % (a.envs, N, env.obs_dim, 'no sink' if a.no_sink else 'ring sink',
+    print(a.scenario + ' B=%d N=%d D=%d %s: %.2f us/step  %.3e env-steps/s' % (a.envs, N, env.obs_dim, 'no sink' if a.no_sink else 'ring sink',
                                                               dt / n * 1e6, a.envs * n / dt), flush=True)
