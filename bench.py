@@ -214,6 +214,9 @@ def main():
     ap.add_argument('--batch-size', type=int, default=1024, help='replay rows gathered per sampled exchange (N > 1)')
     ap.add_argument('--policy-steps', type=int, default=1000, help='batched env steps of the policy-in-the-loop extra')
     ap.add_argument('--policy-chunk', type=int, default=100, help='steps per pw_policy_rollout launch')
+    ap.add_argument('--exit-timeout', type=int, default=30, help='seconds the closing barrier may take (N > 1)')
+    ap.add_argument('--policy-timeout', type=int, default=240, help='seconds after which the policy-in-the-loop extra is '
+                                                                    'abandoned (the line is printed without it)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -369,16 +372,25 @@ def main():
         finite = finite and bool(last_view['terminal'][s_term].all().item())
 
     # ---- policy in the loop ("report policy-in-the-loop separately"; never part of `value`) ----
+    # The headline is measured at this point.  The extra below must never cost the run its ONE JSON line: a watchdog
+    # thread prints the line without the extra and ends the process if the extra does not return in time (a peer that
+    # died inside a point-to-point exchange would otherwise leave the root waiting in a device synchronisation, which no
+    # Python exception or signal handler can interrupt).
+    line_holder = {}
     policy_line = None
+    watchdog = None
     if args.scenario == 'simple_spread' and not os.environ.get('PW_BENCH_NO_POLICY'):
-        try:
-            del outs, acts, slots, last_view
-            if not STUB:
-                torch.cuda.empty_cache()
-            policy_line = policy_in_loop(args, env if STUB else None, rank, world, dev, use_dist, sync)
-        except Exception as e:  # the headline must not depend on this extra
-            policy_line = dict(error=repr(e)[:300])
+        import threading
 
+        def _give_up():
+            if rank == 0 and 'line' in line_holder:
+                ln = dict(line_holder['line'])
+                ln['policy_in_loop'] = dict(error='the policy-in-the-loop extra did not finish within %d s; headline unaffected'
+                                            % args.policy_timeout)
+                print(json.dumps(ln), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.policy_timeout + (0 if rank == 0 else 10), _give_up)
+        watchdog.daemon = True
     if rank == 0:
         value = world * B * T * K / elapsed
         if args.scenario == 'simple_spread' and N == 6 and env.num_landmarks == 6:
@@ -419,11 +431,33 @@ def main():
         }
         if world == 1:
             line['cpu_baseline'] = cpu_line
+        line_holder['line'] = line
+    if watchdog is not None:
+        watchdog.start()
+        try:
+            del outs, acts, slots, last_view
+            if not STUB:
+                torch.cuda.empty_cache()
+            policy_line = policy_in_loop(args, env if STUB else None, rank, world, dev, use_dist, sync)
+        except Exception as e:  # the headline must not depend on this extra
+            policy_line = dict(error=repr(e)[:300])
+        watchdog.cancel()
+    if rank == 0:
+        line = line_holder['line']
         line['policy_in_loop'] = policy_line
         print(json.dumps(line), flush=True)
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        # the line is out; a peer that died must not keep this process (and the launcher) alive in the closing barrier
+        import threading
+        bye = threading.Timer(args.exit_timeout, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # a peer already left (e.g. through its watchdog): nothing left to do but exit cleanly
+            pass
+        bye.cancel()
 
 
 def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
@@ -485,6 +519,8 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
         if actor is not None:
             actor.rollout(penv, Tp, out)
         else:
+            if os.environ.get('PW_BENCH_STUB_FAIL_RANK') == str(rank) and k >= 2:  # tests: a rank dies mid-exchange
+                raise RuntimeError('injected failure on rank %d' % rank)
             penv.stub_policy_chunk(out, k)
             time.sleep(2e-4)
         full(obs0)

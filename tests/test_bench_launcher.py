@@ -64,6 +64,21 @@ def test_bench_under_torchrun_env_does_not_relaunch():
     assert line['policy_in_loop']['gather']['transitions_ingested_root'] == 4 * 50
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.skipif(torch.cuda.device_count() > 0, reason='CPU-container test (stub kernel, gloo)')
+def test_a_dying_peer_in_the_policy_extra_does_not_cost_the_line():
+    """Rank 1 dies inside the full-gather extra; the root would wait for its block for ever.  The watchdog prints the
+    (already measured) headline line without the extra and every process exits 0."""
+    p, lines = _run(['--gpus', '2', '--steps', '4', '--warmup', '1', '--envs', '8', '--agents', '3', '--chunk', '50',
+                     '--batch-size', '8', '--policy-steps', '400', '--policy-chunk', '50', '--policy-timeout', '6',
+                     '--exit-timeout', '4'], extra_env=dict(PW_BENCH_STUB_FAIL_RANK='1'), timeout=200)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['config']['exchange']['error'] is None
+    assert 'did not finish' in line['policy_in_loop']['error']
+
+
 def test_self_launch_command_line():
     """The child command is torch.distributed.run on 127.0.0.1 with the same arguments; built without torch."""
     sys.path.insert(0, ROOT)
