@@ -38,9 +38,10 @@
  *   (The B = 1 compatibility env instead draws from NumPy's global legacy stream on
  *   the host, as upstream reset_world does -- main.py:47 -- and uploads via pw_set_state.)
  *
- * Numerics: IEEE float32, no FMA contraction, correctly rounded / and sqrt, and
- *   a libm-free deterministic softplus/exp (definitions: pworld_math.h).  A CPU
- *   implementation following pworld_math.h reproduces every output bit for bit.
+ * Numerics: IEEE float32, no IMPLICIT FMA contraction, correctly rounded / and sqrt, and
+ *   a libm-free deterministic softplus/exp whose polynomial steps are explicit fmaf (definitions:
+ *   pworld_math.h, revision 2).  A CPU implementation following pworld_math.h reproduces every
+ *   output bit for bit.
  */
 #ifndef PWORLD_H
 #define PWORLD_H

@@ -130,18 +130,17 @@ __device__ __forceinline__ float softplus_branchless(float x)
     const float m = x > 0.0f ? x : 0.0f;
     const float t0 = -ax;                       // <= 0, or NaN
     const float tc = t0 > -87.0f ? t0 : -86.0f;  // keep the exponent arithmetic in range when cut
-    float t = tc * 1.44269504088896341f;
-    float n = floorf(t + 0.5f);
-    float r = tc - n * 0.693359375f;
-    r = r - n * -2.12194440054690583e-4f;
+    float n = floorf(__builtin_fmaf(tc, 1.44269504088896341f, 0.5f));
+    float r = __builtin_fmaf(n, -0.693359375f, tc);
+    r = __builtin_fmaf(n, 2.12194440054690583e-4f, r);
     float p = 1.98412698412698413e-4f;
-    p = p * r + 1.38888888888888894e-3f;
-    p = p * r + 8.33333333333333322e-3f;
-    p = p * r + 4.16666666666666644e-2f;
-    p = p * r + 1.66666666666666657e-1f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
+    p = __builtin_fmaf(p, r, 1.38888888888888894e-3f);
+    p = __builtin_fmaf(p, r, 8.33333333333333322e-3f);
+    p = __builtin_fmaf(p, r, 4.16666666666666644e-2f);
+    p = __builtin_fmaf(p, r, 1.66666666666666657e-1f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
     const int32_t e = (int32_t)n + 127;
     float ex = p * __uint_as_float((uint32_t)e << 23);
     ex = t0 > -87.0f ? ex : (t0 != t0 ? t0 : 0.0f);  // pw_exp: x <= -87 -> +0, NaN -> NaN
@@ -160,18 +159,17 @@ __device__ __forceinline__ float softplus_fastdiv(float x)
     const float m = x > 0.0f ? x : 0.0f;
     const float t0 = -ax;
     const float tc = t0 > -87.0f ? t0 : -86.0f;
-    float t = tc * 1.44269504088896341f;
-    float n = floorf(t + 0.5f);
-    float r = tc - n * 0.693359375f;
-    r = r - n * -2.12194440054690583e-4f;
+    float n = floorf(__builtin_fmaf(tc, 1.44269504088896341f, 0.5f));
+    float r = __builtin_fmaf(n, -0.693359375f, tc);
+    r = __builtin_fmaf(n, 2.12194440054690583e-4f, r);
     float p = 1.98412698412698413e-4f;
-    p = p * r + 1.38888888888888894e-3f;
-    p = p * r + 8.33333333333333322e-3f;
-    p = p * r + 4.16666666666666644e-2f;
-    p = p * r + 1.66666666666666657e-1f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
+    p = __builtin_fmaf(p, r, 1.38888888888888894e-3f);
+    p = __builtin_fmaf(p, r, 8.33333333333333322e-3f);
+    p = __builtin_fmaf(p, r, 4.16666666666666644e-2f);
+    p = __builtin_fmaf(p, r, 1.66666666666666657e-1f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
     const int32_t e = (int32_t)n + 127;
     float ex = p * __uint_as_float((uint32_t)e << 23);
     ex = t0 > -87.0f ? ex : (t0 != t0 ? t0 : 0.0f);
@@ -181,13 +179,13 @@ __device__ __forceinline__ float softplus_fastdiv(float x)
     sq = den == 2.0f ? ex * 0.5f : sq;
     const float z = sq * sq;
     float q = 6.66666666666666657e-2f;
-    q = q * z + 7.69230769230769273e-2f;
-    q = q * z + 9.09090909090909116e-2f;
-    q = q * z + 1.11111111111111105e-1f;
-    q = q * z + 1.42857142857142849e-1f;
-    q = q * z + 0.2f;
-    q = q * z + 3.33333333333333315e-1f;
-    q = q * z + 1.0f;
+    q = __builtin_fmaf(q, z, 7.69230769230769273e-2f);
+    q = __builtin_fmaf(q, z, 9.09090909090909116e-2f);
+    q = __builtin_fmaf(q, z, 1.11111111111111105e-1f);
+    q = __builtin_fmaf(q, z, 1.42857142857142849e-1f);
+    q = __builtin_fmaf(q, z, 0.2f);
+    q = __builtin_fmaf(q, z, 3.33333333333333315e-1f);
+    q = __builtin_fmaf(q, z, 1.0f);
     return m + 2.0f * sq * q;
 }
 

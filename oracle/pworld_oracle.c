@@ -6,7 +6,8 @@
  *          package the reference imports (experiments/scenarios.py:2-3) --
  *          libm exp/log1p, i.e. np.logaddexp's stable form.
  *   *_f32  the SAME operation order in IEEE float32 with a deterministic,
- *          libm-free softplus/exp (only + - * / sqrt, no FMA contraction), so
+ *          libm-free softplus/exp (only + - * / sqrt and explicit fmaf steps -- include/pworld_math.h
+ *          revision 2 --, no implicit FMA contraction), so
  *          the HIP kernels can be compared BIT FOR BIT, integer collision
  *          masks included.
  *
@@ -76,18 +77,17 @@ PO_EXPORT float po_exp_det_f32(float x)
 {
     if (!(x > -87.0f)) return x != x ? x : 0.0f;
     if (x >= 88.0f) return po_u2f(0x7f000000u);
-    float t = x * 1.44269504088896341f;
-    float n = floorf(t + 0.5f);
-    float r = x - n * 0.693359375f;         /* ln2 hi (exact in 9 bits) */
-    r = r - n * -2.12194440054690583e-4f;   /* ln2 lo */
-    float p = 1.98412698412698413e-4f;      /* 1/5040 */
-    p = p * r + 1.38888888888888894e-3f;    /* 1/720 */
-    p = p * r + 8.33333333333333322e-3f;    /* 1/120 */
-    p = p * r + 4.16666666666666644e-2f;    /* 1/24 */
-    p = p * r + 1.66666666666666657e-1f;    /* 1/6 */
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
+    float n = floorf(fmaf(x, 1.44269504088896341f, 0.5f));
+    float r = fmaf(n, -0.693359375f, x);             /* ln2 hi (exact in 9 bits) */
+    r = fmaf(n, 2.12194440054690583e-4f, r);         /* ln2 lo */
+    float p = 1.98412698412698413e-4f;               /* 1/5040 */
+    p = fmaf(p, r, 1.38888888888888894e-3f);         /* 1/720 */
+    p = fmaf(p, r, 8.33333333333333322e-3f);         /* 1/120 */
+    p = fmaf(p, r, 4.16666666666666644e-2f);         /* 1/24 */
+    p = fmaf(p, r, 1.66666666666666657e-1f);         /* 1/6 */
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
     int32_t e = (int32_t)n + 127;
     return p * po_u2f((uint32_t)e << 23);
 }
@@ -97,14 +97,14 @@ PO_EXPORT float po_log1p_det_f32(float t)
 {
     float s = t / (2.0f + t);
     float z = s * s;
-    float q = 6.66666666666666657e-2f;      /* 1/15 */
-    q = q * z + 7.69230769230769273e-2f;    /* 1/13 */
-    q = q * z + 9.09090909090909116e-2f;    /* 1/11 */
-    q = q * z + 1.11111111111111105e-1f;    /* 1/9 */
-    q = q * z + 1.42857142857142849e-1f;    /* 1/7 */
-    q = q * z + 0.2f;
-    q = q * z + 3.33333333333333315e-1f;    /* 1/3 */
-    q = q * z + 1.0f;
+    float q = 6.66666666666666657e-2f;               /* 1/15 */
+    q = fmaf(q, z, 7.69230769230769273e-2f);         /* 1/13 */
+    q = fmaf(q, z, 9.09090909090909116e-2f);         /* 1/11 */
+    q = fmaf(q, z, 1.11111111111111105e-1f);         /* 1/9 */
+    q = fmaf(q, z, 1.42857142857142849e-1f);         /* 1/7 */
+    q = fmaf(q, z, 0.2f);
+    q = fmaf(q, z, 3.33333333333333315e-1f);         /* 1/3 */
+    q = fmaf(q, z, 1.0f);
     return 2.0f * s * q;
 }
 
