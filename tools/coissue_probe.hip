@@ -9,7 +9,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__global__ void __launch_bounds__(512) probe(float *out, unsigned long long *cyc, int iters, int mode, int packed)
+template <int packed>
+__global__ void __launch_bounds__(512) probe(float *out, unsigned long long *cyc, int iters, int mode)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned long long t0 = 0, t1 = 0;
@@ -66,7 +67,8 @@ int main()
     for (int packed = 1; packed >= 0; --packed)
         for (int mode = 1; mode <= 3; ++mode) {
             hipMemset(cyc, 0, 64);
-            hipLaunchKernelGGL(probe, dim3(256), dim3(512), 0, 0, out, cyc, iters, mode, packed);
+            if (packed) hipLaunchKernelGGL(probe<1>, dim3(256), dim3(512), 0, 0, out, cyc, iters, mode);
+            else hipLaunchKernelGGL(probe<0>, dim3(256), dim3(512), 0, 0, out, cyc, iters, mode);
             hipDeviceSynchronize();
             unsigned long long c[8];
             hipMemcpy(c, cyc, 64, hipMemcpyDeviceToHost);
