@@ -70,7 +70,7 @@ def _worker(rank, world, port, q):
     dist.barrier()
 
     # ---- sampled gather
-    gat = CpuSampledGather(_Env(), batch_size=8, rank=rank, world=world, device='cpu', every=2, seed=3)
+    gat = CpuSampledGather(_Env(), batch_size=4 * world, rank=rank, world=world, device='cpu', every=2, seed=3)
     assert gat.R == 4 and gat.W == row_width(N, D)
     for k in range(6):
         out, acts = chunk(rank, k)
@@ -105,29 +105,47 @@ def _free_port():
     return p
 
 
-@pytest.fixture(scope='module')
-def world2():
+def _run_world(world):
     if torch.cuda.device_count() > 0:
         pytest.skip('CPU-container test: it spawns (execs) worker processes, which a process that may have '
                     'initialised the GPU must not do')
-    world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=100) for _ in range(world)]
+    res = [q.get(timeout=60) for _ in range(world)]
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
     return world, [r for r in res if r[2] is not None][0]
 
 
-@pytest.mark.timeout(120)
-def test_full_transition_gather_world2(world2):
-    """Every transition of both ranks, in (exchange, rank, step, env) order, next_obs = the pre-reset row."""
-    world, root = world2
+_world_cache = {}
+
+
+def _cached_world(world):
+    if world not in _world_cache:
+        _world_cache[world] = _run_world(world)
+    return _world_cache[world]
+
+
+@pytest.fixture(scope='module')
+def world2():
+    return _cached_world(2)
+
+
+@pytest.fixture(scope='module', params=[2, 4])
+def worldn(request):
+    return _cached_world(request.param)
+
+
+@pytest.mark.timeout(240)
+def test_full_transition_gather_world2(worldn):
+    """Every transition of every rank (2 and 4 ranks), in (exchange, rank, step, env) order, next_obs = the pre-reset
+    row."""
+    world, root = worldn
     ingested, ring = root[3], root[4]
     assert ingested == 3 * world * T * B and len(ring) == 3 * world
     i = 0

@@ -478,3 +478,31 @@ def test_bench_path_collision_masks_full_size_bitwise(case, monkeypatch):
         _assert_same_bits(_coll(out['coll'][t]), w['coll'], 'coll[%d]' % t)
         hits += int((w['coll'] != (np.uint64(1) << np.arange(N, dtype=np.uint64))[None, :]).sum())
     assert hits > 100        # real collisions were seen, not only the self bits
+
+
+def test_c4_partition_full_size_equals_the_unsharded_batch():
+    """BASELINE configs[3] (C4): simple_spread N = 6, B = 32768 split over 8 GPUs as contiguous shards of 4096 envs.
+    One GPU plays the eight ranks in turn (env_id_base = rank * 4096, its own action slice) and the concatenation of
+    their outputs -- reset observations, 30 rollout steps across an auto-reset, final world state -- must equal the
+    unsharded B = 32768 run bit for bit: the partition has no data-path coupling and the Philox reset is keyed by the
+    GLOBAL env id.  (The exchange that follows the rollout is covered by the gloo world-size tests.)"""
+    world, Bs, N, T = 8, 4096, 6, 30
+    B = world * Bs
+    whole, _ = _mk(num_agents=N, num_envs=B, max_episode_len=25, auto_reset=True, seed=12345678, want_coll=False)
+    acts = torch.randint(0, 5, (T, B, N), dtype=torch.int32, generator=torch.Generator().manual_seed(4)).cuda()
+    obs0 = whole.reset()
+    out = whole.rollout(acts)
+    st = whole.get_state()
+    for rank in range(world):
+        lo, hi = rank * Bs, (rank + 1) * Bs
+        shard, _ = _mk(num_agents=N, num_envs=Bs, max_episode_len=25, auto_reset=True, seed=12345678, env_id_base=lo,
+                       want_coll=False)
+        assert torch.equal(shard.reset(), obs0[lo:hi]), 'reset of shard %d' % rank
+        o = shard.rollout(acts[:, lo:hi].contiguous())
+        for k in ('obs', 'rew', 'rew_shared', 'terminal', 'done'):
+            assert torch.equal(o[k], out[k][:, lo:hi]), (k, rank)
+        assert torch.equal(o['final_obs'][24], out['final_obs'][24, lo:hi])
+        ss = shard.get_state()
+        for k in ('pos', 'vel', 'landmarks', 'ep_step', 'ep_count'):
+            assert torch.equal(ss[k], st[k][lo:hi]), (k, rank)
+    assert out['terminal'][24].all() and int(st['ep_count'][0]) == 2
