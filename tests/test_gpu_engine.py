@@ -828,3 +828,57 @@ def test_one_launch_policy_rollout_simple_tag_equals_the_step_loop(B, adv, good,
         for x, y in zip(res[0][:5], res[1][:5]):
             assert torch.equal(x, y)
         assert res[0][5] == res[1][5] == B and abs(res[0][6] - res[1][6]) < 1e-9 * max(1.0, abs(res[0][6]))
+
+
+def test_exchanges_on_real_rccl_single_rank():
+    """Both exchanges through torch.distributed's "nccl" backend (= RCCL) with ONE rank, in this process (no worker is
+    spawned): the sampled gather's all_gather_into_tensor is a real RCCL launch, the full gather runs its finalize /
+    ingest launches behind the same process-group plumbing bench.py uses.  The multi-rank choreography is covered by
+    the gloo tests; what this adds on a GPU box is that the RCCL path itself initialises and runs."""
+    import socket
+    import torch.distributed as dist
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.dist import FullTransitionGather, SampledTransitionGather
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(0)
+        B, N, T = 512, 6, 50
+        env = make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=25, seed=3)
+        env.reset()
+        gat = SampledTransitionGather(env, 256, 0, 1, dev, every=1, side_stream=True)
+        for k in range(3):
+            acts = torch.randint(0, 5, (T, B, N), device='cuda', dtype=torch.int32)
+            out = env.rollout(acts)
+            gat(out, acts)
+        gat.finish()
+        torch.cuda.synchronize()
+        assert gat.exchanges == 3 and gat.rows_ingested == 3 * 256 and len(gat.memory) == 3 * 256
+        o, a, r, n, d = gat.memory.sample_index(list(range(3 * 256)))
+        assert torch.isfinite(o).all() and (a.sum(-1) == 1).all() and not d.any()
+        # full gather: the policy-in-the-loop rollout writes into the wire block; every transition reaches the ring
+        actor = FusedActor(ActorNetwork(env.obs_dim, 5).cuda().eval(), seed=5)
+        full = FullTransitionGather(env, T, 0, 1, dev)
+        full.prime()
+        obs0 = env.observe()
+        first = obs0.clone()
+        for k in range(2):
+            out = full.outputs()
+            actor.rollout(env, T, out)
+            full(obs0)
+            obs0 = out['obs'][T - 1]
+        full.finish()
+        torch.cuda.synchronize()
+        assert full.rows_ingested == 2 * T * B and len(full.memory) == 2 * T * B
+        o, a, r, n, d = full.memory.sample_index(list(range(B)))
+        assert torch.equal(o, first) and (a.sum(-1) == 1).all()
+    finally:
+        dist.destroy_process_group()
