@@ -441,6 +441,11 @@ def main():
             policy_line = policy_in_loop(args, env if STUB else None, rank, world, dev, use_dist, sync)
         except Exception as e:  # the headline must not depend on this extra
             policy_line = dict(error=repr(e)[:300])
+        if world == 1 and rank == 0 and not STUB and not use_dist:
+            try:
+                line_holder['line']['other_configs'] = other_configs(dev)
+            except Exception as e:
+                line_holder['line']['other_configs'] = dict(error=repr(e)[:300])
         watchdog.cancel()
     if rank == 0:
         line = line_holder['line']
@@ -458,6 +463,39 @@ def main():
         except Exception:  # a peer already left (e.g. through its watchdog): nothing left to do but exit cleanly
             pass
         bye.cancel()
+
+
+def other_configs(dev):
+    """Not part of `value`: the other BASELINE.json configurations and the store-bound regime under the same clock
+    (1 GPU; 100-step pw_rollout launches, every output written, 10 launches timed after 2): C3 simple_tag 4+2 at
+    B = 8192, the C5 end point N = 48 at B = 4096, and N = 6 at B = 65536 (where the kernels stop being latency-bound)."""
+    import torch
+    from multiagent_rl_amd.env import BatchedParticleEnv
+    out = []
+    for name, scen, B, kw in (('C3 simple_tag 4+2, B=8192', 'simple_tag', 8192, dict(num_adversaries=4, num_good=2)),
+                              ('C5 simple_spread N=48, B=4096', 'simple_spread', 4096, dict(num_agents=48)),
+                              ('simple_spread N=6, B=65536', 'simple_spread', 65536, dict(num_agents=6))):
+        env = BatchedParticleEnv(scen, B, max_episode_len=25, auto_reset=True, seed=12345678, **kw)
+        T = 100
+        acts = torch.randint(0, 5, (T, B, env.n), device=dev, dtype=torch.int32)
+        outs = env.alloc_outputs(T, coll=False)
+        launch = env.plan_rollout(acts, outs)
+        env.reset()
+        for _ in range(2):
+            launch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            launch()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rate = B * T * 10 / dt
+        out.append(dict(config=name, value=rate, unit='env-steps/s', us_per_batched_env_step=dt / (10 * T) * 1e6,
+                        bytes_per_env_step=env.bytes_per_env_step,
+                        roofline_frac=rate * env.bytes_per_env_step / 1e9 / HBM_PEAK_GBPS))
+        del env, acts, outs, launch
+        torch.cuda.empty_cache()
+    return out
 
 
 def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
