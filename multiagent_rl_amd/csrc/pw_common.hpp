@@ -196,9 +196,12 @@ __device__ __forceinline__ float softplus_fastdiv(float x)
 // FAST: the same IEEE results through sqrt_rn_core / div_chain when every operand is provably in their range
 // (one range test per pair); anything else -- coincident or astronomically distant entities, a coordinate
 // difference below 2^-60, an exotic contact margin, NaN / inf -- takes the general expressions.
+// collision_force_pair: the pair force (Fx, Fy) on the first entity itself; collision_force adds it to the accumulator
+// (F + f, the upstream order of operands).  The force on the second entity is the exact negation: every operation
+// below is odd in delta.
 template <bool FAST = false>
-__device__ __forceinline__ void collision_force(float px, float py, float qx, float qy, float dist_min,
-                                                float k, float cf, float &fx, float &fy)
+__device__ __forceinline__ void collision_force_pair(float px, float py, float qx, float qy, float dist_min,
+                                                     float k, float cf, float &Fx, float &Fy)
 {
     const float dx = px - qx, dy = py - qy;
     const float d2 = dx * dx + dy * dy;
@@ -216,16 +219,24 @@ __device__ __forceinline__ void collision_force(float px, float py, float qx, fl
             const float xarg = div_chain(-(dist - dist_min), k, div_refined_rcp(k));
             const float pen = softplus_fastdiv(xarg) * k;
             const f32x2 F = div_chain2(a, dist, div_refined_rcp(dist)) * f32x2{pen, pen};
-            fx = F.x + fx;
-            fy = F.y + fy;
+            Fx = F.x;
+            Fy = F.y;
             return;
         }
     }
     const float dist = FAST ? sqrt_rn_fast(d2) : sqrtf(d2);
     const float xarg = -(dist - dist_min) / k;
     const float pen = (FAST ? softplus_branchless(xarg) : pw_softplus(xarg)) * k;
-    const float Fx = cf * dx / dist * pen;
-    const float Fy = cf * dy / dist * pen;
+    Fx = cf * dx / dist * pen;
+    Fy = cf * dy / dist * pen;
+}
+
+template <bool FAST = false>
+__device__ __forceinline__ void collision_force(float px, float py, float qx, float qy, float dist_min,
+                                                float k, float cf, float &fx, float &fy)
+{
+    float Fx, Fy;
+    collision_force_pair<FAST>(px, py, qx, qy, dist_min, k, cf, Fx, Fy);
     fx = Fx + fx;
     fy = Fy + fy;
 }

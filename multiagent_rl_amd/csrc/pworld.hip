@@ -32,6 +32,7 @@
 
 #include "pw_common.hpp"
 #include "pw_kernels_spread.hpp"
+#include "pw_kernels_spread_quad.hpp"
 #include "pw_kernels_tag.hpp"
 #include "pw_kernels_reference.hpp"
 #include "pw_kernels_generic.hpp"
@@ -279,6 +280,22 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         bool blk = kp.N == 3 ? grid.x > 3000 : grid.x > 700;
         if (const char *e = std::getenv("PWORLD_OBS_BLOCK")) blk = std::atoi(e) != 0;
         const int key = kp.N != kp.L ? 0 : (wc && !(um && (kp.N == 3 || kp.N == 6))) ? 0 : kp.N;
+        // N = L = 6 on small grids (BASELINE configs[1]): four cooperating waves per 8 envs, pair-parallel physics
+        // (pw_kernels_spread_quad.hpp).  More total instructions than the duo form, shorter dependent chains: it pays
+        // while the chip is latency bound.  PWORLD_FORCE_QUAD / PWORLD_NO_QUAD override (tests, experiments).
+        {
+            const unsigned qgrid = (unsigned)((kp.B + 7) / 8);
+            bool quad = kp.N == 6 && kp.L == 6 && um && !wc && qgrid <= 768 && !std::getenv("PWORLD_NO_DUO");  // B <= 6144: measured crossover
+            if (std::getenv("PWORLD_NO_QUAD")) quad = false;
+            if (std::getenv("PWORLD_FORCE_QUAD") && kp.N == 6 && kp.L == 6 && um && !wc) quad = true;
+            if (quad) {
+                const size_t qshm = 4 * kWave * sizeof(float4) + 2 * 4 * 6 * 6 * sizeof(float2) + 2 * kWave * sizeof(float) +
+                                    8 * 6 * sizeof(float2) + kWave * sizeof(float4);
+                hipLaunchKernelGGL((pw_spread_quad_kernel<true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
+                PW_HIP_CHECK(hipGetLastError());
+                return PW_OK;
+            }
+        }
         // two cooperating waves per env group pay off while the chip is latency bound (few workgroups
         // per CU); once every SIMD holds several waves the single-wave kernel issues fewer instructions
         const bool duo = grid.x <= 8192 && !std::getenv("PWORLD_NO_DUO");

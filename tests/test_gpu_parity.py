@@ -90,7 +90,7 @@ WANT_COLL = {'on': True}
 
 @pytest.fixture(params=['duo', 'stream', 'duo+coll', 'stream+coll', 'duo+block', 'stream+block', 'fast', 'generic',
                         'duo-dense', 'stream-dense', 'duo+coll-dense', 'stream+coll-dense', 'duo+block-dense',
-                        'stream+block-dense', 'fast-dense', 'generic-dense'])
+                        'stream+block-dense', 'fast-dense', 'generic-dense', 'quad'])
 def kernel_path(request, monkeypatch):
     """Four kernels serve simple_spread with homogeneous agents; all must give the same bits.
     'duo'     pw_spread_duo_kernel    (default when all standard outputs are present),
@@ -99,6 +99,9 @@ def kernel_path(request, monkeypatch):
     'generic' pw_rollout_kernel       (PWORLD_FORCE_GENERIC, read by pw_create).
     'duo' / 'stream' run WITHOUT the optional collision-mask output (the bench path's instantiations);
     'duo+coll' / 'stream+coll' are the instantiations that also store the masks (WANT_COLL tells the tests);
+    'quad' (N = L = 6 only; elsewhere it is the default choice again) forces pw_spread_quad_kernel, the four-wave
+    pair-parallel form small grids of BASELINE configs[1] run (PWORLD_FORCE_QUAD; every other path here sets
+    PWORLD_NO_QUAD so that the duo kernel keeps its coverage);
     'duo+block' / 'stream+block' force the block-wise observation stores large grids use (PWORLD_OBS_BLOCK=1;
     default here: only N >= 12, the test batches being small), '-dense' then gives 60- and 63-row blocks.
     simple_tag has three: pw_tag_duo_kernel ('duo'), pw_tag_stream_kernel ('stream') and the generic kernel
@@ -111,7 +114,13 @@ def kernel_path(request, monkeypatch):
         monkeypatch.setenv('PWORLD_EPW', '64')
         param = param[:-6]
     monkeypatch.delenv('PWORLD_OBS_BLOCK', raising=False)
-    WANT_COLL['on'] = param not in ('stream', 'duo', 'stream+block', 'duo+block')
+    monkeypatch.delenv('PWORLD_FORCE_QUAD', raising=False)
+    monkeypatch.setenv('PWORLD_NO_QUAD', '1')
+    WANT_COLL['on'] = param not in ('stream', 'duo', 'stream+block', 'duo+block', 'quad')
+    if param == 'quad':
+        monkeypatch.delenv('PWORLD_NO_QUAD')
+        monkeypatch.setenv('PWORLD_FORCE_QUAD', '1')
+        param = 'duo'
     if param.endswith('+coll'):
         param = param[:-5]
     if param.endswith('+block'):
@@ -506,3 +515,33 @@ def test_c4_partition_full_size_equals_the_unsharded_batch():
         for k in ('pos', 'vel', 'landmarks', 'ep_step', 'ep_count'):
             assert torch.equal(ss[k], st[k][lo:hi]), (k, rank)
     assert out['terminal'][24].all() and int(st['ep_count'][0]) == 2
+
+
+@pytest.mark.parametrize('B,ep_len', [(4096, 25), (77, 3), (9, 1), (1000, 2)])
+def test_quad_kernel_equals_duo_with_desynchronised_episode_clocks(B, ep_len, monkeypatch):
+    """pw_spread_quad_kernel keeps ONE ring-slot sequence per workgroup: a step in which any of its 8 envs resets makes
+    every env publish two slots.  Envs whose episode clocks are out of step (masked resets, restored checkpoints)
+    therefore reset in different -- also consecutive -- steps of one workgroup; episodes of 1, 2 and 3 steps stress the
+    4-slot ring.  Every output and the final state must equal the duo kernel's (which is anchored on the oracle)."""
+    T, N = 31, 6
+    acts = torch.randint(0, 5, (T, B, N), dtype=torch.int32, generator=torch.Generator().manual_seed(B)).cuda()
+    res = {}
+    for form in ('duo', 'quad'):
+        monkeypatch.delenv('PWORLD_NO_QUAD', raising=False)
+        monkeypatch.delenv('PWORLD_FORCE_QUAD', raising=False)
+        monkeypatch.setenv('PWORLD_NO_QUAD' if form == 'duo' else 'PWORLD_FORCE_QUAD', '1')
+        env, cfg = _mk(num_agents=N, num_envs=B, max_episode_len=ep_len, auto_reset=True, seed=41, want_coll=False)
+        env.reset()
+        st = env.get_state()
+        env.set_state(st['pos'], st['vel'], st['landmarks'],
+                      ep_step=((torch.arange(B, device='cuda') * 7) % ep_len).int(), ep_count=st['ep_count'])
+        out = env.rollout(acts)
+        res[form] = (out, env.get_state())
+    (oa, sa), (ob, sb) = res['duo'], res['quad']
+    for k in ('obs', 'rew', 'rew_shared', 'terminal', 'done'):
+        assert torch.equal(oa[k], ob[k]), k
+    term = oa['terminal']
+    assert term.any() and (ep_len == 1 or not term.all())
+    assert torch.equal(oa['final_obs'][term], ob['final_obs'][term])
+    for k in ('pos', 'vel', 'landmarks', 'ep_step', 'ep_count'):
+        assert torch.equal(sa[k], sb[k]), k

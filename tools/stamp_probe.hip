@@ -34,6 +34,13 @@ int main(int argc, char **argv)
         hipMemcpyFromSymbol(s, HIP_SYMBOL(g_pw_stamps), sizeof(s));
         if (r >= 5) for (int i = 0; i < 16; ++i) tot[i] += s[i];
     }
+    if (N == 6 && !getenv("PWORLD_NO_QUAD") && B <= 8192) {
+        const char *qn[8] = {"P: pair phase (LDS read, near test, force, table write)", "P: row add + integrate + publish", "P: barrier wait", "-",
+                             "OA: barrier wait", "OA: masks + rewards + stores", "OB: barrier wait", "OB: observation rows"};
+        printf("B=%d N=%d (quad kernel): cycles per step, workgroup 0\n", B, N);
+        for (int i = 0; i < 8; ++i) if (i != 3) printf("  %-58s %7.0f cycles\n", qn[i], tot[i] / (double)((reps - 5) * T));
+        return 0;
+    }
     const bool duo = !getenv("PWORLD_NO_DUO");
     const char *names_duo[8] = {"P: action decode + prefetch", "P: near-pair force loop", "P: integrate + publish slot",
                                 "P: barrier wait (O behind?)", "P: near-mask pass", "-", "-", "-"};
