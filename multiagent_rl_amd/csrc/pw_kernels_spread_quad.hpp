@@ -14,7 +14,7 @@ namespace {
 //                 Every pair is tested and, if near, evaluated ONCE, all pairs at the same time -- no per-lane partner
 //                 loop, no separate near-set pass; the pair's force goes to the first agent, its exact negation (IEEE:
 //                 delta, quotients and products only change sign) to the second, through a [agent][partner] table in
-//                 LDS; the env's 6 agent lanes then add their row in ascending partner order (the upstream
+//                 LDS (wave shuffles were measured: slower); the env's 6 agent lanes then add their row in ascending partner order (the upstream
 //                 accumulation order, so the bits do not change; far pairs contribute +-0, which cannot change an
 //                 accumulator that is never -0), integrate and publish {pos, vel} into the ring.
 //   wave OA       8 envs, one step behind (as the duo kernel's O): collision masks, landmark minima, rewards, shared
@@ -99,6 +99,11 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         const float k = A.contact_margin, cf = A.contact_force, dt = A.dt, damp = A.damp, mass = A.mass;
         const uint32_t near_lo = __float_as_uint(A.near_thr2), near_span = 0x7F800000u - near_lo;
         int act_next = A.act[g];
+        // the pair lanes' operands of the coming step are fetched right after the publish, before the barrier (this
+        // wave only reads its own envs' entries, and a wave's LDS operations execute in issue order): the read's latency
+        // hides behind the barrier
+        float2 qi = *reinterpret_cast<const float2 *>(s_ring + ri);
+        float2 qj = *reinterpret_cast<const float2 *>(s_ring + rj);
         PW_STAMP_DECL;
         for (int t = 0; t < T; ++t) {
             PW_STAMP_START;
@@ -107,10 +112,8 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
                 const int tn = t + 1 < T ? t + 1 : t;
                 act_next = A.act[(size_t)tn * BN + g];
             }
+            const bool two_slots = any_reset_step();  // workgroup-uniform; early: it does not depend on the physics
             // ---- pair phase: every unordered pair of the wave's envs at once
-            const float4 *slot = s_ring + cur * kWave;
-            const float2 qi = *reinterpret_cast<const float2 *>(slot + ri);
-            const float2 qj = *reinterpret_cast<const float2 *>(slot + rj);
             float Fx = 0.0f, Fy = 0.0f;
             {
                 const float dx = qj.x - qi.x, dy = qj.y - qi.y;   // the near test of the other kernels: (q - p)^2
@@ -127,7 +130,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             ux *= A.sens; uy *= A.sens;
             if (A.fscale != 1.0f) { ux = A.fscale * ux; uy = A.fscale * uy; }
             float fx = ux + 0.0f, fy = uy + 0.0f;
-            wave_lds_sync();
+            asm volatile("" ::: "memory");  // program order only: the row reads below queue behind the table writes
             // ---- U5: the agent's row, ascending partner order
 #pragma unroll
             for (int j = 0; j < N; ++j) {
@@ -150,11 +153,14 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
                 pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
                 vx = 0.f; vy = 0.f;
             }
-            if (any_reset_step()) {  // workgroup-uniform: every env publishes a second slot
+            if (two_slots) {  // every env publishes a second slot
                 nxt = (nxt + 1) & 3;
                 s_ring[nxt * kWave + me] = make_float4(px, py, vx, vy);
             }
             cur = nxt;
+            asm volatile("" ::: "memory");
+            qi = *reinterpret_cast<const float2 *>(s_ring + cur * kWave + ri);
+            qj = *reinterpret_cast<const float2 *>(s_ring + cur * kWave + rj);
             PW_STAMP(1);
             duo_barrier();
             PW_STAMP(2);
@@ -206,19 +212,17 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
                 const float e2 = ex * ex + ey * ey;
                 best = (j == 0 || e2 < best) ? e2 : best;
             }
-            s_min[me] = sqrtf(best);
-            wave_lds_sync();
+            // per-env reductions by wave shuffle (ds_bpermute: one trip each, no LDS write -> wait -> read)
+            const float own = sqrtf(best);
             float r = 0.0f;
 #pragma unroll
-            for (int l = 0; l < L; ++l) r -= s_min[base + l];
+            for (int l = 0; l < L; ++l) r -= __shfl(own, base + l, kWave);
 #pragma unroll
             for (int j = 0; j < N; ++j)
                 if ((coll >> j) & 1) r -= 1.0f;
-            s_rew[me] = r;
-            wave_lds_sync();
             float acc = 0.0f;
 #pragma unroll
-            for (int i = 0; i < N; ++i) acc += s_rew[base + i];
+            for (int i = 0; i < N; ++i) acc += __shfl(r, base + i, kWave);
             A.rew[tBN + g] = r;
             A.done[tBN + g] = 0;
             A.rew_shared[(size_t)t * A.B + env] = acc;
@@ -232,7 +236,6 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             }
             if (any_reset_step()) { nxt = (nxt + 1) & 3; }
             cur = nxt;
-            wave_lds_sync();  // s_min / s_rew are rewritten next step
             PW_STAMP(1);
         }
 #ifdef PW_STAMPS

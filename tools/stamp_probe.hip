@@ -7,7 +7,7 @@
 
 int main(int argc, char **argv)
 {
-    const int B = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 6, T = 25, reps = 40;
+    const int B = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 6, T = argc > 3 ? atoi(argv[3]) : 25, reps = argc > 3 ? 12 : 40;
     pw_config cfg;
     pw_config_default(&cfg, PW_SIMPLE_SPREAD, B, N, -1, 0);
     cfg.auto_reset = 1;
@@ -17,14 +17,14 @@ int main(int argc, char **argv)
     pw_bind_state(h, state);
     const int D = pw_obs_dim(h);
     size_t BN = (size_t)B * N;
-    int32_t *act; hipMalloc(&act, T * BN * 4);
-    std::vector<int32_t> ha(T * BN); for (auto &a : ha) a = rand() % 5;
-    hipMemcpy(act, ha.data(), T * BN * 4, hipMemcpyHostToDevice);
+    int32_t *act; hipMalloc(&act, (size_t)T * BN * 4);
+    std::vector<int32_t> ha((size_t)T * BN); for (auto &a : ha) a = rand() % 5;
+    hipMemcpy(act, ha.data(), (size_t)T * BN * 4, hipMemcpyHostToDevice);
     pw_step_io io = {};
     io.act_idx = act;
-    hipMalloc((void **)&io.obs, T * BN * D * 4); hipMalloc((void **)&io.final_obs, T * BN * D * 4);
-    hipMalloc((void **)&io.rew, T * BN * 4); hipMalloc((void **)&io.rew_shared, (size_t)T * B * 4);
-    hipMalloc((void **)&io.done, T * BN); hipMalloc((void **)&io.terminal, (size_t)T * B);
+    hipMalloc((void **)&io.obs, (size_t)T * BN * D * 4); hipMalloc((void **)&io.final_obs, (size_t)T * BN * D * 4);
+    hipMalloc((void **)&io.rew, (size_t)T * BN * 4); hipMalloc((void **)&io.rew_shared, (size_t)T * B * 4);
+    hipMalloc((void **)&io.done, (size_t)T * BN); hipMalloc((void **)&io.terminal, (size_t)T * B);
     pw_reset(h, nullptr, nullptr, nullptr);
     unsigned long long tot[16] = {0};
     for (int r = 0; r < reps; ++r) {
