@@ -393,10 +393,8 @@ def main():
         watchdog.daemon = True
     if rank == 0:
         value = world * B * T * K / elapsed
-        if args.scenario == 'simple_spread' and N == 6 and env.num_landmarks == 6:
-            kernel = 'pw_spread_duo_kernel<6,6,true>'
-        else:
-            kernel = 'pw_rollout (%s N=%d)' % (args.scenario, N)
+        # the dispatcher's own record of what it launched (pw_rollout_kernel)
+        kernel = env.last_kernel() if hasattr(env, 'last_kernel') else 'stub (no device)'
         line = {
             'metric': 'env-steps/sec, simple_spread N=6 x B envs, 1/2/4/8 MI355X',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,

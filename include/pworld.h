@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define PW_VERSION 101 /* 0.1.1: pw_replay_store grew act_heads / per_agent / head_width; wire-block entry points */
+#define PW_VERSION 102 /* 0.1.1: pw_replay_store grew act_heads / per_agent / head_width; wire-block entry points */
 #define PW_MAX_AGENTS 64
 #define PW_MAX_LANDMARKS 64
 
@@ -170,6 +170,11 @@ int pw_reward(pw_handle *h, float *rew, uint64_t *coll, void *stream);
 int pw_step(pw_handle *h, const pw_step_io *io, void *stream);
 /* T consecutive steps in ONE launch (state stays in registers/LDS between steps). */
 int pw_rollout(pw_handle *h, const pw_step_io *io, int num_steps, void *stream);
+
+/* Name of the device kernel the last pw_step / pw_rollout on this handle launched (a static string; "" before the
+ * first launch).  The dispatcher picks a kernel per (scenario, N, L, B, outputs requested): measurement tools name the
+ * dominant kernel from this, not from a table of their own. */
+const char *pw_rollout_kernel(const pw_handle *h);
 
 /* Algorithmic HBM bytes of one env-step: 57N + 8L + 8NL for local obs. */
 size_t pw_algorithmic_bytes_per_env_step(const pw_handle *h);

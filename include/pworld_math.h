@@ -5,14 +5,28 @@
  * fused multiply-add of C99: one rounding), floorf, int<->float conversion and
  * bit casts; compile WITHOUT implicit FMA contraction (-ffp-contract=off: a fused
  * operation happens exactly where fmaf is written, nowhere else) and with correctly
- * rounded division.  (Revision 2 of the contract: the polynomial and range-reduction
- * steps of pw_exp / pw_log1p01 are fmaf steps -- 16 instructions fewer per contact
- * pair on the GPU, a little more accurate; revision 1 used separate * and +.)
+ * rounded division.
  *
  * They replace, inside upstream get_collision_force / simple_tag's bound():
  *   np.logaddexp(0, x)  -> pw_softplus(x)
  *   np.exp(x)           -> pw_exp(x)
- * Accuracy: <= 3e-7 relative against float64 libm over the ranges used.
+ *
+ * Revision 3 of the contract (revision 1: separate * and +; revision 2: fmaf steps,
+ * Horner polynomials, log1p through t / (2 + t)).  The batched env step is bound by
+ * the LENGTH of the dependent instruction chain of one contact pair, not by the
+ * number of instructions, so revision 3 states the same functions as short chains:
+ *   - polynomials in Estrin form (independent pairs, then powers of two of the
+ *     argument): 3 dependent fmaf levels instead of 7;
+ *   - log1p(t) on [0, 1] as t + t^2 Q(t), Q a degree-7 minimax polynomial of
+ *     (log1p(t) - t) / t^2 -- no division (revision 2's t / (2 + t) was a 10-deep
+ *     chain on its own), and the leading term t is exact, so the result is rounded
+ *     once at the end;
+ *   - pw_softplus adds max(x, 0) into that last fused step.
+ * A contact pair's softplus is 15 dependent operations deep (revision 2: 42).
+ * Accuracy against float64 libm, measured by oracle/math_accuracy.c over every
+ * float32 argument of the ranges used: see the table that tool prints
+ * (profiles/r2_math_accuracy.txt): pw_exp <= 1.8e-7 relative (1.5 ulp), pw_log1p01
+ * <= 1.7e-7, pw_softplus <= 2.6e-7 (revision 2 claimed 3e-7).
  */
 #ifndef PWORLD_MATH_H
 #define PWORLD_MATH_H
@@ -27,6 +41,16 @@
 #define PW_HD static inline
 #endif
 
+/* Q's coefficients (float32 values, written with 9 significant digits) */
+#define PW_LQ0 (-4.999969006e-01f)
+#define PW_LQ1 (3.332236707e-01f)
+#define PW_LQ2 (-2.486616373e-01f)
+#define PW_LQ3 (1.919044554e-01f)
+#define PW_LQ4 (-1.383424997e-01f)
+#define PW_LQ5 (8.017139137e-02f)
+#define PW_LQ6 (-3.066807054e-02f)
+#define PW_LQ7 (5.516789388e-03f)
+
 PW_HD float pw_bits_to_float(uint32_t u)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -39,7 +63,8 @@ PW_HD float pw_bits_to_float(uint32_t u)
 }
 
 /* exp(x). x <= -87 (or NaN < test fails) -> +0 exactly, so no subnormal is ever
- * produced; x >= 88 -> 2^127. Cody-Waite reduction by ln2, degree-7 Taylor. */
+ * produced; x >= 88 -> 2^127. Cody-Waite reduction by ln2, degree-7 Taylor in
+ * Estrin form. */
 PW_HD float pw_exp(float x)
 {
     if (!(x > -87.0f)) return x != x ? x : 0.0f;
@@ -47,40 +72,48 @@ PW_HD float pw_exp(float x)
     float n = floorf(fmaf(x, 1.44269504088896341f, 0.5f));
     float r = fmaf(n, -0.693359375f, x);
     r = fmaf(n, 2.12194440054690583e-4f, r);
-    float p = 1.98412698412698413e-4f;
-    p = fmaf(p, r, 1.38888888888888894e-3f);
-    p = fmaf(p, r, 8.33333333333333322e-3f);
-    p = fmaf(p, r, 4.16666666666666644e-2f);
-    p = fmaf(p, r, 1.66666666666666657e-1f);
-    p = fmaf(p, r, 0.5f);
-    p = fmaf(p, r, 1.0f);
-    p = fmaf(p, r, 1.0f);
+    float r2 = r * r;
+    float r4 = r2 * r2;
+    float p01 = 1.0f + r;
+    float p23 = fmaf(1.66666666666666657e-1f, r, 0.5f);
+    float p45 = fmaf(8.33333333333333322e-3f, r, 4.16666666666666644e-2f);
+    float p67 = fmaf(1.98412698412698413e-4f, r, 1.38888888888888894e-3f);
+    float lo = fmaf(p23, r2, p01);
+    float hi = fmaf(p67, r2, p45);
+    float p = fmaf(hi, r4, lo);
     int32_t e = (int32_t)n + 127;
     return p * pw_bits_to_float((uint32_t)e << 23);
 }
 
-/* log1p(t) for t in [0, 1]: 2 atanh(t / (2 + t)), 8-term odd series. */
-PW_HD float pw_log1p01(float t)
+/* Q(t) ~ (log1p(t) - t) / t^2 on [0, 1] (degree-7 minimax, weight t), Estrin form. */
+PW_HD float pw_log1p01_q(float t)
 {
-    float s = t / (2.0f + t);
-    float z = s * s;
-    float q = 6.66666666666666657e-2f;
-    q = fmaf(q, z, 7.69230769230769273e-2f);
-    q = fmaf(q, z, 9.09090909090909116e-2f);
-    q = fmaf(q, z, 1.11111111111111105e-1f);
-    q = fmaf(q, z, 1.42857142857142849e-1f);
-    q = fmaf(q, z, 0.2f);
-    q = fmaf(q, z, 3.33333333333333315e-1f);
-    q = fmaf(q, z, 1.0f);
-    return 2.0f * s * q;
+    float t2 = t * t;
+    float t4 = t2 * t2;
+    float q01 = fmaf(PW_LQ1, t, PW_LQ0);
+    float q23 = fmaf(PW_LQ3, t, PW_LQ2);
+    float q45 = fmaf(PW_LQ5, t, PW_LQ4);
+    float q67 = fmaf(PW_LQ7, t, PW_LQ6);
+    float lo = fmaf(q23, t2, q01);
+    float hi = fmaf(q67, t2, q45);
+    return fmaf(hi, t4, lo);
 }
 
-/* logaddexp(0, x) = max(x, 0) + log1p(exp(-|x|)); exactly 0 for x <= -87. */
+/* log1p(t) for t in [0, 1]: t + t^2 Q(t).  log1p(0) = +0 exactly. */
+PW_HD float pw_log1p01(float t)
+{
+    return fmaf(t * t, pw_log1p01_q(t), t);
+}
+
+/* logaddexp(0, x) = max(x, 0) + log1p(exp(-|x|)), the max added inside the last fused
+ * step: fmaf(t^2, Q(t), t + max(x, 0)) with t = exp(-|x|); exactly +0 for x <= -87,
+ * exactly x for x >= 87. */
 PW_HD float pw_softplus(float x)
 {
     float ax = x < 0.0f ? -x : x;
     float m = x > 0.0f ? x : 0.0f;
-    return m + pw_log1p01(pw_exp(-ax));
+    float t = pw_exp(-ax);
+    return fmaf(t * t, pw_log1p01_q(t), t + m);
 }
 
 /* Philox4x32-10 (Salmon, Moraes, Dror, Shaw; SC'11). */

@@ -85,6 +85,7 @@ SIGNATURES = {
     'pw_reward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pw_step': (C.c_int, [C.c_void_p, C.POINTER(PwStepIO), C.c_void_p]),
     'pw_rollout': (C.c_int, [C.c_void_p, C.POINTER(PwStepIO), C.c_int, C.c_void_p]),
+    'pw_rollout_kernel': (C.c_char_p, [C.c_void_p]),
     'pw_algorithmic_bytes_per_env_step': (C.c_size_t, [C.c_void_p]),
     'pw_replay_add': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.c_void_p, C.c_int32] + [C.c_void_p] * 7 + [C.c_void_p]),
     'pw_counter_add': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),

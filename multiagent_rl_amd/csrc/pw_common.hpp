@@ -121,72 +121,39 @@ __device__ __forceinline__ f32x2 div_chain2(f32x2 a, float b, float y)
     return __builtin_elementwise_fma(__builtin_elementwise_fma(nb, q1, a), yy, q1);
 }
 
-// pw_softplus with the exp argument known to be <= 0: same operations as include/pworld_math.h
-// (so the same bits), but branch-free: the polynomial runs on a clamped argument and the
-// exact-zero cut / NaN pass-through are selects.
+// pw_softplus (include/pworld_math.h, contract revision 3): the same operations, so the same bits, but branch-free --
+// the polynomial runs on a clamped argument and the exact-zero cut / NaN pass-through ride on the power-of-two scale
+// factor, which is computed beside the polynomial, not after it.  The dependent chain from x to the result is 15
+// operations: clamp, fma, floor, 2 reduction fmas, 3 Estrin levels, scale, 3 Estrin levels of Q, the final fma (revision
+// 2: 42, a third of them the division inside log1p).
 __device__ __forceinline__ float softplus_branchless(float x)
 {
     const float ax = x < 0.0f ? -x : x;
     const float m = x > 0.0f ? x : 0.0f;
-    const float t0 = -ax;                       // <= 0, or NaN
-    const float tc = t0 > -87.0f ? t0 : -86.0f;  // keep the exponent arithmetic in range when cut
-    float n = floorf(__builtin_fmaf(tc, 1.44269504088896341f, 0.5f));
+    const float t0 = -ax;                        // <= 0, or NaN
+    const float tc = t0 > -87.0f ? t0 : -87.0f;  // keep the exponent arithmetic in range when cut (and for NaN)
+    const float n = floorf(__builtin_fmaf(tc, 1.44269504088896341f, 0.5f));
     float r = __builtin_fmaf(n, -0.693359375f, tc);
     r = __builtin_fmaf(n, 2.12194440054690583e-4f, r);
-    float p = 1.98412698412698413e-4f;
-    p = __builtin_fmaf(p, r, 1.38888888888888894e-3f);
-    p = __builtin_fmaf(p, r, 8.33333333333333322e-3f);
-    p = __builtin_fmaf(p, r, 4.16666666666666644e-2f);
-    p = __builtin_fmaf(p, r, 1.66666666666666657e-1f);
-    p = __builtin_fmaf(p, r, 0.5f);
-    p = __builtin_fmaf(p, r, 1.0f);
-    p = __builtin_fmaf(p, r, 1.0f);
+    // pw_exp: x <= -87 -> +0, NaN -> NaN: as the scale factor (p is finite and positive on the clamped argument)
     const int32_t e = (int32_t)n + 127;
-    float ex = p * __uint_as_float((uint32_t)e << 23);
-    ex = t0 > -87.0f ? ex : (t0 != t0 ? t0 : 0.0f);  // pw_exp: x <= -87 -> +0, NaN -> NaN
-    return m + pw_log1p01(ex);
-}
-
-// get_collision_force seen from entity i against entity j: force on i.
-// delta = p_i - p_j; dist = sqrt(sum(delta^2)); pen = logaddexp(0, -(dist - dist_min)/k) * k;
-// force = contact_force * delta / dist * pen.  (The force on the pair's second entity is
-// the exact negation, which is what this evaluates to from that entity's side.)
-// softplus_branchless with log1p's t / (2 + t) through div_chain: t = exp(-|x|) in [0, 1] and the divisor in
-// [2, 3] are in range unless t < 2^-23, where 2 + t rounds to 2 and the IEEE quotient is t * 0.5 exactly.
-__device__ __forceinline__ float softplus_fastdiv(float x)
-{
-    const float ax = x < 0.0f ? -x : x;
-    const float m = x > 0.0f ? x : 0.0f;
-    const float t0 = -ax;
-    const float tc = t0 > -87.0f ? t0 : -86.0f;
-    float n = floorf(__builtin_fmaf(tc, 1.44269504088896341f, 0.5f));
-    float r = __builtin_fmaf(n, -0.693359375f, tc);
-    r = __builtin_fmaf(n, 2.12194440054690583e-4f, r);
-    float p = 1.98412698412698413e-4f;
-    p = __builtin_fmaf(p, r, 1.38888888888888894e-3f);
-    p = __builtin_fmaf(p, r, 8.33333333333333322e-3f);
-    p = __builtin_fmaf(p, r, 4.16666666666666644e-2f);
-    p = __builtin_fmaf(p, r, 1.66666666666666657e-1f);
-    p = __builtin_fmaf(p, r, 0.5f);
-    p = __builtin_fmaf(p, r, 1.0f);
-    p = __builtin_fmaf(p, r, 1.0f);
-    const int32_t e = (int32_t)n + 127;
-    float ex = p * __uint_as_float((uint32_t)e << 23);
-    ex = t0 > -87.0f ? ex : (t0 != t0 ? t0 : 0.0f);
-    // pw_log1p01(ex)
-    const float den = 2.0f + ex;
-    float sq = div_chain(ex, den, div_refined_rcp(den));
-    sq = den == 2.0f ? ex * 0.5f : sq;
-    const float z = sq * sq;
-    float q = 6.66666666666666657e-2f;
-    q = __builtin_fmaf(q, z, 7.69230769230769273e-2f);
-    q = __builtin_fmaf(q, z, 9.09090909090909116e-2f);
-    q = __builtin_fmaf(q, z, 1.11111111111111105e-1f);
-    q = __builtin_fmaf(q, z, 1.42857142857142849e-1f);
-    q = __builtin_fmaf(q, z, 0.2f);
-    q = __builtin_fmaf(q, z, 3.33333333333333315e-1f);
-    q = __builtin_fmaf(q, z, 1.0f);
-    return m + 2.0f * sq * q;
+    float scale = __uint_as_float((uint32_t)e << 23);
+    scale = t0 > -87.0f ? scale : (t0 != t0 ? t0 : 0.0f);
+    const float r2 = r * r, r4 = r2 * r2;
+    const float p01 = 1.0f + r;
+    const float p23 = __builtin_fmaf(1.66666666666666657e-1f, r, 0.5f);
+    const float p45 = __builtin_fmaf(8.33333333333333322e-3f, r, 4.16666666666666644e-2f);
+    const float p67 = __builtin_fmaf(1.98412698412698413e-4f, r, 1.38888888888888894e-3f);
+    const float p = __builtin_fmaf(__builtin_fmaf(p67, r2, p45), r4, __builtin_fmaf(p23, r2, p01));
+    const float t = p * scale;
+    // pw_log1p01's Q and the fused last step
+    const float t2 = t * t, t4 = t2 * t2;
+    const float q01 = __builtin_fmaf(PW_LQ1, t, PW_LQ0);
+    const float q23 = __builtin_fmaf(PW_LQ3, t, PW_LQ2);
+    const float q45 = __builtin_fmaf(PW_LQ5, t, PW_LQ4);
+    const float q67 = __builtin_fmaf(PW_LQ7, t, PW_LQ6);
+    const float q = __builtin_fmaf(__builtin_fmaf(q67, t2, q45), t4, __builtin_fmaf(q23, t2, q01));
+    return __builtin_fmaf(t2, q, t + m);
 }
 
 // get_collision_force seen from entity i against entity j: force on i.
@@ -217,7 +184,7 @@ __device__ __forceinline__ void collision_force_pair(float px, float py, float q
         if (__builtin_expect(in_range, 1)) {
             const float dist = sqrt_rn_core(d2);
             const float xarg = div_chain(-(dist - dist_min), k, div_refined_rcp(k));
-            const float pen = softplus_fastdiv(xarg) * k;
+            const float pen = softplus_branchless(xarg) * k;
             const f32x2 F = div_chain2(a, dist, div_refined_rcp(dist)) * f32x2{pen, pen};
             Fx = F.x;
             Fy = F.y;

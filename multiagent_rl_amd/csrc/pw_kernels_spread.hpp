@@ -197,7 +197,12 @@ __global__ void __launch_bounds__(kWave) pw_spread_fast_kernel(const KParams P, 
 #ifdef PW_STAMPS
 __device__ unsigned long long g_pw_stamps[16];
 #define PW_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_now = 0; (void)st_now
-#define PW_STAMP_START asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory")
+// sampled once, at the first step: afterwards every segment runs from the previous stamp, so the segments of one step add
+// up to the whole loop body
+#define PW_STAMP_START                                                                                  \
+    do {                                                                                                \
+        if (st_prev == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory"); \
+    } while (0)
 #define PW_STAMP(i)                                                                      \
     do {                                                                                 \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory");   \

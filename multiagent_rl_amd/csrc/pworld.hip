@@ -52,6 +52,7 @@ struct pw_handle {
     TagParams tp;   // its constant part (pointers are filled per launch)
     float *comm;    // simple_reference planes inside the bound state block
     int32_t *goal;
+    const char *last_kernel;  // name of the kernel the last pw_step / pw_rollout launched (pw_rollout_kernel)
 };
 
 namespace {
@@ -191,6 +192,14 @@ int check_ready(const pw_handle *h)
     return PW_OK;
 }
 
+// every env-step launch records which kernel it was (pw_rollout_kernel: bench.py and the profile tools name the
+// dominant kernel from the dispatcher's own decision, not from a table kept beside it)
+#define PW_LAUNCH(h, kern, ...)                \
+    do {                                       \
+        (h)->last_kernel = #kern;              \
+        hipLaunchKernelGGL(kern, __VA_ARGS__); \
+    } while (0)
+
 int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
 {
     if (int rc = check_ready(h)) return rc;
@@ -208,13 +217,13 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
     const KParams &kp = h->kp;
     if (h->cfg.scenario == PW_SIMPLE_REFERENCE) {
         if (io->act_idx && !io->act_comm) return fail(PW_EINVAL, "simple_reference needs act_comm next to act_idx");
-        hipLaunchKernelGGL((pw_reference_rollout_kernel<kDimC, false>), dim3((kp.B + 31) / 32), dim3(kWave), 0,
+        PW_LAUNCH(h, (pw_reference_rollout_kernel<kDimC, false>), dim3((kp.B + 31) / 32), dim3(kWave), 0,
                            static_cast<hipStream_t>(stream), ref_params(h), *io, io->act_comm, T);
         PW_HIP_CHECK(hipGetLastError());
         return PW_OK;
     }
     if (h->cfg.scenario == PW_SIMPLE_SPEAKER_LISTENER) {
-        hipLaunchKernelGGL((pw_reference_rollout_kernel<kDimCSL, true>), dim3((kp.B + 31) / 32), dim3(kWave), 0,
+        PW_LAUNCH(h, (pw_reference_rollout_kernel<kDimCSL, true>), dim3((kp.B + 31) / 32), dim3(kWave), 0,
                            static_cast<hipStream_t>(stream), ref_params(h), *io, nullptr, T);
         PW_HIP_CHECK(hipGetLastError());
         return PW_OK;
@@ -239,10 +248,10 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
 #define PW_TAG_LAUNCH(n, a, l, c)                                                                              \
     do {                                                                                                       \
         if (duo) {                                                                                             \
-            if (um) hipLaunchKernelGGL((pw_tag_duo_kernel<n, a, l, true, c>), grid, block2, shm2, st, A, T);   \
-            else hipLaunchKernelGGL((pw_tag_duo_kernel<n, a, l, false, c>), grid, block2, shm2, st, A, T);     \
-        } else if (um) hipLaunchKernelGGL((pw_tag_stream_kernel<n, a, l, true, c>), grid, block, shm, st, A, T); \
-        else hipLaunchKernelGGL((pw_tag_stream_kernel<n, a, l, false, c>), grid, block, shm, st, A, T);        \
+            if (um) PW_LAUNCH(h, (pw_tag_duo_kernel<n, a, l, true, c>), grid, block2, shm2, st, A, T);   \
+            else PW_LAUNCH(h, (pw_tag_duo_kernel<n, a, l, false, c>), grid, block2, shm2, st, A, T);     \
+        } else if (um) PW_LAUNCH(h, (pw_tag_stream_kernel<n, a, l, true, c>), grid, block, shm, st, A, T); \
+        else PW_LAUNCH(h, (pw_tag_stream_kernel<n, a, l, false, c>), grid, block, shm, st, A, T);        \
     } while (0)
         if (wc) {
             if (kp.N == 6 && kp.A == 4 && kp.L == 2 && um) PW_TAG_LAUNCH(6, 4, 2, true);
@@ -290,8 +299,8 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
             if (std::getenv("PWORLD_FORCE_QUAD") && kp.N == 6 && kp.L == 6 && um && !wc) quad = true;
             if (quad) {
                 const size_t qshm = 4 * kWave * sizeof(float4) + 2 * 4 * 6 * 6 * sizeof(float2) + 2 * kWave * sizeof(float) +
-                                    8 * 6 * sizeof(float2) + kWave * sizeof(float4);
-                hipLaunchKernelGGL((pw_spread_quad_kernel<true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
+                                    8 * 6 * sizeof(float2) + kWave * sizeof(float4) + 2 * 4 * kWave * sizeof(int32_t);
+                PW_LAUNCH(h, (pw_spread_quad_kernel<true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
                 PW_HIP_CHECK(hipGetLastError());
                 return PW_OK;
             }
@@ -304,49 +313,49 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
                                 2 * kWave * sizeof(float) + 16 + kWave * sizeof(float4);
             const dim3 block2(2 * kWave);
             if (wc) {
-                if (key == 3) hipLaunchKernelGGL((pw_spread_duo_kernel<3, 3, true, true>), grid, block2, shm2, st, A, T);
-                else if (key == 6) hipLaunchKernelGGL((pw_spread_duo_kernel<6, 6, true, true>), grid, block2, shm2, st, A, T);
-                else if (um) hipLaunchKernelGGL((pw_spread_duo_kernel<0, 0, true, true>), grid, block2, shm2, st, A, T);
-                else hipLaunchKernelGGL((pw_spread_duo_kernel<0, 0, false, true>), grid, block2, shm2, st, A, T);
+                if (key == 3) PW_LAUNCH(h, (pw_spread_duo_kernel<3, 3, true, true>), grid, block2, shm2, st, A, T);
+                else if (key == 6) PW_LAUNCH(h, (pw_spread_duo_kernel<6, 6, true, true>), grid, block2, shm2, st, A, T);
+                else if (um) PW_LAUNCH(h, (pw_spread_duo_kernel<0, 0, true, true>), grid, block2, shm2, st, A, T);
+                else PW_LAUNCH(h, (pw_spread_duo_kernel<0, 0, false, true>), grid, block2, shm2, st, A, T);
                 PW_HIP_CHECK(hipGetLastError());
                 return PW_OK;
             }
             switch (key) {
 #define PW_DUO_CASE(n)                                                                                              \
     case n:                                                                                                         \
-        if (um && blk) hipLaunchKernelGGL((pw_spread_duo_kernel<n, n, true, false, true>), grid, block2, shm2, st, A, T); \
-        else if (um) hipLaunchKernelGGL((pw_spread_duo_kernel<n, n, true>), grid, block2, shm2, st, A, T);          \
-        else hipLaunchKernelGGL((pw_spread_duo_kernel<n, n, false>), grid, block2, shm2, st, A, T);                 \
+        if (um && blk) PW_LAUNCH(h, (pw_spread_duo_kernel<n, n, true, false, true>), grid, block2, shm2, st, A, T); \
+        else if (um) PW_LAUNCH(h, (pw_spread_duo_kernel<n, n, true>), grid, block2, shm2, st, A, T);          \
+        else PW_LAUNCH(h, (pw_spread_duo_kernel<n, n, false>), grid, block2, shm2, st, A, T);                 \
         break;
                 PW_DUO_CASE(3) PW_DUO_CASE(6) PW_DUO_CASE(9) PW_DUO_CASE(12) PW_DUO_CASE(24) PW_DUO_CASE(48)
 #undef PW_DUO_CASE
             default:
-                if (um) hipLaunchKernelGGL((pw_spread_duo_kernel<0, 0, true>), grid, block2, shm2, st, A, T);
-                else hipLaunchKernelGGL((pw_spread_duo_kernel<0, 0, false>), grid, block2, shm2, st, A, T);
+                if (um) PW_LAUNCH(h, (pw_spread_duo_kernel<0, 0, true>), grid, block2, shm2, st, A, T);
+                else PW_LAUNCH(h, (pw_spread_duo_kernel<0, 0, false>), grid, block2, shm2, st, A, T);
             }
             PW_HIP_CHECK(hipGetLastError());
             return PW_OK;
         }
         if (wc) {
-            if (key == 3) hipLaunchKernelGGL((pw_spread_stream_kernel<3, 3, true, true>), grid, block, shm, st, A, T);
-            else if (key == 6) hipLaunchKernelGGL((pw_spread_stream_kernel<6, 6, true, true>), grid, block, shm, st, A, T);
-            else if (um) hipLaunchKernelGGL((pw_spread_stream_kernel<0, 0, true, true>), grid, block, shm, st, A, T);
-            else hipLaunchKernelGGL((pw_spread_stream_kernel<0, 0, false, true>), grid, block, shm, st, A, T);
+            if (key == 3) PW_LAUNCH(h, (pw_spread_stream_kernel<3, 3, true, true>), grid, block, shm, st, A, T);
+            else if (key == 6) PW_LAUNCH(h, (pw_spread_stream_kernel<6, 6, true, true>), grid, block, shm, st, A, T);
+            else if (um) PW_LAUNCH(h, (pw_spread_stream_kernel<0, 0, true, true>), grid, block, shm, st, A, T);
+            else PW_LAUNCH(h, (pw_spread_stream_kernel<0, 0, false, true>), grid, block, shm, st, A, T);
             PW_HIP_CHECK(hipGetLastError());
             return PW_OK;
         }
         switch (key) {
 #define PW_STREAM_CASE(n)                                                                                           \
     case n:                                                                                                         \
-        if (um && blk) hipLaunchKernelGGL((pw_spread_stream_kernel<n, n, true, false, true>), grid, block, shm, st, A, T); \
-        else if (um) hipLaunchKernelGGL((pw_spread_stream_kernel<n, n, true>), grid, block, shm, st, A, T);         \
-        else hipLaunchKernelGGL((pw_spread_stream_kernel<n, n, false>), grid, block, shm, st, A, T);                \
+        if (um && blk) PW_LAUNCH(h, (pw_spread_stream_kernel<n, n, true, false, true>), grid, block, shm, st, A, T); \
+        else if (um) PW_LAUNCH(h, (pw_spread_stream_kernel<n, n, true>), grid, block, shm, st, A, T);         \
+        else PW_LAUNCH(h, (pw_spread_stream_kernel<n, n, false>), grid, block, shm, st, A, T);                \
         break;
             PW_STREAM_CASE(3) PW_STREAM_CASE(6) PW_STREAM_CASE(9) PW_STREAM_CASE(12) PW_STREAM_CASE(24) PW_STREAM_CASE(48)
 #undef PW_STREAM_CASE
         default:
-            if (um) hipLaunchKernelGGL((pw_spread_stream_kernel<0, 0, true>), grid, block, shm, st, A, T);
-            else hipLaunchKernelGGL((pw_spread_stream_kernel<0, 0, false>), grid, block, shm, st, A, T);
+            if (um) PW_LAUNCH(h, (pw_spread_stream_kernel<0, 0, true>), grid, block, shm, st, A, T);
+            else PW_LAUNCH(h, (pw_spread_stream_kernel<0, 0, false>), grid, block, shm, st, A, T);
         }
         PW_HIP_CHECK(hipGetLastError());
         return PW_OK;
@@ -356,18 +365,18 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         switch (kp.N) {
 #define PW_FAST_CASE(n)                                                                                      \
     case n:                                                                                                  \
-        hipLaunchKernelGGL((pw_spread_fast_kernel<n>), grid, block, shmem, st, kp, *io, T, h->fc);           \
+        PW_LAUNCH(h, (pw_spread_fast_kernel<n>), grid, block, shmem, st, kp, *io, T, h->fc);           \
         break;
             PW_FAST_CASE(3) PW_FAST_CASE(6) PW_FAST_CASE(9) PW_FAST_CASE(12)
 #undef PW_FAST_CASE
         default:
-            hipLaunchKernelGGL((pw_spread_fast_kernel<0>), grid, block, shmem, st, kp, *io, T, h->fc);
+            PW_LAUNCH(h, (pw_spread_fast_kernel<0>), grid, block, shmem, st, kp, *io, T, h->fc);
         }
         PW_HIP_CHECK(hipGetLastError());
         return PW_OK;
     }
     return dispatch(h, [&](auto scen, auto obs) {
-        hipLaunchKernelGGL((pw_rollout_kernel<decltype(scen)::value, decltype(obs)::value>), grid, block, shmem,
+        PW_LAUNCH(h, (pw_rollout_kernel<decltype(scen)::value, decltype(obs)::value>), grid, block, shmem,
                            static_cast<hipStream_t>(stream), kp, *io, T);
         PW_HIP_CHECK(hipGetLastError());
         return (int)PW_OK;
@@ -501,6 +510,7 @@ int pw_create(const pw_config *cfg, pw_handle **out)
     if (!h) return fail(PW_ENOMEM, "out of host memory");
     h->cfg = *cfg;
     h->bound = false;
+    h->last_kernel = nullptr;
     KParams &kp = h->kp;
     std::memset(&kp, 0, sizeof(kp));
     kp.B = cfg->num_envs; kp.N = cfg->num_agents; kp.L = cfg->num_landmarks;
@@ -679,6 +689,8 @@ int pw_reward(pw_handle *h, float *rew, uint64_t *coll, void *stream)
 }
 
 int pw_step(pw_handle *h, const pw_step_io *io, void *stream) { return launch_rollout(h, io, 1, stream); }
+
+const char *pw_rollout_kernel(const pw_handle *h) { return h && h->last_kernel ? h->last_kernel : ""; }
 
 int pw_rollout(pw_handle *h, const pw_step_io *io, int num_steps, void *stream)
 {

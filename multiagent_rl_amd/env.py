@@ -297,6 +297,10 @@ class BatchedParticleEnv(object):
         info = {k: out[k] for k in ('terminal', 'rew_shared', 'final_obs', 'coll') if k in out}
         return out['obs'], out['rew'], out['done'], info
 
+    def last_kernel(self):
+        """Name of the device kernel the last step / rollout launched, e.g. 'pw_spread_quad_kernel<true>' (pw_rollout_kernel)."""
+        return self.lib.pw_rollout_kernel(self._h).decode().strip('()').replace(', ', ',')
+
     def rollout(self, actions, out=None):
         """T steps in one launch; actions [T,B,N] int (or [T,B,N,5] float) -> dict of [T,...] tensors."""
         T = int(actions.shape[0])

@@ -72,7 +72,8 @@ PO_EXPORT int po_obs_dim(const po_config *c)
 /* ---- deterministic float32 math (restated, not shared, from include/pworld_math.h) ---- */
 static inline float po_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-/* exp(x), x in (-87, 88); x <= -87 -> 0 exactly; x >= 88 -> 2^127 */
+/* exp(x), x in (-87, 88); x <= -87 -> 0 exactly; x >= 88 -> 2^127.  Contract revision 3: degree-7 Taylor in
+ * Estrin form (pairs, then r^2, r^4) */
 PO_EXPORT float po_exp_det_f32(float x)
 {
     if (!(x > -87.0f)) return x != x ? x : 0.0f;
@@ -80,40 +81,40 @@ PO_EXPORT float po_exp_det_f32(float x)
     float n = floorf(fmaf(x, 1.44269504088896341f, 0.5f));
     float r = fmaf(n, -0.693359375f, x);             /* ln2 hi (exact in 9 bits) */
     r = fmaf(n, 2.12194440054690583e-4f, r);         /* ln2 lo */
-    float p = 1.98412698412698413e-4f;               /* 1/5040 */
-    p = fmaf(p, r, 1.38888888888888894e-3f);         /* 1/720 */
-    p = fmaf(p, r, 8.33333333333333322e-3f);         /* 1/120 */
-    p = fmaf(p, r, 4.16666666666666644e-2f);         /* 1/24 */
-    p = fmaf(p, r, 1.66666666666666657e-1f);         /* 1/6 */
-    p = fmaf(p, r, 0.5f);
-    p = fmaf(p, r, 1.0f);
-    p = fmaf(p, r, 1.0f);
+    const float r2 = r * r, r4 = r2 * r2;
+    const float a = 1.0f + r;
+    const float b = fmaf(1.66666666666666657e-1f, r, 0.5f);                     /* 1/2 + r/6 */
+    const float c = fmaf(8.33333333333333322e-3f, r, 4.16666666666666644e-2f);  /* 1/24 + r/120 */
+    const float d = fmaf(1.98412698412698413e-4f, r, 1.38888888888888894e-3f);  /* 1/720 + r/5040 */
+    const float p = fmaf(fmaf(d, r2, c), r4, fmaf(b, r2, a));
     int32_t e = (int32_t)n + 127;
     return p * po_u2f((uint32_t)e << 23);
 }
 
-/* log1p(t), t in [0, 1]: 2 atanh(t / (2 + t)) */
-PO_EXPORT float po_log1p_det_f32(float t)
+/* Q(t) ~ (log1p(t) - t) / t^2 on [0, 1]: degree-7 minimax, Estrin form */
+static inline float po_log1p_q_f32(float t)
 {
-    float s = t / (2.0f + t);
-    float z = s * s;
-    float q = 6.66666666666666657e-2f;               /* 1/15 */
-    q = fmaf(q, z, 7.69230769230769273e-2f);         /* 1/13 */
-    q = fmaf(q, z, 9.09090909090909116e-2f);         /* 1/11 */
-    q = fmaf(q, z, 1.11111111111111105e-1f);         /* 1/9 */
-    q = fmaf(q, z, 1.42857142857142849e-1f);         /* 1/7 */
-    q = fmaf(q, z, 0.2f);
-    q = fmaf(q, z, 3.33333333333333315e-1f);         /* 1/3 */
-    q = fmaf(q, z, 1.0f);
-    return 2.0f * s * q;
+    const float t2 = t * t, t4 = t2 * t2;
+    const float a = fmaf(3.332236707e-01f, t, -4.999969006e-01f);
+    const float b = fmaf(1.919044554e-01f, t, -2.486616373e-01f);
+    const float c = fmaf(8.017139137e-02f, t, -1.383424997e-01f);
+    const float d = fmaf(5.516789388e-03f, t, -3.066807054e-02f);
+    return fmaf(fmaf(d, t2, c), t4, fmaf(b, t2, a));
 }
 
-/* logaddexp(0, x) = max(x, 0) + log1p(exp(-|x|)) */
+/* log1p(t), t in [0, 1]: t + t^2 Q(t) */
+PO_EXPORT float po_log1p_det_f32(float t)
+{
+    return fmaf(t * t, po_log1p_q_f32(t), t);
+}
+
+/* logaddexp(0, x) = max(x, 0) + log1p(exp(-|x|)); the max goes into the last fused step */
 PO_EXPORT float po_softplus_det_f32(float x)
 {
     float ax = x < 0.0f ? -x : x;
     float m = x > 0.0f ? x : 0.0f;
-    return m + po_log1p_det_f32(po_exp_det_f32(-ax));
+    const float t = po_exp_det_f32(-ax);
+    return fmaf(t * t, po_log1p_q_f32(t), t + m);
 }
 
 /* vectorised forms for the device-math bit tests: fn 0/4 sqrtf, 1/2 softplus, 3 exp, 5 x / aux */

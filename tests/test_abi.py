@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'libpworld.so lacks %s declared in include/pworld.h' % n
     assert set(names) == set(_lib.SIGNATURES), 'ctypes table and header disagree: %s' % (
         set(names) ^ set(_lib.SIGNATURES))
-    assert lib.pw_version() == 101
+    assert lib.pw_version() == 102
 
 
 def test_config_default_matches_canonical_constants():

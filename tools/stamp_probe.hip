@@ -27,18 +27,25 @@ int main(int argc, char **argv)
     hipMalloc((void **)&io.done, (size_t)T * BN); hipMalloc((void **)&io.terminal, (size_t)T * B);
     pw_reset(h, nullptr, nullptr, nullptr);
     unsigned long long tot[16] = {0};
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double wall_ms = 0;
     for (int r = 0; r < reps; ++r) {
+        hipEventRecord(e0, nullptr);
         if (pw_rollout(h, &io, T, nullptr)) { printf("rollout: %s\n", pw_last_error()); return 1; }
+        hipEventRecord(e1, nullptr);
         hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (r >= 5) wall_ms += ms;
         unsigned long long s[16];
         hipMemcpyFromSymbol(s, HIP_SYMBOL(g_pw_stamps), sizeof(s));
         if (r >= 5) for (int i = 0; i < 16; ++i) tot[i] += s[i];
     }
     if (N == 6 && !getenv("PWORLD_NO_QUAD") && B <= 8192) {
-        const char *qn[8] = {"P: pair phase (LDS read, near test, force, table write)", "P: row add + integrate + publish", "P: barrier wait", "-",
+        const char *qn[8] = {"P: pair phase (LDS read, near test, force, table write)", "P: row add + integrate + publish", "P: barrier wait", "P: wait for the step's action indices (vmcnt)",
                              "OA: barrier wait", "OA: masks + rewards + stores", "OB: barrier wait", "OB: observation rows"};
-        printf("B=%d N=%d (quad kernel): cycles per step, workgroup 0\n", B, N);
-        for (int i = 0; i < 8; ++i) if (i != 3) printf("  %-58s %7.0f cycles\n", qn[i], tot[i] / (double)((reps - 5) * T));
+        printf("B=%d N=%d (quad kernel): cycles per step, workgroup 0; this stamped build runs %.3f us per step\n", B, N,
+               wall_ms * 1e3 / ((reps - 5) * T));
+        for (int i = 0; i < 8; ++i) printf("  %-58s %7.0f cycles\n", qn[i], tot[i] / (double)((reps - 5) * T));
         return 0;
     }
     const bool duo = !getenv("PWORLD_NO_DUO");
