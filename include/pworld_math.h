@@ -110,9 +110,8 @@ PW_HD float pw_log1p01(float t)
  * exactly x for x >= 87. */
 PW_HD float pw_softplus(float x)
 {
-    float ax = x < 0.0f ? -x : x;
     float m = x > 0.0f ? x : 0.0f;
-    float t = pw_exp(-ax);
+    float t = pw_exp(-fabsf(x));
     return fmaf(t * t, pw_log1p01_q(t), t + m);
 }
 

@@ -121,6 +121,29 @@ __device__ __forceinline__ f32x2 div_chain2(f32x2 a, float b, float y)
     return __builtin_elementwise_fma(__builtin_elementwise_fma(nb, q1, a), yy, q1);
 }
 
+// ---- action indices fetched AHEAD by LDS-direct loads ---------------------------------------------------------------
+// A physics wave reads one action index per lane and step from HBM.  Issued one step ahead into a register, that load
+// costs a full chip 250-400 cycles of every step (stamps: profiles/r2_action_prefetch.txt): HBM latency under a
+// 3-4 TB/s write stream exceeds a step.  Fetching further ahead into registers does not work -- rotating pending
+// registers through an unrolled loop makes the compiler copy them at the back edge, and a copy of a pending load waits
+// for it -- so the loads write LDS directly (global_load_lds_dword: destination = M0 + 4 * lane, no register), four steps
+// ahead, into a four-slot ring of the wave.  The compiler does not count these loads; the wave must have NO other vector
+// memory operation in its step loop (the physics waves of the duo / quad kernels have none: the output waves do the
+// stores), must have consumed every counted load before the first fetch, and writes its waits out: vmcnt(3) at the
+// top of step t leaves the fetches of steps t+1 .. t+3 in flight.
+__device__ __forceinline__ void act_fetch_issue(const int32_t *src_lane, const uint32_t lds_slot)
+{
+    unsigned keep;
+    // every earlier LDS read of this wave has returned (the slot's previous content was read four steps ago, but the
+    // order is cheap to guarantee); M0 is the compiler's: saved and restored inside the statement
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src_lane), "s"(lds_slot) : "memory");
+}
+__device__ __forceinline__ void act_fetch_wait3() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+__device__ __forceinline__ void act_fetch_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+constexpr int kActRingBytes = 4 * kWave * (int)sizeof(int32_t);  // per physics wave
+
 // pw_softplus (include/pworld_math.h, contract revision 3): the same operations, so the same bits, but branch-free --
 // the polynomial runs on a clamped argument and the exact-zero cut / NaN pass-through ride on the power-of-two scale
 // factor, which is computed beside the polynomial, not after it.  The dependent chain from x to the result is 15
@@ -128,9 +151,8 @@ __device__ __forceinline__ f32x2 div_chain2(f32x2 a, float b, float y)
 // 2: 42, a third of them the division inside log1p).
 __device__ __forceinline__ float softplus_branchless(float x)
 {
-    const float ax = x < 0.0f ? -x : x;
     const float m = x > 0.0f ? x : 0.0f;
-    const float t0 = -ax;                        // <= 0, or NaN
+    const float t0 = -__builtin_fabsf(x);        // <= 0, or NaN; a source modifier of the clamp below, not an instruction
     const float tc = t0 > -87.0f ? t0 : -87.0f;  // keep the exponent arithmetic in range when cut (and for NaN)
     const float n = floorf(__builtin_fmaf(tc, 1.44269504088896341f, 0.5f));
     float r = __builtin_fmaf(n, -0.693359375f, tc);

@@ -99,26 +99,13 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         wave_lds_sync();
         const float k = A.contact_margin, cf = A.contact_force, dt = A.dt, damp = A.damp, mass = A.mass;
         const uint32_t near_lo = __float_as_uint(A.near_thr2), near_span = 0x7F800000u - near_lo;
-        // Action indices come from HBM once per step and lane.  Under a full chip that load takes longer than a step
-        // (measured: 385 cycles of every step were spent waiting for a load issued one step ahead), so they are fetched
-        // FOUR steps ahead -- by loads that write LDS directly (global_load_lds_dword: destination = M0 + 4 * lane,
-        // no register), into a four-slot ring of this wave.  A register destination does not work here: rotating four
-        // pending registers through an unrolled loop makes the compiler copy them at the back edge, and a copy of a
-        // pending load waits for it.  The compiler does not count these loads (nor does anything else in this wave's
-        // loop use vmcnt), so the waits are written out: vmcnt(3) at the top of step t leaves the loads of steps
-        // t+1 .. t+3 in flight.
+        // Action indices: fetched four steps ahead by LDS-direct loads (pw_common.hpp, act_fetch_issue: under a full chip
+        // a load issued one step ahead cost 385 cycles of every step)
         const int32_t *act_g = A.act + g;
         int32_t *act_ring = s_act + wave * (4 * kWave);
         const uint32_t act_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(act_ring));
         auto fetch_act = [&](int t) {  // indices of step t (clamped: the tail re-fetches the last step) -> slot t & 3
-            const int32_t *src = act_g + (size_t)(t < T ? t : T - 1) * BN;
-            const uint32_t dst = act_lds + (uint32_t)(t & 3) * (kWave * 4);
-            unsigned keep;
-            // every earlier LDS read of this wave has returned (the slot's previous content was read four steps ago,
-            // but the order is cheap to guarantee), M0 is the compiler's: saved and restored inside the statement
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            act_fetch_issue(act_g + (size_t)(t < T ? t : T - 1) * BN, act_lds + (uint32_t)(t & 3) * (kWave * 4));
         };
         // every load the compiler counts is consumed before the first uncounted one is issued: a counted wait inside the
         // loop (for a value first used there) would be short by the fetches in flight, i.e. drain them
@@ -132,7 +119,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         PW_STAMP_DECL;
         for (int t = 0; t < T; ++t) {
             PW_STAMP_START;
-            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // step t's indices are in LDS
+            act_fetch_wait3();  // step t's indices are in LDS
             PW_STAMP(3);
             const int ai = act_ring[(t & 3) * kWave + lane];
             const bool two_slots = any_reset_step();  // workgroup-uniform; early: it does not depend on the physics
@@ -188,7 +175,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             duo_barrier();
             PW_STAMP(2);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's fetches have landed before the wave ends
+        act_fetch_drain();  // the tail's fetches have landed before the wave ends
 #ifdef PW_STAMPS
         if (blockIdx.x == 0 && wave == 0 && lane == 0)
             for (int i_ = 0; i_ < 4; ++i_) g_pw_stamps[i_] = st_acc[i_];

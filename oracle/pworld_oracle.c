@@ -111,9 +111,8 @@ PO_EXPORT float po_log1p_det_f32(float t)
 /* logaddexp(0, x) = max(x, 0) + log1p(exp(-|x|)); the max goes into the last fused step */
 PO_EXPORT float po_softplus_det_f32(float x)
 {
-    float ax = x < 0.0f ? -x : x;
     float m = x > 0.0f ? x : 0.0f;
-    const float t = po_exp_det_f32(-ax);
+    const float t = po_exp_det_f32(-fabsf(x));
     return fmaf(t * t, po_log1p_q_f32(t), t + m);
 }
 
