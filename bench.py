@@ -179,7 +179,7 @@ class _StubEnv(object):
             out['final_obs'].fill_(-float(1000 * self.rank + k))
 
 
-def _profile_lookup(scenario, N, B):
+def _profile_lookup(scenario, N, B, kernel=None):
     """Counter-side figures of the dominant kernel from the committed rocprofv3 summaries (profiles/): HBM traffic
     per ENV-STEP (FETCH_SIZE + WRITE_SIZE passes, per the MI355X guide) and the VALU issue share (SQ counters).
     PMC counters cannot be read from inside this process; bench scales the per-env-step figure to its launch."""
@@ -192,6 +192,10 @@ def _profile_lookup(scenario, N, B):
             continue
         w = sm.get('workload', {})
         if w.get('scenario') == scenario and w.get('N') == N and w.get('B') == B and 'traffic_bytes_per_env_step' in sm:
+            # counters belong to a kernel: only a profile of the kernel that actually ran is quoted
+            fam = (kernel or '').split('<')[0]
+            if fam and fam not in sm.get('kernel', ''):
+                continue
             best = dict(sm, _file=os.path.relpath(f, ROOT))
             break
     return best
@@ -203,6 +207,7 @@ def main():
     ap.add_argument('--steps', type=int, default=40,
                     help='timed bench steps = pw_rollout launches of --chunk batched env steps each')
     ap.add_argument('--warmup', type=int, default=4, help='untimed launches of the same size')
+    ap.add_argument('--ramp-ms', type=float, default=60.0, help='untimed launches for this long before the warm-up (clock ramp)')
     ap.add_argument('--envs', type=int, default=4096, help='B per GPU')
     ap.add_argument('--agents', type=int, default=6)
     ap.add_argument('--chunk', type=int, default=1000,
@@ -317,6 +322,20 @@ def main():
             except Exception as e:
                 exchange_state['error'] = repr(e)[:200]
 
+    # Clock ramp.  A chip that has been idle (the CPU baseline above runs for ~20 s) reaches its sustained clock only
+    # after tens of milliseconds of load: with the driver's `--warmup 5` (3 ms of launches) the timed launches ran
+    # 6 % slower than after 50 (profiles/README.md).  So the SAME launch runs untimed for --ramp-ms first; the env is
+    # then reset again, so the W warm-up and K timed launches below start from the state they always started from.
+    ramp = dict(launches=0, ms=0.0)
+    if not STUB and args.ramp_ms > 0:
+        env.reset()
+        t_r = time.perf_counter()
+        while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
+            for i in range(8):
+                slots[i % RING][0]()
+            sync()
+            ramp['launches'] += 8
+        ramp['ms'] = (time.perf_counter() - t_r) * 1e3
     env.reset()
     run(W, 0)
     if shard is not None:
@@ -352,7 +371,7 @@ def main():
     bytes_per_launch = float(env.bytes_per_env_step) * env_steps_per_launch
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
 
-    prof = _profile_lookup(args.scenario, N, B)
+    prof = _profile_lookup(args.scenario, N, B, env.last_kernel() if hasattr(env, 'last_kernel') else None)
     traffic = frac_by_traffic = None
     issue = None
     if prof is not None:
@@ -402,8 +421,10 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'stub (tests only: no kernel ran)' if STUB else 'synthetic',
             'config': {'workload': '%s N=%d L=%d, B=%d envs per GPU (global %d), local obs D=%d, episode 25 with '
                                    'auto-reset, uniform int32 action indices; 1 bench step = 1 pw_rollout launch = %d '
-                                   'batched env steps; %d launches timed after %d warm-up launches'
-                                   % (args.scenario, N, env.num_landmarks, B, world * B, D, T, K, W),
+                                   'batched env steps; %d launches timed after %d warm-up launches (before those: an '
+                                   'untimed clock ramp of %d of the same launches, %.0f ms, then a reset)'
+                                   % (args.scenario, N, env.num_landmarks, B, world * B, D, T, K, W, ramp['launches'], ramp['ms']),
+                       'clock_ramp': ramp,
                        'env_steps_per_step': world * B * T, 'batched_env_steps_per_launch': T,
                        'batched_env_steps_timed': K * T, 'us_per_batched_env_step': elapsed * 1e6 / (K * T),
                        'global_batch': world * B, 'parallelism': 'env-shard x%d' % world,

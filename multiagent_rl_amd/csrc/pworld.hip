@@ -294,7 +294,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         // while the chip is latency bound.  PWORLD_FORCE_QUAD / PWORLD_NO_QUAD override (tests, experiments).
         {
             const unsigned qgrid = (unsigned)((kp.B + 7) / 8);
-            bool quad = kp.N == 6 && kp.L == 6 && um && !wc && qgrid <= 768 && !std::getenv("PWORLD_NO_DUO");  // B <= 6144: measured crossover
+            bool quad = kp.N == 6 && kp.L == 6 && um && !wc && qgrid <= 1536 && !std::getenv("PWORLD_NO_DUO");  // B <= 12288: measured crossover (profiles/r2_sweeps_final.txt)
             if (std::getenv("PWORLD_NO_QUAD")) quad = false;
             if (std::getenv("PWORLD_FORCE_QUAD") && kp.N == 6 && kp.L == 6 && um && !wc) quad = true;
             if (quad) {
