@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
     float2 *s_lmB = reinterpret_cast<float2 *>(s_rew + kWave);             // [8 * 6] OB (16-byte aligned)
     float4 *s_rowB = reinterpret_cast<float4 *>(s_lmB + EPW * L);          // [64] OB: {pos, vel} of every row
     int32_t *s_act = reinterpret_cast<int32_t *>(s_rowB + kWave);          // [2 P waves][4 steps][64] action indices
+    float2 *s_utab = reinterpret_cast<float2 *>(s_act + 2 * 4 * kWave);    // [2 P waves][8] action force per index
 
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = (int)threadIdx.x & 63;
@@ -54,13 +55,27 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
     const int envs_here = A.B - env0 < EPW ? A.B - env0 : EPW;
     const size_t BN = (size_t)A.B * N;
 
-    // every wave follows the episode clocks of all 8 envs (lane e < 8 <-> env e): is there a reset in this step?
-    int eps_all = A.ep_step[env0 + (lane < envs_here ? lane : 0)];
-    auto any_reset_step = [&]() -> bool {
-        const int e1 = eps_all + 1;
-        const bool rst = A.auto_reset && A.max_episode_len > 0 && e1 >= A.max_episode_len;
-        eps_all = rst ? 0 : e1;
-        return __any(rst && lane < envs_here);
+    // Episode clocks.  Every wave follows the clocks of all 8 envs (lane e < 8 <-> env e), but not by counting: a clock
+    // is kept as an offset -- clock before step t = t + off -- so nothing has to be incremented, and the workgroup-uniform
+    // question "does any env reset in this step?" is one scalar compare with t_reset, the first step in which one does;
+    // the vector work (which envs, the new offsets, the next t_reset) runs only in those steps.
+    const bool resets = A.auto_reset && A.max_episode_len > 0;
+    int offs_all = A.ep_step[env0 + (lane < envs_here ? lane : 0)];
+    auto next_reset_step = [&](int t_from) -> int {  // first step >= t_from in which some env's clock reaches max_episode_len
+        if (!resets) return 0x7fffffff;
+        int rem = A.max_episode_len - 1 - (t_from + offs_all);
+        rem = rem < 0 ? 0 : rem;
+        int m = 0x7fffffff;
+        for (int e = 0; e < envs_here; ++e) {  // 8 scalar reads: runs once per episode end
+            const int r = __builtin_amdgcn_readlane(rem, e);
+            m = r < m ? r : m;
+        }
+        return t_from + m;
+    };
+    int t_reset = next_reset_step(0);
+    auto reset_step_update = [&](int t) {  // call in a step with t == t_reset, once: the clocks that reached the end restart
+        if (t + 1 + offs_all >= A.max_episode_len) offs_all = -(t + 1);
+        t_reset = next_reset_step(t + 1);
     };
     int cur = 0;  // ring slot of the current state: workgroup-uniform
 
@@ -85,17 +100,27 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         int pi, pj;
         quad_pair_of(pq, pi, pj);
         const int ri = (e0 + pe) * N + pi, rj = (e0 + pe) * N + pj;
+        // force table [agent][partner slot]: a row holds the agent's 5 partners in ascending order (slot = partner index,
+        // minus one behind the agent's own index), padded to 6 entries so that rows stay 16-byte aligned
         float2 *ftab = s_ftab + wave * (EPP * N * N);
-        float2 *f_ij = ftab + (pe * N + pi) * N + pj, *f_ji = ftab + (pe * N + pj) * N + pi;
+        float2 *f_ij = ftab + (pe * N + pi) * N + (pj - 1), *f_ji = ftab + (pe * N + pj) * N + pi;   // pi < pj
         const float2 *row = ftab + (e4 * N + a) * N;
 
         float px = A.pos_x[g], py = A.pos_y[g], vx = A.vel_x[g], vy = A.vel_y[g];
-        int ep_step = A.ep_step[env];
+        int ep_off = A.ep_step[env];  // clock before step t = t + ep_off
         uint32_t ep_count = A.ep_count[env];
         s_ring[me] = make_float4(px, py, vx, vy);
-        // the table's diagonal is never written by a pair lane: +0 there lets the agent lanes add the whole row (an
-        // accumulator that is never -0 is unchanged by + 0) instead of selecting around their own index
-        ftab[(e4 * N + a) * N + a] = make_float2(0.0f, 0.0f);
+        // U2 + U4 as a table: the action force of an index is one of five constants, computed here once with the step's
+        // own expressions (so the bits are the step's), entry 5 = any other index (no force); a step reads ONE entry
+        float2 *utab = s_utab + wave * 8;
+        if (lane < 6) {
+            const int ai = lane;
+            float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
+            float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
+            ux *= A.sens; uy *= A.sens;
+            if (A.fscale != 1.0f) { ux = A.fscale * ux; uy = A.fscale * uy; }
+            utab[lane] = make_float2(ux + 0.0f, uy + 0.0f);
+        }
         wave_lds_sync();
         const float k = A.contact_margin, cf = A.contact_force, dt = A.dt, damp = A.damp, mass = A.mass;
         const uint32_t near_lo = __float_as_uint(A.near_thr2), near_span = 0x7F800000u - near_lo;
@@ -109,7 +134,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         };
         // every load the compiler counts is consumed before the first uncounted one is issued: a counted wait inside the
         // loop (for a value first used there) would be short by the fetches in flight, i.e. drain them
-        asm volatile("" :: "v"(ep_step), "v"(ep_count), "v"(eps_all), "v"(px), "v"(py), "v"(vx), "v"(vy));
+        asm volatile("" :: "v"(ep_off), "v"(ep_count), "v"(offs_all), "v"(px), "v"(py), "v"(vx), "v"(vy), "s"(t_reset));
         fetch_act(0); fetch_act(1); fetch_act(2); fetch_act(3);
         // the pair lanes' operands of the coming step are fetched right after the publish, before the barrier (this
         // wave only reads its own envs' entries, and a wave's LDS operations execute in issue order): the read's latency
@@ -121,8 +146,9 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             PW_STAMP_START;
             act_fetch_wait3();  // step t's indices are in LDS
             PW_STAMP(3);
-            const int ai = act_ring[(t & 3) * kWave + lane];
-            const bool two_slots = any_reset_step();  // workgroup-uniform; early: it does not depend on the physics
+            const uint32_t ai = (uint32_t)act_ring[(t & 3) * kWave + lane];
+            const float2 u0 = utab[ai < 5u ? ai : 5u];  // {u_x + 0, u_y + 0}: the accumulators' starting values
+            const bool two_slots = t == t_reset;        // workgroup-uniform: some env of the workgroup resets in this step
             // ---- pair phase: every unordered pair of the wave's envs at once
             float Fx = 0.0f, Fy = 0.0f;
             {
@@ -134,16 +160,11 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             *f_ij = make_float2(Fx, Fy);
             *f_ji = make_float2(-Fx, -Fy);
             PW_STAMP(0);
-            // ---- U2 + U4 of the agent lanes, meanwhile
-            float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
-            float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
-            ux *= A.sens; uy *= A.sens;
-            if (A.fscale != 1.0f) { ux = A.fscale * ux; uy = A.fscale * uy; }
-            float fx = ux + 0.0f, fy = uy + 0.0f;
+            float fx = u0.x, fy = u0.y;
             fetch_act(t + 4);  // into the slot just read; also the program-order point between table writes and row reads
             // ---- U5: the agent's row, ascending partner order
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
+            for (int j = 0; j < N - 1; ++j) {
                 const float2 F = row[j];
                 fx = F.x + fx;
                 fy = F.y + fy;
@@ -156,14 +177,14 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             py = py + vy * dt;
             int nxt = (cur + 1) & 3;
             s_ring[nxt * kWave + me] = make_float4(px, py, vx, vy);
-            ep_step += 1;
-            if (A.auto_reset && A.max_episode_len > 0 && ep_step >= A.max_episode_len) {
-                ep_count += 1;
-                ep_step = 0;
-                pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
-                vx = 0.f; vy = 0.f;
-            }
-            if (two_slots) {  // every env publishes a second slot
+            if (two_slots) {  // rare (once per episode): the envs at their episode's end restart, EVERY env publishes a second slot
+                if (t + 1 + ep_off >= A.max_episode_len) {
+                    ep_count += 1;
+                    ep_off = -(t + 1);
+                    pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
+                    vx = 0.f; vy = 0.f;
+                }
+                reset_step_update(t);
                 nxt = (nxt + 1) & 3;
                 s_ring[nxt * kWave + me] = make_float4(px, py, vx, vy);
             }
@@ -182,7 +203,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
 #endif
         A.pos_x[g] = px; A.pos_y[g] = py;
         A.vel_x[g] = vx; A.vel_y[g] = vy;
-        A.ep_step[env] = ep_step;
+        A.ep_step[env] = T + ep_off;
         A.ep_count[env] = ep_count;
         return;
     }
@@ -195,7 +216,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
     const int base = e_local * N, me = base + a;
     const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
     const uint64_t env_id = A.env_id_base + (uint64_t)env;
-    int ep_step = A.ep_step[env];
+    int ep_off = A.ep_step[env];  // clock before step t = t + ep_off
     uint32_t ep_count = A.ep_count[env];
     float olx = A.lm_x[(size_t)env * L + a], oly = A.lm_y[(size_t)env * L + a];  // the landmark this lane owns
 
@@ -211,41 +232,49 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             const float4 *slot = s_ring + nxt * kWave + base;
             const float2 mine = *reinterpret_cast<const float2 *>(slot + a);
             const float px = mine.x, py = mine.y;
-            uint32_t coll = 0;
-            float best = 0.0f;
+            int cnt = 0;
+            float e2[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const float2 q = *reinterpret_cast<const float2 *>(slot + j);
                 const float dx = q.x - px, dy = q.y - py;
                 const float d2 = dx * dx + dy * dy;
-                if (d2 < A.coll_thr2) coll |= 1u << j;
+                cnt += d2 < A.coll_thr2 ? 1 : 0;
                 const float ex = q.x - olx, ey = q.y - oly;
-                const float e2 = ex * ex + ey * ey;
-                best = (j == 0 || e2 < best) ? e2 : best;
+                e2[j] = ex * ex + ey * ey;
             }
+            // min() keeps its first argument unless a later one is smaller: a NaN in front stays, NaNs behind are
+            // skipped -- i.e. the NaN-ignoring minimum of all six unless the first one is NaN (e2 is never -0): a tree
+            float best = __builtin_fminf(__builtin_fminf(__builtin_fminf(e2[0], e2[1]), __builtin_fminf(e2[2], e2[3])),
+                                         __builtin_fminf(e2[4], e2[5]));
+            best = e2[0] != e2[0] ? e2[0] : best;
             // per-env reductions by wave shuffle (ds_bpermute: one trip each, no LDS write -> wait -> read)
-            const float own = sqrtf(best);
+            const float own = sqrtf(best);  // branch-free expansion: the guarded fast form (a vector compare feeding exec) measured 8 % slower on this chain
             float r = 0.0f;
 #pragma unroll
             for (int l = 0; l < L; ++l) r -= __shfl(own, base + l, kWave);
+            // "rew -= 1" once per colliding agent (itself included): the subtrahends are all the same, so only their
+            // number matters; r - 0 is r, so the six steps are selects of the subtrahend, not branches (a loop up to the
+            // wave's largest count was measured: a vector compare feeding a scalar branch per iteration costs more)
 #pragma unroll
-            for (int j = 0; j < N; ++j)
-                if ((coll >> j) & 1) r -= 1.0f;
+            for (int k2 = 0; k2 < N; ++k2) r -= k2 < cnt ? 1.0f : 0.0f;
             float acc = 0.0f;
 #pragma unroll
             for (int i = 0; i < N; ++i) acc += __shfl(r, base + i, kWave);
             A.rew[tBN + g] = r;
             A.done[tBN + g] = 0;
             A.rew_shared[(size_t)t * A.B + env] = acc;
-            ep_step += 1;
-            const bool term = A.max_episode_len > 0 && ep_step >= A.max_episode_len;
+            const bool term = A.max_episode_len > 0 && t + 1 + ep_off >= A.max_episode_len;
             A.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
-            if (term && A.auto_reset) {
-                ep_count += 1;
-                ep_step = 0;
-                pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)(N + a), -1.0f, 1.0f, &olx, &oly);
+            if (t == t_reset) {  // workgroup-uniform, once per episode
+                if (term) {
+                    ep_count += 1;
+                    ep_off = -(t + 1);
+                    pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)(N + a), -1.0f, 1.0f, &olx, &oly);
+                }
+                reset_step_update(t);
+                nxt = (nxt + 1) & 3;
             }
-            if (any_reset_step()) { nxt = (nxt + 1) & 3; }
             cur = nxt;
             PW_STAMP(1);
         }
@@ -271,15 +300,15 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         PW_STAMP(0);
         int nxt = (cur + 1) & 3;
         float4 st = s_ring[nxt * kWave + me];
-        ep_step += 1;
-        const bool rst = A.auto_reset && A.max_episode_len > 0 && ep_step >= A.max_episode_len;
-        if (rst) {
-            if (A.final_obs) stream_write_obs<L>(A.final_obs + (tBN + g) * D, L, s_lmB + base, st.x, st.y, st.z, st.w);
-            ep_count += 1;
-            ep_step = 0;
-            pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)(N + a), -1.0f, 1.0f, &olx, &oly);
-        }
-        if (any_reset_step()) {  // workgroup-uniform
+        if (t == t_reset) {  // workgroup-uniform, once per episode
+            const bool rst = t + 1 + ep_off >= A.max_episode_len;
+            if (rst) {
+                if (A.final_obs) stream_write_obs<L>(A.final_obs + (tBN + g) * D, L, s_lmB + base, st.x, st.y, st.z, st.w);
+                ep_count += 1;
+                ep_off = -(t + 1);
+                pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)(N + a), -1.0f, 1.0f, &olx, &oly);
+            }
+            reset_step_update(t);
             wave_lds_sync();     // the pre-reset rows have read the old landmarks
             if (rst) s_lmB[me] = make_float2(olx, oly);
             nxt = (nxt + 1) & 3;

@@ -299,7 +299,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
             if (std::getenv("PWORLD_FORCE_QUAD") && kp.N == 6 && kp.L == 6 && um && !wc) quad = true;
             if (quad) {
                 const size_t qshm = 4 * kWave * sizeof(float4) + 2 * 4 * 6 * 6 * sizeof(float2) + 2 * kWave * sizeof(float) +
-                                    8 * 6 * sizeof(float2) + kWave * sizeof(float4) + 2 * kActRingBytes;
+                                    8 * 6 * sizeof(float2) + kWave * sizeof(float4) + 2 * kActRingBytes + 2 * 8 * sizeof(float2);
                 PW_LAUNCH(h, (pw_spread_quad_kernel<true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
                 PW_HIP_CHECK(hipGetLastError());
                 return PW_OK;
