@@ -121,6 +121,28 @@ __device__ __forceinline__ f32x2 div_chain2(f32x2 a, float b, float y)
     return __builtin_elementwise_fma(__builtin_elementwise_fma(nb, q1, a), yy, q1);
 }
 
+// ---- streaming stores -----------------------------------------------------------------------------------------------
+// The rollout's outputs are written once and not read again by the GPU for a long time (the consumer is the learner, a
+// chunk later): stored with the non-temporal hint they do not displace each other in L2 / MALL on their way out.
+// Measured (tools/step_time.hip A/B, profiles/r2_nt_stores.txt): the block-wise observation stores with the hint: B = 65536,
+// N = 6: +6.5 %, N = 24 at B = 4096: +6 %, C2: +1 %.  The row-per-lane observation stores write a quarter line each and
+// stay plain.
+template <typename T>
+__device__ __forceinline__ void nt_store(T *p, const T v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void nt_store(float4 *p, const float4 v)
+{
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(nt4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt4 *>(p));
+}
+__device__ __forceinline__ void nt_store(float2 *p, const float2 v)
+{
+    typedef float nt2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(nt2{v.x, v.y}, reinterpret_cast<nt2 *>(p));
+}
+
+// The per-agent / per-env planes take the hint only at N <= 6 (kNtPlanes in the spread kernels): C2 +2 %, B = 65536 +4 % on
+// top of the block stores, but N = 12: -2 %, N = 24: -3 %.
+
 // ---- action indices fetched AHEAD by LDS-direct loads ---------------------------------------------------------------
 // A physics wave reads one action index per lane and step from HBM.  Issued one step ahead into a register, that load
 // costs a full chip 250-400 cycles of every step (stamps: profiles/r2_action_prefetch.txt): HBM latency under a

@@ -263,6 +263,15 @@ struct StreamParams {
     uint64_t *coll;  // [T,B,N] collision masks; written only by the COLL instantiations
 };
 
+// A store into one of the per-agent / per-env output planes: with the non-temporal hint where the enclosing kernel's
+// kNtPlanes says so (pw_common.hpp, nt_store).  A macro, not a function template: routed through a function the plain
+// branch cost the N = 48 kernel 71 VGPRs (168 -> 239) and a third of its occupancy.
+#define PW_PLANE_STORE(lvalue, value)                     \
+    do {                                                  \
+        if constexpr (kNtPlanes) nt_store(&(lvalue), value); \
+        else (lvalue) = (value);                          \
+    } while (0)
+
 template <int LT>
 __device__ __forceinline__ void stream_write_obs(float *__restrict__ o, const int L, const float2 *lm, float px,
                                                  float py, float vx, float vy)
@@ -336,12 +345,12 @@ __device__ __forceinline__ void stream_write_obs_block(float *__restrict__ blk, 
             if (WIDE) {
                 const float4 o = cc[u] == 0 ? make_float4(st[u].z, st[u].w, st[u].x, st[u].y)
                                             : make_float4(lm[u].x - st[u].x, lm[u].y - st[u].y, lm[u].z - st[u].x, lm[u].w - st[u].y);
-                if (q < total) reinterpret_cast<float4 *>(blk)[q] = o;
+                if (q < total) nt_store(reinterpret_cast<float4 *>(blk) + q, o);
             } else {
                 const float2 o = cc[u] == 0 ? make_float2(st[u].z, st[u].w)
                                  : cc[u] == 1 ? make_float2(st[u].x, st[u].y)
                                               : make_float2(lm[u].x - st[u].x, lm[u].y - st[u].y);
-                if (q < total) reinterpret_cast<float2 *>(blk)[q] = o;
+                if (q < total) nt_store(reinterpret_cast<float2 *>(blk) + q, o);
             }
         }
     }
@@ -382,6 +391,7 @@ template <int NT, int LT, bool UNIT_MASS, bool COLL = false, bool BLOCK = false>
 __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamParams A, const int T)
 {
     using MaskT = typename std::conditional<(NT > 0 && NT <= 32), uint32_t, uint64_t>::type;
+    constexpr bool kNtPlanes = NT > 0 && NT <= 6;  // per-agent / per-env planes with the non-temporal hint (pw_common.hpp, out_store)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int N = NT ? NT : A.N, L = LT ? LT : A.L, D = 4 + 2 * L;
     float2 *s_pos = reinterpret_cast<float2 *>(smem_raw);  // [64]
@@ -471,13 +481,13 @@ __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamPar
 #pragma unroll(NT > 0 ? NT : 1)
         for (int i = 0; i < (NT ? NT : N); ++i) acc += __shfl(r, base + i, kWave);
         PW_STAMP(4);
-        A.rew[tBN + g] = r;
-        A.done[tBN + g] = 0;
-        if (COLL) A.coll[tBN + g] = (uint64_t)coll;  // is_collision bits of the state this step produced (pre-reset)
-        A.rew_shared[(size_t)t * A.B + env] = acc;
+        PW_PLANE_STORE(A.rew[tBN + g], r);
+        PW_PLANE_STORE(A.done[tBN + g], (uint8_t)0);
+        if (COLL) { PW_PLANE_STORE(A.coll[tBN + g], (uint64_t)coll); }  // is_collision bits of the state this step produced (pre-reset)
+        PW_PLANE_STORE(A.rew_shared[(size_t)t * A.B + env], acc);
         ep_step += 1;
         const bool term = A.max_episode_len > 0 && ep_step >= A.max_episode_len;
-        A.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+        PW_PLANE_STORE(A.terminal[(size_t)t * A.B + env], (uint8_t)(term ? 1 : 0));
         if (term && A.auto_reset) {  // same for every lane of an env; rare (1 step in max_episode_len)
             if (A.final_obs) stream_write_obs<LT>(A.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
             wave_lds_sync();
@@ -558,6 +568,7 @@ template <int NT, int LT, bool UNIT_MASS, bool COLL = false, bool BLOCK = false>
 __global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamParams A, const int T)
 {
     using MaskT = typename std::conditional<(NT > 0 && NT <= 32), uint32_t, uint64_t>::type;
+    constexpr bool kNtPlanes = NT > 0 && NT <= 6;  // per-agent / per-env planes with the non-temporal hint (pw_common.hpp, out_store)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int N = NT ? NT : A.N, L = LT ? LT : A.L, D = 4 + 2 * L;
     float4 *s_ring = reinterpret_cast<float4 *>(smem_raw);            // [3][64] {px, py, vx, vy}
@@ -688,13 +699,13 @@ __global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamPa
 #pragma unroll(NT > 0 ? NT : 1)
             for (int i = 0; i < (NT ? NT : N); ++i) acc += s_rew[base + i];
             PW_STAMP(1);
-            A.rew[tBN + g] = r;
-            A.done[tBN + g] = 0;
-            if (COLL) A.coll[tBN + g] = (uint64_t)coll;
-            A.rew_shared[(size_t)t * A.B + env] = acc;
+            PW_PLANE_STORE(A.rew[tBN + g], r);
+            PW_PLANE_STORE(A.done[tBN + g], (uint8_t)0);
+            if (COLL) { PW_PLANE_STORE(A.coll[tBN + g], (uint64_t)coll); }
+            PW_PLANE_STORE(A.rew_shared[(size_t)t * A.B + env], acc);
             ep_step += 1;
             const bool term = A.max_episode_len > 0 && ep_step >= A.max_episode_len;
-            A.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+            PW_PLANE_STORE(A.terminal[(size_t)t * A.B + env], (uint8_t)(term ? 1 : 0));
             if (term && A.auto_reset) {
                 if (A.final_obs) stream_write_obs<LT>(A.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
                 wave_lds_sync();

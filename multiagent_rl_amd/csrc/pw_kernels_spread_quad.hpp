@@ -261,11 +261,11 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             float acc = 0.0f;
 #pragma unroll
             for (int i = 0; i < N; ++i) acc += __shfl(r, base + i, kWave);
-            A.rew[tBN + g] = r;
-            A.done[tBN + g] = 0;
-            A.rew_shared[(size_t)t * A.B + env] = acc;
+            nt_store(A.rew + tBN + g, r);
+            nt_store(A.done + tBN + g, (uint8_t)0);
+            nt_store(A.rew_shared + (size_t)t * A.B + env, acc);
             const bool term = A.max_episode_len > 0 && t + 1 + ep_off >= A.max_episode_len;
-            A.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+            nt_store(A.terminal + (size_t)t * A.B + env, (uint8_t)(term ? 1 : 0));
             if (t == t_reset) {  // workgroup-uniform, once per episode
                 if (term) {
                     ep_count += 1;
