@@ -21,6 +21,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 struct TagParams {
     int B, N, L, A, D, epw, max_episode_len, auto_reset;
+    int obs_block;  // duo kernel: stage the wave's observation rows in LDS and store them as one contiguous block (0 / 2 / 4 = chunk floats)
     uint64_t seed, env_id_base;
     float dt, damp, contact_force, contact_margin, mass;
     float sens[2], fscale[2], max_speed[2];
@@ -199,13 +200,13 @@ __global__ void __launch_bounds__(kWave) pw_tag_stream_kernel(const TagParams P,
         wave_lds_sync();
         float acc = 0.0f;
         for (int i = 0; i < N; ++i) acc += s_rew[base + i];
-        P.rew[tBN + g] = r;
-        P.done[tBN + g] = 0;
-        if (COLL) P.coll[tBN + g] = coll;
-        P.rew_shared[(size_t)t * P.B + env] = acc;
+        nt_store(&P.rew[tBN + g], r);
+        nt_store(&P.done[tBN + g], (uint8_t)0);
+        if (COLL) nt_store(&P.coll[tBN + g], coll);
+        nt_store(&P.rew_shared[(size_t)t * P.B + env], acc);
         ep_step += 1;
         const bool term = P.max_episode_len > 0 && ep_step >= P.max_episode_len;
-        P.terminal[(size_t)t * P.B + env] = term ? 1 : 0;
+        nt_store(&P.terminal[(size_t)t * P.B + env], (uint8_t)(term ? 1 : 0));
         if (term && P.auto_reset) {
             if (P.final_obs)
                 tag_write_obs<NT, AT, LT>(P.final_obs + (tBN + g) * D, N, A, L, D, a, lmv, pp, vv, px, py, vx, vy);
@@ -258,6 +259,9 @@ __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P
     float *s_rew = reinterpret_cast<float *>(s_mhi + kWave);               // [64] (wave O)
     float2 *s_lm_p = reinterpret_cast<float2 *>(s_rew + kWave);            // [epw * L] wave P's landmarks
     float2 *s_lm_o = s_lm_p + P.epw * L;                                   // [epw * L] wave O's landmarks
+    // [64][D] the wave's observation rows, staged for the block-wise store (only when P.obs_block; 16-byte aligned)
+    float *s_rows = reinterpret_cast<float *>(smem_raw + ((3 * kWave * sizeof(float4) + 3 * kWave * sizeof(float) +
+                                                          2 * (size_t)P.epw * L * sizeof(float2) + 15) & ~(size_t)15));
 
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = (int)threadIdx.x & 63;
@@ -427,13 +431,13 @@ __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P
             wave_lds_sync();
             float acc = 0.0f;
             for (int i = 0; i < N; ++i) acc += s_rew[base + i];
-            P.rew[tBN + g] = r;
-            P.done[tBN + g] = 0;
-            if (COLL) P.coll[tBN + g] = coll;
-            P.rew_shared[(size_t)t * P.B + env] = acc;
+            nt_store(&P.rew[tBN + g], r);
+            nt_store(&P.done[tBN + g], (uint8_t)0);
+            if (COLL) nt_store(&P.coll[tBN + g], coll);
+            nt_store(&P.rew_shared[(size_t)t * P.B + env], acc);
             ep_step += 1;
             const bool term = P.max_episode_len > 0 && ep_step >= P.max_episode_len;
-            P.terminal[(size_t)t * P.B + env] = term ? 1 : 0;
+            nt_store(&P.terminal[(size_t)t * P.B + env], (uint8_t)(term ? 1 : 0));
             if (term && P.auto_reset) {
                 if (P.final_obs) write_row(P.final_obs + (tBN + g) * D, slot, px, py, vx, vy);
                 wave_lds_sync();
@@ -451,8 +455,28 @@ __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P
             }
             cur = nxt;
             wave_lds_sync();
-            write_row(P.obs + (tBN + g) * D, slot, px, py, vx, vy);
-            if (kStoresPerStep > 0) __builtin_amdgcn_s_waitcnt((kVm & 0xF) | 0x0F70 | ((kVm >> 4) << 14));
+            if (P.obs_block) {
+                // A wave's rows are contiguous in the obs plane.  Row-per-lane they leave as 8-byte pieces at a stride of D
+                // floats (every store instruction touches 48 cache lines); staged in LDS they leave as ONE block, 1 KiB
+                // (or 512 B) contiguous per store instruction -- what pw_kernels_spread.hpp's stream_write_obs_block does
+                // for simple_spread, here through LDS because a tag row is ragged (pw_common.hpp, nt_store: the hint).
+                write_row(s_rows + me * D, slot, px, py, vx, vy);
+                wave_lds_sync();
+                const int envs_here = P.B - (int)blockIdx.x * P.epw < P.epw ? P.B - (int)blockIdx.x * P.epw : P.epw;
+                const int total = envs_here * N * D;  // floats
+                float *blk = P.obs + (tBN + (size_t)blockIdx.x * P.epw * N) * D;
+                if (P.obs_block == 4) {
+                    for (int q = lane; 4 * q < total; q += kWave)
+                        nt_store(reinterpret_cast<float4 *>(blk) + q, reinterpret_cast<const float4 *>(s_rows)[q]);
+                } else {
+                    for (int q = lane; 2 * q < total; q += kWave)
+                        nt_store(reinterpret_cast<float2 *>(blk) + q, reinterpret_cast<const float2 *>(s_rows)[q]);
+                }
+                wave_lds_sync();  // the block's LDS reads are done before the rows change again
+            } else {
+                write_row(P.obs + (tBN + g) * D, slot, px, py, vx, vy);
+                if (kStoresPerStep > 0) __builtin_amdgcn_s_waitcnt((kVm & 0xF) | 0x0F70 | ((kVm >> 4) << 14));
+            }
         }
         for (int l = a; l < L; l += N) {
             const float2 q = lmv[l];

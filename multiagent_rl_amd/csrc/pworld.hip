@@ -241,9 +241,23 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         hipStream_t st = static_cast<hipStream_t>(stream);
         const size_t shm = 2 * kWave * sizeof(float2) + 3 * kWave * sizeof(float) + (size_t)kp.epw * kp.L * sizeof(float2);
         const bool um = kp.mass == 1.0f;
-        // measured: +3.5 % at B = 8192 (820 workgroups), -3 % at B = 65536: only worth it on small grids
-        const bool duo = (grid.x <= 1024 && !std::getenv("PWORLD_NO_DUO")) || std::getenv("PWORLD_FORCE_DUO");
-        const size_t shm2 = 3 * kWave * sizeof(float4) + 3 * kWave * sizeof(float) + 2 * (size_t)kp.epw * kp.L * sizeof(float2);
+        // two waves per env group, as for simple_spread.  With the block-wise observation stores (below) the duo form
+        // leads on every grid measured: B = 8192: 1.69 vs 2.41 us per step, B = 65536: 10.3 vs 19.0 (profiles/r2_tag_block.txt)
+        const bool duo = (grid.x <= 8192 && !std::getenv("PWORLD_NO_DUO")) || std::getenv("PWORLD_FORCE_DUO");
+        size_t shm2 = 3 * kWave * sizeof(float4) + 3 * kWave * sizeof(float) + 2 * (size_t)kp.epw * kp.L * sizeof(float2);
+        // Block-wise observation stores of the duo kernel (rows staged in LDS): short rows only (LDS), chunks of 4 floats
+        // when every wave's block starts and ends on 16 bytes, else of 2 (D is even).  PWORLD_OBS_BLOCK=0/1 overrides.
+        A.obs_block = 0;
+        if (duo && kp.D <= 32) {
+            bool on = grid.x > 700;   // as for simple_spread (profiles/r2_obs_block_threshold.txt)
+            if (const char *e = std::getenv("PWORLD_OBS_BLOCK")) on = std::atoi(e) != 0;
+            if (on) {
+                const bool v4 = ((size_t)kp.B * kp.N * kp.D) % 4 == 0 && ((size_t)kp.epw * kp.N * kp.D) % 4 == 0 &&
+                                (reinterpret_cast<uintptr_t>(io->obs) & 15) == 0 && kp.B % kp.epw == 0;
+                A.obs_block = v4 ? 4 : 2;
+                shm2 = ((shm2 + 15) & ~(size_t)15) + (size_t)kWave * kp.D * sizeof(float);
+            }
+        }
         const dim3 block2(2 * kWave);
 #define PW_TAG_LAUNCH(n, a, l, c)                                                                              \
     do {                                                                                                       \

@@ -10,7 +10,8 @@ int main(int argc, char **argv)
     const int B = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 6, T = argc > 3 ? atoi(argv[3]) : 1000;
     const int reps = argc > 4 ? atoi(argv[4]) : 12, slots = argc > 5 ? atoi(argv[5]) : 2;
     pw_config cfg;
-    pw_config_default(&cfg, PW_SIMPLE_SPREAD, B, N, -1, 0);
+    const bool tag = getenv("ST_TAG") != nullptr;
+    pw_config_default(&cfg, tag ? PW_SIMPLE_TAG : PW_SIMPLE_SPREAD, B, N, tag ? 2 : -1, tag ? 4 : 0);
     cfg.auto_reset = 1;
     pw_handle *h;
     if (pw_create(&cfg, &h)) { printf("create: %s\n", pw_last_error()); return 1; }
