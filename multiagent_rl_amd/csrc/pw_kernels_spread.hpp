@@ -580,6 +580,7 @@ __global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamPa
     // (odd L: the block writer reads it as float4 too, so pad)
     float4 *s_row = reinterpret_cast<float4 *>(smem_raw + ((3 * kWave * sizeof(float4) + (size_t)A.epw * L * sizeof(float2) +
                                                             2 * kWave * sizeof(float) + 15) & ~(size_t)15));
+    float2 *s_utab = reinterpret_cast<float2 *>(s_row + kWave);      // [8] action force per index (wave P)
 
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = (int)threadIdx.x & 63;
@@ -603,22 +604,30 @@ __global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamPa
         float px = A.pos_x[g], py = A.pos_y[g], vx = A.vel_x[g], vy = A.vel_y[g];
         s_ring[me] = make_float4(px, py, vx, vy);
         wave_lds_sync();
+        // U2 + U4 as a table: the action force of an index is one of five constants, computed here once with the step's
+        // own expressions (so the bits are the step's), entry 5 = any other index (no force); a step reads ONE entry
+        if (lane < 6) {
+            const int ai = lane;
+            float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
+            float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
+            ux *= A.sens; uy *= A.sens;
+            if (A.fscale != 1.0f) { ux = A.fscale * ux; uy = A.fscale * uy; }
+            s_utab[lane] = make_float2(ux + 0.0f, uy + 0.0f);
+        }
+        wave_lds_sync();
         MaskT near = duo_near_pass<NT, MaskT>(N, a, s_ring + base, px, py, A.near_thr2);
         const float k = A.contact_margin, cf = A.contact_force, dt = A.dt, damp = A.damp, mass = A.mass;
         int act_next = A.act[g];
         PW_STAMP_DECL;
         for (int t = 0; t < T; ++t) {
             PW_STAMP_START;
-            const int ai = act_next;
+            const uint32_t ai = (uint32_t)act_next;
             {
                 const int tn = t + 1 < T ? t + 1 : t;
                 act_next = A.act[(size_t)tn * BN + g];
             }
-            float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
-            float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
-            ux *= A.sens; uy *= A.sens;
-            if (A.fscale != 1.0f) { ux = A.fscale * ux; uy = A.fscale * uy; }
-            float fx = ux + 0.0f, fy = uy + 0.0f;
+            const float2 u0 = s_utab[ai < 5u ? ai : 5u];  // {u_x + 0, u_y + 0}: the accumulators' starting values
+            float fx = u0.x, fy = u0.y;
             const float4 *pp = s_ring + cur * kWave + base;
             PW_STAMP(0);
             near_force_loop<MaskT, float4>(near, pp, px, py, A.dist_min, k, cf, fx, fy);

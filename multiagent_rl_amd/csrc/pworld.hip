@@ -324,7 +324,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         const bool duo = grid.x <= 8192 && !std::getenv("PWORLD_NO_DUO");
         if (duo || std::getenv("PWORLD_FORCE_DUO")) {
             const size_t shm2 = 3 * kWave * sizeof(float4) + (size_t)kp.epw * kp.L * sizeof(float2) +
-                                2 * kWave * sizeof(float) + 16 + kWave * sizeof(float4);
+                                2 * kWave * sizeof(float) + 16 + kWave * sizeof(float4) + 8 * sizeof(float2);
             const dim3 block2(2 * kWave);
             if (wc) {
                 if (key == 3) PW_LAUNCH(h, (pw_spread_duo_kernel<3, 3, true, true>), grid, block2, shm2, st, A, T);

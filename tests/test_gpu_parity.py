@@ -545,3 +545,25 @@ def test_quad_kernel_equals_duo_with_desynchronised_episode_clocks(B, ep_len, mo
     assert torch.equal(oa['final_obs'][term], ob['final_obs'][term])
     for k in ('pos', 'vel', 'landmarks', 'ep_step', 'ep_count'):
         assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case, want', [
+    (dict(scenario='simple_spread', num_agents=6, num_envs=4096), 'pw_spread_quad_kernel'),       # C2: the bench path
+    (dict(scenario='simple_spread', num_agents=6, num_envs=16384), 'pw_spread_duo_kernel<6,6,true,false,true>'),
+    (dict(scenario='simple_spread', num_agents=3, num_envs=4096), 'pw_spread_duo_kernel<3,3,true>'),
+    (dict(scenario='simple_spread', num_agents=48, num_envs=4096), 'pw_spread_duo_kernel<48,48,true,false,true>'),
+    (dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192), 'pw_tag_duo_kernel<6,4,2,true,false>'),
+], ids=['C2', 'B16384', 'N3', 'N48', 'C3'])
+def test_dispatcher_reports_the_kernel_it_launched(case, want, monkeypatch):
+    """pw_rollout_kernel(): bench.py and the profile tools name the dominant kernel from the dispatcher's own record, so the
+    record has to be right -- the BASELINE configurations land on the kernels DESIGN.md says they do."""
+    for k in ('PWORLD_EPW', 'PWORLD_FORCE_GENERIC', 'PWORLD_NO_STREAM', 'PWORLD_NO_DUO', 'PWORLD_NO_QUAD', 'PWORLD_FORCE_QUAD',
+              'PWORLD_OBS_BLOCK', 'PWORLD_FORCE_DUO'):
+        monkeypatch.delenv(k, raising=False)
+    env, _ = _mk(max_episode_len=25, auto_reset=True, seed=5, want_coll=False, **case)
+    assert env.last_kernel() == ''            # nothing launched yet on this handle
+    env.reset()
+    acts = torch.randint(0, 5, (3, env.num_envs, env.n), dtype=torch.int32)
+    env.rollout(acts)
+    assert env.last_kernel().startswith(want), env.last_kernel()

@@ -312,3 +312,52 @@ def test_oracle_self_regression_vectors():
         tr = trajectory(name, kw, seed)
         for k, v in tr.items():
             np.testing.assert_allclose(v, g['%d/%s' % (i, k)], rtol=0, atol=1e-12, err_msg='%s %s' % (name, k))
+
+
+def test_published_math_header_equals_the_oracle_restatement_bitwise(tmp_path):
+    """include/pworld_math.h is the PUBLISHED float32 contract; oracle/pworld_oracle.c restates it independently (not
+    shared code).  Compiled as plain C, the header must give the oracle's bits for pw_exp / pw_log1p01 / pw_softplus over
+    every exponent, the exact-zero cut, NaN and inf -- otherwise the kernels would be tested against something other than
+    what a user of the header reproduces.  (The device forms are compared with the oracle in test_gpu_parity.py.)"""
+    import ctypes as C
+    import os
+    import shutil
+    import subprocess
+    cc = shutil.which('gcc') or shutil.which('cc')
+    if cc is None:
+        pytest.skip('no C compiler')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "pworld_math.h"\n'
+                   'void hdr_v(int fn, const float *x, float *y, long n) {\n'
+                   '  for (long i = 0; i < n; ++i) y[i] = fn == 0 ? pw_exp(x[i]) : fn == 1 ? pw_log1p01(x[i]) : pw_softplus(x[i]);\n'
+                   '}\n')
+    so = tmp_path / 'hdr.so'
+    fma = ['-mfma'] if 'fma' in open('/proc/cpuinfo').read().split() else []
+    subprocess.check_call([cc, '-O2', '-std=c11', '-ffp-contract=off', '-fno-fast-math', *fma, '-fPIC', '-shared',
+                           '-I', os.path.join(root, 'include'), '-o', str(so), str(src), '-lm'])
+    hdr = C.CDLL(str(so))
+    L = co.lib()
+    rng = np.random.RandomState(7)
+    bits = rng.randint(0, 2 ** 32, 400_000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    special = np.array([0.0, -0.0, 1e-45, 1.17549435e-38, 1.0, -1.0, 87.0, -87.0, -86.999, -87.001, 88.0, 300.0, -300.0,
+                        np.inf, -np.inf, np.nan, 3.4e38, -3.4e38], np.float32)
+    xs = np.concatenate([special, bits, rng.uniform(-100, 320, 400_000).astype(np.float32)])
+    ts = np.concatenate([special[:5], np.float32(2.0) ** -rng.uniform(0, 126, 10_000).astype(np.float32),
+                         rng.uniform(0, 1, 10_000).astype(np.float32)])
+
+    def run(fn, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(x)
+        hdr.hdr_v(C.c_int(fn), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.c_long(x.size))
+        return y
+
+    def same_bits(a, b):
+        return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
+
+    assert same_bits(run(0, xs), co.math_v(3, xs))                      # pw_exp
+    assert same_bits(run(2, xs), co.math_v(1, xs))                      # pw_softplus
+    L.po_log1p_det_f32.restype = C.c_float
+    L.po_log1p_det_f32.argtypes = [C.c_float]
+    want = np.array([L.po_log1p_det_f32(float(t)) for t in ts], np.float32)
+    assert same_bits(run(1, ts), want)                              # pw_log1p01
