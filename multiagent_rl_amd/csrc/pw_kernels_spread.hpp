@@ -391,7 +391,7 @@ template <int NT, int LT, bool UNIT_MASS, bool COLL = false, bool BLOCK = false>
 __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamParams A, const int T)
 {
     using MaskT = typename std::conditional<(NT > 0 && NT <= 32), uint32_t, uint64_t>::type;
-    constexpr bool kNtPlanes = NT > 0 && NT <= 6;  // per-agent / per-env planes with the non-temporal hint (pw_common.hpp, out_store)
+    constexpr bool kNtPlanes = NT > 0 && NT <= 6;  // per-agent / per-env planes with the non-temporal hint (PW_PLANE_STORE; pw_common.hpp nt_store)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int N = NT ? NT : A.N, L = LT ? LT : A.L, D = 4 + 2 * L;
     float2 *s_pos = reinterpret_cast<float2 *>(smem_raw);  // [64]
@@ -568,7 +568,7 @@ template <int NT, int LT, bool UNIT_MASS, bool COLL = false, bool BLOCK = false>
 __global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamParams A, const int T)
 {
     using MaskT = typename std::conditional<(NT > 0 && NT <= 32), uint32_t, uint64_t>::type;
-    constexpr bool kNtPlanes = NT > 0 && NT <= 6;  // per-agent / per-env planes with the non-temporal hint (pw_common.hpp, out_store)
+    constexpr bool kNtPlanes = NT > 0 && NT <= 6;  // per-agent / per-env planes with the non-temporal hint (PW_PLANE_STORE; pw_common.hpp nt_store)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int N = NT ? NT : A.N, L = LT ? LT : A.L, D = 4 + 2 * L;
     float4 *s_ring = reinterpret_cast<float4 *>(smem_raw);            // [3][64] {px, py, vx, vy}
