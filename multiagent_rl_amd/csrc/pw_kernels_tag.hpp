@@ -248,8 +248,8 @@ __global__ void __launch_bounds__(kWave) pw_tag_stream_kernel(const TagParams P,
 // its own copy of the landmarks (both draw them from Philox at a reset), so the only cross-wave traffic is
 // the ring.  Used while the grid is small enough to be latency bound.
 // ------------------------------------------------------------------------------------------
-template <int NT, int AT, int LT, bool UNIT_MASS, bool COLL = false>
-__global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P, const int T)
+template <int NT, int AT, int LT, bool UNIT_MASS, bool COLL = false, bool TRIO = false>
+__global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_tag_duo_kernel(const TagParams P, const int T)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int N = NT ? NT : P.N, A = AT >= 0 ? AT : P.A, L = LT ? LT : P.L, D = P.D;
@@ -310,7 +310,9 @@ __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P
         near_pass(s_ring + base);
         const float k = P.contact_margin, cf = P.contact_force, dt = P.dt, damp = P.damp, mass = P.mass;
         int act_next = P.act[g];
+        PW_STAMP_DECL;
         for (int t = 0; t < T; ++t) {
+            PW_STAMP_START;
             const int ai = act_next;
             {
                 const int tn = t + 1 < T ? t + 1 : t;
@@ -322,6 +324,7 @@ __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P
             if (my_fscale != 1.0f) { ux = my_fscale * ux; uy = my_fscale * uy; }
             float fx = ux + 0.0f, fy = uy + 0.0f;
             const float4 *pp = s_ring + cur * kWave + base;
+            PW_STAMP(0);
             for (uint64_t m = near_a; m; m &= m - 1) {
                 const int j = __builtin_ctzll(m);
                 const float2 q = *reinterpret_cast<const float2 *>(pp + j);
@@ -331,6 +334,7 @@ __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P
                 const float2 q = lmv[__builtin_ctzll(m)];
                 collision_force<true>(px, py, q.x, q.y, dmin_lm, k, cf, fx, fy);
             }
+            PW_STAMP(1);
             vx = vx * damp; vy = vy * damp;
             vx = vx + div_mass<UNIT_MASS>(fx, mass) * dt;
             vy = vy + div_mass<UNIT_MASS>(fy, mass) * dt;
@@ -360,15 +364,24 @@ __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P
                 s_ring[nxt * kWave + me] = make_float4(px, py, 0.f, 0.f);
             }
             cur = nxt;
+            PW_STAMP(2);
             duo_barrier();
+            PW_STAMP(3);
             near_pass(s_ring + cur * kWave + base);
+            PW_STAMP(4);
         }
+        PW_STAMP_FLUSH;
         P.pos_x[g] = px; P.pos_y[g] = py;
         P.vel_x[g] = vx; P.vel_y[g] = vy;
         P.ep_step[env] = ep_step;
         P.ep_count[env] = ep_count;
     } else {
         // ================================ wave O: outputs ================================
+        // One wave does both halves below -- or two do one each (TRIO: wave 1 the collision masks, rewards and the
+        // per-agent / per-env planes, wave 2 the observation rows and the landmarks they need).  At C3 the single output
+        // wave was the step's critical path (stamps: 3400 busy cycles against the physics wave's 2680); the halves share
+        // nothing but the ring slot they read, so each follows the slot sequence and the episode clock itself.
+        const bool do_rew = !TRIO || wave == 1, do_obs = !TRIO || wave == 2;  // compile-time true in the two-wave form
         float2 *lmv = s_lm_o + e_local * L;
         const float cthr_adv = P.coll_thr2[cls][0], cthr_good = P.coll_thr2[cls][1];
         const uint64_t adv_bits = A >= 64 ? ~0ull : ((1ull << A) - 1ull);
@@ -398,55 +411,63 @@ __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P
             }
             while (2 * kk < D) o2[kk++] = make_float2(0.0f, 0.0f);
         };
+        PW_STAMP_DECL;
         for (int t = 0; t < T; ++t) {
             const size_t tBN = (size_t)t * BN;
+            PW_STAMP_START;
             duo_barrier();
+            PW_STAMP(0);
             int nxt = cur + 1; nxt = nxt == 3 ? 0 : nxt;
             const float4 *slot = s_ring + nxt * kWave + base;
             const float4 mine = slot[a];
             float px = mine.x, py = mine.y, vx = mine.z, vy = mine.w;
-            uint64_t coll = 0;
-#pragma unroll(NT > 0 ? NT : 1)
-            for (int j = 0; j < (NT ? NT : N); ++j) {
-                const float4 q = slot[j];
-                const float dx = q.x - px, dy = q.y - py;
-                if (dx * dx + dy * dy < (j >= A ? cthr_good : cthr_adv)) coll |= 1ull << j;
-            }
-            s_mlo[me] = (uint32_t)coll;
-            s_mhi[me] = (uint32_t)(coll >> 32);
-            wave_lds_sync();
-            float r = 0.0f;
-            if (cls) {
-                for (int q = 0; q < A; ++q)
-                    if ((coll >> q) & 1) r -= 10.0f;
-                r -= tag_bound(fabsf(px));
-                r -= tag_bound(fabsf(py));
-            } else {
-                for (int gj = A; gj < N; ++gj) {
-                    const uint64_t mg = ((uint64_t)s_mhi[base + gj] << 32) | s_mlo[base + gj];
-                    r += 10.0f * (float)__builtin_popcountll(mg & adv_bits);
-                }
-            }
-            s_rew[me] = r;
-            wave_lds_sync();
-            float acc = 0.0f;
-            for (int i = 0; i < N; ++i) acc += s_rew[base + i];
-            nt_store(&P.rew[tBN + g], r);
-            nt_store(&P.done[tBN + g], (uint8_t)0);
-            if (COLL) nt_store(&P.coll[tBN + g], coll);
-            nt_store(&P.rew_shared[(size_t)t * P.B + env], acc);
             ep_step += 1;
             const bool term = P.max_episode_len > 0 && ep_step >= P.max_episode_len;
-            nt_store(&P.terminal[(size_t)t * P.B + env], (uint8_t)(term ? 1 : 0));
+            if (do_rew) {
+                uint64_t coll = 0;
+#pragma unroll(NT > 0 ? NT : 1)
+                for (int j = 0; j < (NT ? NT : N); ++j) {
+                    const float4 q = slot[j];
+                    const float dx = q.x - px, dy = q.y - py;
+                    if (dx * dx + dy * dy < (j >= A ? cthr_good : cthr_adv)) coll |= 1ull << j;
+                }
+                s_mlo[me] = (uint32_t)coll;
+                s_mhi[me] = (uint32_t)(coll >> 32);
+                wave_lds_sync();
+                float r = 0.0f;
+                if (cls) {
+                    for (int q = 0; q < A; ++q)
+                        if ((coll >> q) & 1) r -= 10.0f;
+                    r -= tag_bound(fabsf(px));
+                    r -= tag_bound(fabsf(py));
+                } else {
+                    for (int gj = A; gj < N; ++gj) {
+                        const uint64_t mg = ((uint64_t)s_mhi[base + gj] << 32) | s_mlo[base + gj];
+                        r += 10.0f * (float)__builtin_popcountll(mg & adv_bits);
+                    }
+                }
+                s_rew[me] = r;
+                wave_lds_sync();
+                float acc = 0.0f;
+                for (int i = 0; i < N; ++i) acc += s_rew[base + i];
+                PW_STAMP(1);
+                nt_store(&P.rew[tBN + g], r);
+                nt_store(&P.done[tBN + g], (uint8_t)0);
+                if (COLL) nt_store(&P.coll[tBN + g], coll);
+                nt_store(&P.rew_shared[(size_t)t * P.B + env], acc);
+                nt_store(&P.terminal[(size_t)t * P.B + env], (uint8_t)(term ? 1 : 0));
+            }
             if (term && P.auto_reset) {
-                if (P.final_obs) write_row(P.final_obs + (tBN + g) * D, slot, px, py, vx, vy);
+                if (do_obs && P.final_obs) write_row(P.final_obs + (tBN + g) * D, slot, px, py, vx, vy);
                 wave_lds_sync();
                 ep_count += 1;
                 ep_step = 0;
-                for (int l = a; l < L; l += N) {
-                    float x, y;
-                    pw_reset_xy(P.seed, env_id, ep_count, (uint32_t)(N + l), -0.9f, 0.9f, &x, &y);
-                    lmv[l] = make_float2(x, y);
+                if (do_obs) {
+                    for (int l = a; l < L; l += N) {
+                        float x, y;
+                        pw_reset_xy(P.seed, env_id, ep_count, (uint32_t)(N + l), -0.9f, 0.9f, &x, &y);
+                        lmv[l] = make_float2(x, y);
+                    }
                 }
                 nxt = nxt + 1; nxt = nxt == 3 ? 0 : nxt;
                 slot = s_ring + nxt * kWave + base;  // post-reset state published by P
@@ -455,7 +476,9 @@ __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P
             }
             cur = nxt;
             wave_lds_sync();
-            if (P.obs_block) {
+            if (!do_obs) {
+                // (the rewards wave of a trio: nothing more in this step)
+            } else if (P.obs_block) {
                 // A wave's rows are contiguous in the obs plane.  Row-per-lane they leave as 8-byte pieces at a stride of D
                 // floats (every store instruction touches 48 cache lines); staged in LDS they leave as ONE block, 1 KiB
                 // (or 512 B) contiguous per store instruction -- what pw_kernels_spread.hpp's stream_write_obs_block does
@@ -477,11 +500,20 @@ __global__ void __launch_bounds__(2 * kWave) pw_tag_duo_kernel(const TagParams P
                 write_row(P.obs + (tBN + g) * D, slot, px, py, vx, vy);
                 if (kStoresPerStep > 0) __builtin_amdgcn_s_waitcnt((kVm & 0xF) | 0x0F70 | ((kVm >> 4) << 14));
             }
+            PW_STAMP(2);
         }
-        for (int l = a; l < L; l += N) {
-            const float2 q = lmv[l];
-            P.lm_x[(size_t)env * L + l] = q.x;
-            P.lm_y[(size_t)env * L + l] = q.y;
+#ifdef PW_STAMPS
+        if (blockIdx.x == 0 && lane == 0) {
+            if (do_rew) { g_pw_stamps[8] = st_acc[0]; g_pw_stamps[9] = st_acc[1]; }
+            if (do_obs) { g_pw_stamps[10] = st_acc[2]; g_pw_stamps[11] = st_acc[0]; }
+        }
+#endif
+        if (do_obs) {
+            for (int l = a; l < L; l += N) {
+                const float2 q = lmv[l];
+                P.lm_x[(size_t)env * L + l] = q.x;
+                P.lm_y[(size_t)env * L + l] = q.y;
+            }
         }
     }
 }

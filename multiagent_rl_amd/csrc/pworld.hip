@@ -258,10 +258,17 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
                 shm2 = ((shm2 + 15) & ~(size_t)15) + (size_t)kWave * kp.D * sizeof(float);
             }
         }
-        const dim3 block2(2 * kWave);
+        // Three waves per env group (the output wave split into a rewards wave and an observation wave) where the single
+        // output wave is the step's critical path: measured crossover in profiles/r2_tag_block.txt.  PWORLD_TAG_TRIO=0/1.
+        bool trio = duo && grid.x >= 512 && grid.x <= 1280;
+        if (const char *e = std::getenv("PWORLD_TAG_TRIO")) trio = duo && std::atoi(e) != 0;
+        const dim3 block2((trio ? 3 : 2) * kWave);
 #define PW_TAG_LAUNCH(n, a, l, c)                                                                              \
     do {                                                                                                       \
-        if (duo) {                                                                                             \
+        if (duo && trio) {                                                                                     \
+            if (um) PW_LAUNCH(h, (pw_tag_duo_kernel<n, a, l, true, c, true>), grid, block2, shm2, st, A, T);   \
+            else PW_LAUNCH(h, (pw_tag_duo_kernel<n, a, l, false, c, true>), grid, block2, shm2, st, A, T);     \
+        } else if (duo) {                                                                                      \
             if (um) PW_LAUNCH(h, (pw_tag_duo_kernel<n, a, l, true, c>), grid, block2, shm2, st, A, T);   \
             else PW_LAUNCH(h, (pw_tag_duo_kernel<n, a, l, false, c>), grid, block2, shm2, st, A, T);     \
         } else if (um) PW_LAUNCH(h, (pw_tag_stream_kernel<n, a, l, true, c>), grid, block, shm, st, A, T); \

@@ -553,7 +553,7 @@ def test_quad_kernel_equals_duo_with_desynchronised_episode_clocks(B, ep_len, mo
     (dict(scenario='simple_spread', num_agents=6, num_envs=16384), 'pw_spread_duo_kernel<6,6,true,false,true>'),
     (dict(scenario='simple_spread', num_agents=3, num_envs=4096), 'pw_spread_duo_kernel<3,3,true>'),
     (dict(scenario='simple_spread', num_agents=48, num_envs=4096), 'pw_spread_duo_kernel<48,48,true,false,true>'),
-    (dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192), 'pw_tag_duo_kernel<6,4,2,true,false>'),
+    (dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192), 'pw_tag_duo_kernel<6,4,2,true,false,true>'),   # three-wave form
 ], ids=['C2', 'B16384', 'N3', 'N48', 'C3'])
 def test_dispatcher_reports_the_kernel_it_launched(case, want, monkeypatch):
     """pw_rollout_kernel(): bench.py and the profile tools name the dominant kernel from the dispatcher's own record, so the

@@ -9,7 +9,8 @@ int main(int argc, char **argv)
 {
     const int B = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 6, T = argc > 3 ? atoi(argv[3]) : 25, reps = argc > 3 ? 12 : 40;
     pw_config cfg;
-    pw_config_default(&cfg, PW_SIMPLE_SPREAD, B, N, -1, 0);
+    const bool tag = getenv("ST_TAG") != nullptr;  // simple_tag 4+2 (pass N = 6)
+    pw_config_default(&cfg, tag ? PW_SIMPLE_TAG : PW_SIMPLE_SPREAD, B, N, tag ? 2 : -1, tag ? 4 : 0);
     cfg.auto_reset = 1;
     pw_handle *h;
     if (pw_create(&cfg, &h)) { printf("create: %s\n", pw_last_error()); return 1; }
@@ -40,7 +41,14 @@ int main(int argc, char **argv)
         hipMemcpyFromSymbol(s, HIP_SYMBOL(g_pw_stamps), sizeof(s));
         if (r >= 5) for (int i = 0; i < 16; ++i) tot[i] += s[i];
     }
-    if (N == 6 && !getenv("PWORLD_NO_QUAD") && B <= 8192) {
+    if (tag) {
+        const char *tn[12] = {"P: action decode", "P: near-pair force loops (agents, landmarks)", "P: integrate, speed clamp, publish", "P: barrier wait", "P: near-mask pass", "-", "-", "-",
+                              "O / OA: barrier wait", "O / OA: masks + rewards (+ planes)", "O / OB: (planes,) reset check, obs rows", "OB: barrier wait (trio only)"};
+        printf("simple_tag B=%d N=%d (duo kernel): cycles per step, workgroup 0; this stamped build runs %.3f us per step\n", B, N, wall_ms * 1e3 / ((reps - 5) * T));
+        for (int i = 0; i < 12; ++i) if (tn[i][0] != '-') printf("  %-52s %7.0f cycles\n", tn[i], tot[i] / (double)((reps - 5) * T));
+        return 0;
+    }
+    if (N == 6 && !getenv("PWORLD_NO_QUAD") && B <= 12288) {
         const char *qn[8] = {"P: pair phase (LDS read, near test, force, table write)", "P: row add + integrate + publish", "P: barrier wait", "P: wait for the step's action indices (vmcnt)",
                              "OA: barrier wait", "OA: masks + rewards + stores", "OB: barrier wait", "OB: observation rows"};
         printf("B=%d N=%d (quad kernel): cycles per step, workgroup 0; this stamped build runs %.3f us per step\n", B, N,
