@@ -564,8 +564,8 @@ __device__ __forceinline__ MaskT duo_near_pass(const int N, const int a, const f
     return near & ~((MaskT)1 << a);
 }
 
-template <int NT, int LT, bool UNIT_MASS, bool COLL = false, bool BLOCK = false>
-__global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamParams A, const int T)
+template <int NT, int LT, bool UNIT_MASS, bool COLL = false, bool BLOCK = false, bool TRIO = false>
+__global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_spread_duo_kernel(const StreamParams A, const int T)
 {
     using MaskT = typename std::conditional<(NT > 0 && NT <= 32), uint32_t, uint64_t>::type;
     constexpr bool kNtPlanes = NT > 0 && NT <= 6;  // per-agent / per-env planes with the non-temporal hint (PW_PLANE_STORE; pw_common.hpp nt_store)
@@ -662,13 +662,18 @@ __global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamPa
         A.ep_count[env] = ep_count;
     } else {
         // ================================ wave O: outputs ================================
+        // One wave does both halves below -- or, TRIO, two do one each: wave 1 the collision masks, landmark minima,
+        // rewards and the per-agent / per-env planes, wave 2 the observation rows.  They share nothing but the ring slot
+        // they read; each follows the slot sequence, the episode clock and its landmark itself (only wave 2 keeps the
+        // landmarks in LDS, for the rows).  Used where the single output wave is the step's critical path (mid-size grids).
+        const bool do_rew = !TRIO || wave == 1, do_obs = !TRIO || wave == 2;  // compile-time true in the two-wave form
         float2 *lmv = s_lm + e_local * L;
         const int la = a < L ? a : 0;
         float olx = 0.f, oly = 0.f;
         if (L > 0) {
             olx = A.lm_x[(size_t)env * L + la];
             oly = A.lm_y[(size_t)env * L + la];
-            lmv[la] = make_float2(olx, oly);
+            if (do_obs) lmv[la] = make_float2(olx, oly);
         }
         constexpr int kStoresPerStep = LT > 0 ? 4 + (COLL ? 1 : 0) + (BLOCK ? obs_block_stores<NT, LT>() : (LT % 2 == 0 ? 1 + LT / 2 : 2 + LT)) : 0;
         constexpr int kVm = kStoresPerStep < 63 ? kStoresPerStep : 63;
@@ -682,68 +687,72 @@ __global__ void __launch_bounds__(2 * kWave) pw_spread_duo_kernel(const StreamPa
             const float4 *slot = s_ring + nxt * kWave + base;
             const float4 mine = slot[a];
             float px = mine.x, py = mine.y, vx = mine.z, vy = mine.w;
-            MaskT coll = 0;
-            float best = 0.0f;
+            if (do_rew) {
+                MaskT coll = 0;
+                float best = 0.0f;
 #pragma unroll(NT > 0 ? NT : 1)
-            for (int j = 0; j < (NT ? NT : N); ++j) {
-                const float2 q = *reinterpret_cast<const float2 *>(slot + j);
-                const float dx = q.x - px, dy = q.y - py;
-                const float d2 = dx * dx + dy * dy;
-                if (d2 < A.coll_thr2) coll |= (MaskT)1 << j;
-                const float ex = q.x - olx, ey = q.y - oly;
-                const float e2 = ex * ex + ey * ey;
-                best = (j == 0 || e2 < best) ? e2 : best;
-            }
-            s_min[me] = sqrtf(best);
-            wave_lds_sync();
-            float r = 0.0f;
+                for (int j = 0; j < (NT ? NT : N); ++j) {
+                    const float2 q = *reinterpret_cast<const float2 *>(slot + j);
+                    const float dx = q.x - px, dy = q.y - py;
+                    const float d2 = dx * dx + dy * dy;
+                    if (d2 < A.coll_thr2) coll |= (MaskT)1 << j;
+                    const float ex = q.x - olx, ey = q.y - oly;
+                    const float e2 = ex * ex + ey * ey;
+                    best = (j == 0 || e2 < best) ? e2 : best;
+                }
+                s_min[me] = sqrtf(best);
+                wave_lds_sync();
+                float r = 0.0f;
 #pragma unroll(LT > 0 ? LT : 1)
-            for (int l = 0; l < (LT ? LT : L); ++l) r -= s_min[base + l];
+                for (int l = 0; l < (LT ? LT : L); ++l) r -= s_min[base + l];
 #pragma unroll(NT > 0 ? NT : 1)
-            for (int j = 0; j < (NT ? NT : N); ++j)
-                if ((coll >> j) & 1) r -= 1.0f;
-            s_rew[me] = r;
-            wave_lds_sync();
-            float acc = 0.0f;
+                for (int j = 0; j < (NT ? NT : N); ++j)
+                    if ((coll >> j) & 1) r -= 1.0f;
+                s_rew[me] = r;
+                wave_lds_sync();
+                float acc = 0.0f;
 #pragma unroll(NT > 0 ? NT : 1)
-            for (int i = 0; i < (NT ? NT : N); ++i) acc += s_rew[base + i];
-            PW_STAMP(1);
-            PW_PLANE_STORE(A.rew[tBN + g], r);
-            PW_PLANE_STORE(A.done[tBN + g], (uint8_t)0);
-            if (COLL) { PW_PLANE_STORE(A.coll[tBN + g], (uint64_t)coll); }
-            PW_PLANE_STORE(A.rew_shared[(size_t)t * A.B + env], acc);
+                for (int i = 0; i < (NT ? NT : N); ++i) acc += s_rew[base + i];
+                PW_STAMP(1);
+                PW_PLANE_STORE(A.rew[tBN + g], r);
+                PW_PLANE_STORE(A.done[tBN + g], (uint8_t)0);
+                if (COLL) { PW_PLANE_STORE(A.coll[tBN + g], (uint64_t)coll); }
+                PW_PLANE_STORE(A.rew_shared[(size_t)t * A.B + env], acc);
+            }
             ep_step += 1;
             const bool term = A.max_episode_len > 0 && ep_step >= A.max_episode_len;
-            PW_PLANE_STORE(A.terminal[(size_t)t * A.B + env], (uint8_t)(term ? 1 : 0));
+            if (do_rew) { PW_PLANE_STORE(A.terminal[(size_t)t * A.B + env], (uint8_t)(term ? 1 : 0)); }
             if (term && A.auto_reset) {
-                if (A.final_obs) stream_write_obs<LT>(A.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+                if (do_obs && A.final_obs) stream_write_obs<LT>(A.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
                 wave_lds_sync();
                 ep_count += 1;
                 ep_step = 0;
                 if (L > 0) {
                     pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)(N + la), -1.0f, 1.0f, &olx, &oly);
-                    lmv[la] = make_float2(olx, oly);
+                    if (do_obs) lmv[la] = make_float2(olx, oly);
                 }
                 nxt = nxt + 1; nxt = nxt == 3 ? 0 : nxt;
                 const float4 fresh = s_ring[nxt * kWave + me];  // post-reset state published by P
                 px = fresh.x; py = fresh.y; vx = fresh.z; vy = fresh.w;
             }
             cur = nxt;
-            if (BLOCK) s_row[me] = make_float4(px, py, vx, vy);
-            wave_lds_sync();
-            if constexpr (BLOCK)
-                stream_write_obs_block<NT, LT>(A.obs + (tBN + (size_t)blockIdx.x * A.epw * N) * D, rows_here, lane, s_row, s_lm);
-            else
-                stream_write_obs<LT>(A.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+            if (do_obs) {
+                if (BLOCK) s_row[me] = make_float4(px, py, vx, vy);
+                wave_lds_sync();
+                if constexpr (BLOCK)
+                    stream_write_obs_block<NT, LT>(A.obs + (tBN + (size_t)blockIdx.x * A.epw * N) * D, rows_here, lane, s_row, s_lm);
+                else
+                    stream_write_obs<LT>(A.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+            }
             PW_STAMP(2);
-            if (LT > 0) __builtin_amdgcn_s_waitcnt((kVm & 0xF) | 0x0F70 | ((kVm >> 4) << 14));
+            if (LT > 0 && !TRIO) __builtin_amdgcn_s_waitcnt((kVm & 0xF) | 0x0F70 | ((kVm >> 4) << 14));
             PW_STAMP(3);
         }
 #ifdef PW_STAMPS
         if (blockIdx.x == 0 && lane == 0)
             for (int i_ = 0; i_ < 8; ++i_) g_pw_stamps[8 + i_] = st_acc[i_];
 #endif
-        if (L > 0) {
+        if (L > 0 && do_obs) {
             A.lm_x[(size_t)env * L + la] = olx;
             A.lm_y[(size_t)env * L + la] = oly;
         }

@@ -332,7 +332,11 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         if (duo || std::getenv("PWORLD_FORCE_DUO")) {
             const size_t shm2 = 3 * kWave * sizeof(float4) + (size_t)kp.epw * kp.L * sizeof(float2) +
                                 2 * kWave * sizeof(float) + 16 + kWave * sizeof(float4) + 8 * sizeof(float2);
-            const dim3 block2(2 * kWave);
+            // three waves per env group (the output wave split in two) where the single output wave is the step's critical
+            // path: block-store instantiations on mid-size grids (measured: profiles/r2_trio.txt).  PWORLD_SPREAD_TRIO=0/1.
+            bool trio = um && blk && !wc && key >= 12 && grid.x >= 512 && grid.x <= 1280;
+            if (const char *e = std::getenv("PWORLD_SPREAD_TRIO")) trio = um && blk && !wc && key >= 6 && std::atoi(e) != 0;
+            const dim3 block2((trio ? 3 : 2) * kWave);
             if (wc) {
                 if (key == 3) PW_LAUNCH(h, (pw_spread_duo_kernel<3, 3, true, true>), grid, block2, shm2, st, A, T);
                 else if (key == 6) PW_LAUNCH(h, (pw_spread_duo_kernel<6, 6, true, true>), grid, block2, shm2, st, A, T);
@@ -344,7 +348,8 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
             switch (key) {
 #define PW_DUO_CASE(n)                                                                                              \
     case n:                                                                                                         \
-        if (um && blk) PW_LAUNCH(h, (pw_spread_duo_kernel<n, n, true, false, true>), grid, block2, shm2, st, A, T); \
+        if (um && blk && trio) PW_LAUNCH(h, (pw_spread_duo_kernel<n, n, true, false, true, true>), grid, block2, shm2, st, A, T); \
+        else if (um && blk) PW_LAUNCH(h, (pw_spread_duo_kernel<n, n, true, false, true>), grid, block2, shm2, st, A, T); \
         else if (um) PW_LAUNCH(h, (pw_spread_duo_kernel<n, n, true>), grid, block2, shm2, st, A, T);          \
         else PW_LAUNCH(h, (pw_spread_duo_kernel<n, n, false>), grid, block2, shm2, st, A, T);                 \
         break;
