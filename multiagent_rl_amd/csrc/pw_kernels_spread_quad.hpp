@@ -26,6 +26,11 @@ namespace {
 // another env's slot index; each wave follows all 8 episode clocks itself.  Envs out of step with each other can make
 // that happen in consecutive steps, so the ring has 4 slots: the two the output waves are reading (one step behind)
 // and the two the physics waves may be writing.
+// Per-step overheads are kept off the physics waves' instruction stream: the episode clocks are offsets behind ONE scalar
+// compare per step (the vector work runs in reset steps only), the action force is a six-entry table lookup, the action
+// indices arrive four steps ahead by LDS-direct loads (pw_common.hpp act_fetch_issue), the pair operands of the next step
+// are read back before the barrier.  Measured state (profiles/r2_action_prefetch.txt, r2_c2_b4096_quad_summary.json):
+// 0.62 us per step at B = 4096, the three kinds of waves within 10 % of each other, 0.53 us for a lone workgroup.
 // Arithmetic and results are identical to the other simple_spread kernels (same bit-exact tests, `quad` path).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void quad_pair_of(const int q, int &i, int &j)
