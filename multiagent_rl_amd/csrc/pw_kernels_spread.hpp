@@ -251,6 +251,7 @@ __device__ __forceinline__ float div_mass(float x, float mass) { return UNIT_MAS
 
 struct StreamParams {
     int B, N, L, epw, max_episode_len, auto_reset;
+    int p_prio;  // duo kernel: raise the physics wave's issue priority (set by the launch: small and mid-size grids)
     uint64_t seed, env_id_base;
     float dt, damp, contact_force, contact_margin, mass;
     float dist_min, coll_thr2, near_thr2, sens, fscale;
@@ -601,6 +602,7 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_spread_duo_kernel(c
 
     if (wave == 0) {
         // ================================ wave P: physics ================================
+        if (A.p_prio) __builtin_amdgcn_s_setprio(3);  // serve the physics wave first where it shares a SIMD with output waves
         float px = A.pos_x[g], py = A.pos_y[g], vx = A.vel_x[g], vy = A.vel_y[g];
         s_ring[me] = make_float4(px, py, vx, vy);
         wave_lds_sync();

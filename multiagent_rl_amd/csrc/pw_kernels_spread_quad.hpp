@@ -86,6 +86,9 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
 
     if (wave < 2) {
         // ================================ waves P0, P1: pair-parallel physics ================================
+        // the physics waves are the step's critical path, the output waves have slack: where one of each shares a SIMD
+        // (two workgroups per CU at B = 4096) the arbiter should serve the physics wave first
+        __builtin_amdgcn_s_setprio(3);
         const int e0 = wave * EPP;
         const int nv = envs_here - e0 < 0 ? 0 : envs_here - e0 < EPP ? envs_here - e0 : EPP;  // envs of this wave
         if (nv == 0) {  // nothing to advance: keep the workgroup's barriers company

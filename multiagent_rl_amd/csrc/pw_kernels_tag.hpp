@@ -21,6 +21,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 struct TagParams {
     int B, N, L, A, D, epw, max_episode_len, auto_reset;
+    int p_prio;     // duo kernel: raise the physics wave's issue priority (set by the launch: small and mid-size grids)
     int obs_block;  // duo kernel: stage the wave's observation rows in LDS and store them as one contiguous block (0 / 2 / 4 = chunk floats)
     uint64_t seed, env_id_base;
     float dt, damp, contact_force, contact_margin, mass;
@@ -282,6 +283,7 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_tag_duo_kernel(cons
 
     if (wave == 0) {
         // ================================ wave P: physics ================================
+        if (P.p_prio) __builtin_amdgcn_s_setprio(3);  // serve the physics wave first where it shares a SIMD with output waves
         float2 *lmv = s_lm_p + e_local * L;
         const float my_sens = P.sens[cls], my_fscale = P.fscale[cls], my_maxspeed = P.max_speed[cls];
         const float dmin_adv = P.dist_min[cls][0], dmin_good = P.dist_min[cls][1], dmin_lm = P.dist_min_lm[cls];

@@ -248,6 +248,9 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         // Block-wise observation stores of the duo kernel (rows staged in LDS): short rows only (LDS), chunks of 4 floats
         // when every wave's block starts and ends on 16 bytes, else of 2 (D is even).  PWORLD_OBS_BLOCK=0/1 overrides.
         A.obs_block = 0;
+        // the physics wave first where it shares a SIMD with output waves: -2..-4 % step time on grids up to 2048 workgroups
+        // (C3, N = 3 / 12, B = 16384), +2..4 % on the larger ones (profiles/r2_priority.txt)
+        A.p_prio = std::getenv("PWORLD_P_PRIO") ? std::atoi(std::getenv("PWORLD_P_PRIO")) : (grid.x <= 2048 ? 1 : 0);
         if (duo && kp.D <= 32) {
             bool on = grid.x > 700;   // as for simple_spread (profiles/r2_obs_block_threshold.txt)
             if (const char *e = std::getenv("PWORLD_OBS_BLOCK")) on = std::atoi(e) != 0;
@@ -288,6 +291,9 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         (size_t)kp.B * kp.N * kp.D * sizeof(float) < (1ull << 31) && !std::getenv("PWORLD_NO_STREAM")) {
         StreamParams A;
         A.B = kp.B; A.N = kp.N; A.L = kp.L; A.epw = kp.epw;
+        // the physics wave first where it shares a SIMD with output waves: -2..-4 % step time on grids up to 2048 workgroups
+        // (C3, N = 3 / 12, B = 16384), +2..4 % on the larger ones (profiles/r2_priority.txt)
+        A.p_prio = std::getenv("PWORLD_P_PRIO") ? std::atoi(std::getenv("PWORLD_P_PRIO")) : (grid.x <= 2048 ? 1 : 0);
         A.max_episode_len = kp.max_episode_len; A.auto_reset = kp.auto_reset;
         A.seed = kp.seed; A.env_id_base = kp.env_id_base;
         A.dt = kp.dt; A.damp = kp.damp; A.contact_force = kp.contact_force; A.contact_margin = kp.contact_margin;
