@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define PW_VERSION 102 /* 0.1.1: pw_replay_store grew act_heads / per_agent / head_width; wire-block entry points */
+#define PW_VERSION 102 /* 0.1.2: + pw_rollout_kernel (0.1.1: pw_replay_store grew act_heads / per_agent / head_width; wire-block entry points) */
 #define PW_MAX_AGENTS 64
 #define PW_MAX_LANDMARKS 64
 

@@ -25,7 +25,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'libpworld.so lacks %s declared in include/pworld.h' % n
     assert set(names) == set(_lib.SIGNATURES), 'ctypes table and header disagree: %s' % (
         set(names) ^ set(_lib.SIGNATURES))
-    assert lib.pw_version() == 102
+    import re
+    want = int(re.search(r'#define\s+PW_VERSION\s+(\d+)', open(os.path.join(ROOT, 'include', 'pworld.h')).read()).group(1))
+    assert lib.pw_version() == want      # the library and the header it was built against agree
 
 
 def test_config_default_matches_canonical_constants():
