@@ -270,12 +270,9 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
 #pragma unroll
             for (int i = 0; i < N; ++i) acc += __shfl(r, base + i, kWave);
             nt_store(A.rew + tBN + g, r);
-            nt_store(A.done + tBN + g, (uint8_t)0);
-            nt_store(A.rew_shared + (size_t)t * A.B + env, acc);
-            const bool term = A.max_episode_len > 0 && t + 1 + ep_off >= A.max_episode_len;
-            nt_store(A.terminal + (size_t)t * A.B + env, (uint8_t)(term ? 1 : 0));
+            nt_store(A.rew_shared + (size_t)t * A.B + env, acc);   // (done / terminal: wave OB, which has the slack)
             if (t == t_reset) {  // workgroup-uniform, once per episode
-                if (term) {
+                if (t + 1 + ep_off >= A.max_episode_len) {
                     ep_count += 1;
                     ep_off = -(t + 1);
                     pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)(N + a), -1.0f, 1.0f, &olx, &oly);
@@ -308,6 +305,8 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         PW_STAMP(0);
         int nxt = (cur + 1) & 3;
         float4 st = s_ring[nxt * kWave + me];
+        nt_store(A.done + tBN + g, (uint8_t)0);
+        nt_store(A.terminal + (size_t)t * A.B + env, (uint8_t)(A.max_episode_len > 0 && t + 1 + ep_off >= A.max_episode_len ? 1 : 0));
         if (t == t_reset) {  // workgroup-uniform, once per episode
             const bool rst = t + 1 + ep_off >= A.max_episode_len;
             if (rst) {
