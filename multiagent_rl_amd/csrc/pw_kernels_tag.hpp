@@ -397,6 +397,7 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_tag_duo_kernel(cons
         // wave was the step's critical path (stamps: 3400 busy cycles against the physics wave's 2680); the halves share
         // nothing but the ring slot they read, so each follows the slot sequence and the episode clock itself.
         const bool do_rew = !TRIO || wave == 1, do_obs = !TRIO || wave == 2;  // compile-time true in the two-wave form
+        if (TRIO && wave == 2 && P.p_prio) __builtin_amdgcn_s_setprio(2);  // the observation wave is the longer of the two output waves
         float2 *lmv = s_lm_o + e_local * L;
         const float cthr_adv = P.coll_thr2[cls][0], cthr_good = P.coll_thr2[cls][1];
         const uint64_t adv_bits = A >= 64 ? ~0ull : ((1ull << A) - 1ull);
