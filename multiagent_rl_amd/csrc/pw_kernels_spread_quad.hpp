@@ -229,6 +229,9 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
     float olx = A.lm_x[(size_t)env * L + a], oly = A.lm_y[(size_t)env * L + a];  // the landmark this lane owns
 
     if (wave == 2) {
+        // with the physics waves at priority 3 this wave had become the longest of the four (1356 busy cycles against OB's
+        // 1044): it goes first too -- the observation wave fills the slots the other three leave (C2 -2.2 % step time)
+        __builtin_amdgcn_s_setprio(3);
         // ---------------- OA: masks, rewards, small stores ----------------
         PW_STAMP_DECL;
         for (int t = 0; t < T; ++t) {
