@@ -251,7 +251,7 @@ __device__ __forceinline__ float div_mass(float x, float mass) { return UNIT_MAS
 
 struct StreamParams {
     int B, N, L, epw, max_episode_len, auto_reset;
-    int p_prio;  // duo kernel: raise the physics wave's issue priority (set by the launch: small and mid-size grids)
+    int p_prio;  // duo kernel: issue priority per wave, 2 bits each (wave 0 = physics in bits 0-1, ...); set by the launch
     uint64_t seed, env_id_base;
     float dt, damp, contact_force, contact_margin, mass;
     float dist_min, coll_thr2, near_thr2, sens, fscale;
@@ -602,7 +602,10 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_spread_duo_kernel(c
 
     if (wave == 0) {
         // ================================ wave P: physics ================================
-        if (A.p_prio) __builtin_amdgcn_s_setprio(3);  // serve the physics wave first where it shares a SIMD with output waves
+        // issue priorities (A.p_prio: 2 bits per wave, set by the launch): the physics wave first where it shares a SIMD
+        // with output waves of another workgroup
+        switch (A.p_prio & 3) { case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break;
+                                case 3: __builtin_amdgcn_s_setprio(3); break; default: break; }
         float px = A.pos_x[g], py = A.pos_y[g], vx = A.vel_x[g], vy = A.vel_y[g];
         s_ring[me] = make_float4(px, py, vx, vy);
         wave_lds_sync();
@@ -669,6 +672,8 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_spread_duo_kernel(c
         // they read; each follows the slot sequence, the episode clock and its landmark itself (only wave 2 keeps the
         // landmarks in LDS, for the rows).  Used where the single output wave is the step's critical path (mid-size grids).
         const bool do_rew = !TRIO || wave == 1, do_obs = !TRIO || wave == 2;  // compile-time true in the two-wave form
+        switch ((A.p_prio >> (2 * wave)) & 3) { case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break;
+                                                case 3: __builtin_amdgcn_s_setprio(3); break; default: break; }
         float2 *lmv = s_lm + e_local * L;
         const int la = a < L ? a : 0;
         float olx = 0.f, oly = 0.f;

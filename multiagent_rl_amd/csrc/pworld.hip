@@ -291,9 +291,9 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         (size_t)kp.B * kp.N * kp.D * sizeof(float) < (1ull << 31) && !std::getenv("PWORLD_NO_STREAM")) {
         StreamParams A;
         A.B = kp.B; A.N = kp.N; A.L = kp.L; A.epw = kp.epw;
-        // the physics wave first where it shares a SIMD with output waves: -2..-4 % step time on grids up to 2048 workgroups
-        // (C3, N = 3 / 12, B = 16384), +2..4 % on the larger ones (profiles/r2_priority.txt)
-        A.p_prio = std::getenv("PWORLD_P_PRIO") ? std::atoi(std::getenv("PWORLD_P_PRIO")) : (grid.x <= 2048 ? 1 : 0);
+        // issue priority per wave, 2 bits each: the physics wave first where it shares a SIMD with output waves: -2..-4 % step
+        // time on grids up to 2048 workgroups (N = 3 / 12, B = 16384), +2..4 % on the larger ones (profiles/r2_priority.txt)
+        A.p_prio = std::getenv("PWORLD_P_PRIO") ? std::atoi(std::getenv("PWORLD_P_PRIO")) : (grid.x <= 2048 ? 3 : 0);
         A.max_episode_len = kp.max_episode_len; A.auto_reset = kp.auto_reset;
         A.seed = kp.seed; A.env_id_base = kp.env_id_base;
         A.dt = kp.dt; A.damp = kp.damp; A.contact_force = kp.contact_force; A.contact_margin = kp.contact_margin;
@@ -342,6 +342,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
             // path: block-store instantiations on mid-size grids (measured: profiles/r2_trio.txt).  PWORLD_SPREAD_TRIO=0/1.
             bool trio = um && blk && !wc && key >= 12 && grid.x >= 512 && grid.x <= 1280;
             if (const char *e = std::getenv("PWORLD_SPREAD_TRIO")) trio = um && blk && !wc && key >= 6 && std::atoi(e) != 0;
+            if (trio && !std::getenv("PWORLD_P_PRIO")) A.p_prio = 3 | (3 << 4);  // three waves: physics and observation wave first (N = 12: -2.5 %)
             const dim3 block2((trio ? 3 : 2) * kWave);
             if (wc) {
                 if (key == 3) PW_LAUNCH(h, (pw_spread_duo_kernel<3, 3, true, true>), grid, block2, shm2, st, A, T);
