@@ -427,6 +427,47 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_tag_duo_kernel(cons
             }
             while (2 * kk < D) o2[kk++] = make_float2(0.0f, 0.0f);
         };
+        // Direct composition of the block (compile-time rosters): a row is DE = D / 2 float2 entries for BOTH roles (good
+        // rows end in a zero entry), so the wave's block is a regular rows x DE grid and entry n = lane + 64 i has a fixed
+        // (row, column) for the whole launch.  Every entry is "A - B" of two 8-byte LDS reads: A = the row's own velocity /
+        // position, a landmark, another agent's position or velocity, B = the row's position or a zero that lives in LDS
+        // (x - 0 is x) -- the subtractions write_row does, without staging the rows: per step one {pos, vel} publish per
+        // lane, then NIT x (2 reads, 1 packed subtraction, 1 store of 512 contiguous bytes per wave).
+        constexpr bool kDirect = NT > 0 && AT >= 0 && LT > 0;
+        constexpr int DE = kDirect ? (4 + 2 * LT + 2 * (NT - 1) + 2 * (NT - AT)) / 2 : 1;
+        constexpr int kMaxRows = kDirect ? (kWave / NT) * NT : 1;
+        constexpr int NIT = kDirect ? (kMaxRows * DE + kWave - 1) / kWave : 1;
+        float4 *s_state = reinterpret_cast<float4 *>(s_rows);                 // [64] {pos, vel} of every row, current slot
+        float2 *s_zero = reinterpret_cast<float2 *>(s_state + kWave);         // {0, 0}
+        int offA[NIT], offB[NIT];   // byte offsets into the workgroup's LDS
+        const int envs_here_o = P.B - (int)blockIdx.x * P.epw < P.epw ? P.B - (int)blockIdx.x * P.epw : P.epw;
+        const int n_entries = envs_here_o * N * DE;
+        if (kDirect && do_obs && P.obs_block) {
+            if (lane == 0) *s_zero = make_float2(0.0f, 0.0f);
+            const int zoff = (int)(reinterpret_cast<unsigned char *>(s_zero) - smem_raw);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int n = lane + kWave * it;
+                const int nn = n < n_entries ? n : 0;
+                const int r = nn / DE, kk = nn - r * DE;
+                const int e = r / NT, ar = r - e * NT;
+                const int self = (int)(reinterpret_cast<unsigned char *>(s_state + r) - smem_raw);  // {px, py, vx, vy}
+                int oa, ob = zoff;
+                if (kk == 0) oa = self + 8;                        // vel
+                else if (kk == 1) oa = self;                       // pos
+                else if (kk < 2 + LT) { oa = (int)(reinterpret_cast<unsigned char *>(s_lm_o + e * LT + (kk - 2)) - smem_raw); ob = self; }
+                else if (kk < 2 + LT + NT - 1) {
+                    const int m = kk - 2 - LT, j = m < ar ? m : m + 1;
+                    oa = (int)(reinterpret_cast<unsigned char *>(s_state + e * NT + j) - smem_raw);
+                    ob = self;
+                } else {
+                    int j = AT + (kk - (2 + LT + NT - 1));          // good agents in order, skipping the row's own
+                    if (ar >= AT && j >= ar) j += 1;
+                    oa = j < NT ? (int)(reinterpret_cast<unsigned char *>(s_state + e * NT + j) - smem_raw) + 8 : zoff;
+                }
+                offA[it] = oa; offB[it] = ob;
+            }
+        }
         PW_STAMP_DECL;
         for (int t = 0; t < T; ++t) {
             const size_t tBN = (size_t)t * BN;
@@ -494,6 +535,20 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_tag_duo_kernel(cons
             wave_lds_sync();
             if (!do_obs) {
                 // (the rewards wave of a trio: nothing more in this step)
+            } else if (kDirect && P.obs_block) {
+                s_state[me] = make_float4(px, py, vx, vy);
+                wave_lds_sync();
+                float2 *blk2 = reinterpret_cast<float2 *>(P.obs + (tBN + (size_t)blockIdx.x * P.epw * N) * D);
+                float2 va[NIT], vb[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    va[it] = *reinterpret_cast<const float2 *>(smem_raw + offA[it]);
+                    vb[it] = *reinterpret_cast<const float2 *>(smem_raw + offB[it]);
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    if (lane + kWave * it < n_entries) nt_store(blk2 + lane + kWave * it, make_float2(va[it].x - vb[it].x, va[it].y - vb[it].y));
+                wave_lds_sync();  // the reads are done before the states change again
             } else if (P.obs_block) {
                 // A wave's rows are contiguous in the obs plane.  Row-per-lane they leave as 8-byte pieces at a stride of D
                 // floats (every store instruction touches 48 cache lines); staged in LDS they leave as ONE block, 1 KiB
