@@ -14,6 +14,12 @@ third-party package, so these fixtures pin the BOUNDARY, not the arithmetic:
                       encode shapes (NumPy-1 semantics; the literal call raises under NumPy >= 2).
   actor_forward.npz   rls.model.ac_network_multi_gumbel.ActorNetwork: state_dict, input, logits, and the
                       hard Gumbel one-hot of ddpg_gumbel_fix.Trainer.gumbel_softmax under torch.manual_seed.
+  reference_scenarios.json  experiments.scenarios (R2 make_env, R3 local_obs_*) -- the REFERENCE's own factory and
+                      observation functions, imported behind a two-module shell for the absent third-party `multiagent`
+                      package (its `scenarios.load(..).Scenario` / `environment.MultiAgentEnv` resolve to the CPU
+                      oracle's world classes; nothing of experiments/scenarios.py is restated): the flags make_env
+                      leaves on the env (collaborative / shared_reward, force_discrete_action, the n= path), the spaces,
+                      and the rows local_obs_simple_spread / _reference / _speaker_listener return on fixed states.
 """
 import json
 import os
@@ -169,9 +175,103 @@ def make_actor():
     print('actor_forward.npz: %s' % sorted(actor.state_dict().keys()))
 
 
+def _import_reference_scenarios():
+    """experiments/scenarios.py:2-3 imports `multiagent.scenarios` and `multiagent.environment.MultiAgentEnv`; the package
+    is absent.  A shell of two modules supplies exactly those two names from the CPU oracle, so
+    that the reference's OWN make_env / local_obs_* code runs (on the oracle's world objects)."""
+    import types
+
+    def with_upstream_observation(cls):
+        # upstream scenarios call their (full) observation `observation`; make_env patches the local one over it
+        return type(cls.__name__, (cls,), dict(observation=cls.observation_full))
+
+    table = {'simple_spread.py': with_upstream_observation(po.SimpleSpread),
+             'simple_reference.py': with_upstream_observation(po.SimpleReference),
+             'simple_speaker_listener.py': with_upstream_observation(po.SimpleSpeakerListener)}
+    pkg = types.ModuleType('multiagent')
+    scen = types.ModuleType('multiagent.scenarios')
+    scen.load = lambda name: types.SimpleNamespace(Scenario=table[name])
+    envm = types.ModuleType('multiagent.environment')
+    envm.MultiAgentEnv = po.OracleMultiAgentEnv
+    pkg.scenarios, pkg.environment = scen, envm
+    sys.modules.update({'multiagent': pkg, 'multiagent.scenarios': scen, 'multiagent.environment': envm})
+    import experiments.scenarios as ref
+    return ref
+
+
+def make_reference_scenarios():
+    """R2 / R3 from the reference's own code (experiments/scenarios.py:6-64,124-192)."""
+    ref = _import_reference_scenarios()
+    rng = np.random.RandomState(20241004)
+
+    def grid(*shape):  # multiples of 2^-12 in [-1, 1]: every difference below is exact in float32 AND float64
+        return rng.randint(-4096, 4097, shape) / 4096.0
+
+    out = {}
+    for key, name, n in (('simple_spread', 'simple_spread', None), ('simple_spread_n6', 'simple_spread', 6),
+                         ('simple_reference', 'simple_reference', None),
+                         ('simple_speaker_listener', 'simple_speaker_listener', None)):
+        np.random.seed(12345678)
+        env = ref.make_env(name, n=n, benchmark=False, discrete_action=True, local_observation=True)  # main.py:39
+        world = env.world
+        rec = dict(scenario=name, n_arg=n, n=env.n, num_landmarks=len(world.landmarks),
+                   world_collaborative=bool(world.collaborative), shared_reward=bool(env.shared_reward),
+                   force_discrete_action=bool(env.force_discrete_action),
+                   discrete_action_space=bool(env.discrete_action_space),
+                   discrete_action_input=bool(env.discrete_action_input),
+                   observation_is_reference_function=env.observation_callback.__func__.__name__,
+                   observation_space=[list(s.shape) for s in env.observation_space],
+                   action_space=[repr(s) for s in env.action_space],
+                   action_has_high=[hasattr(s, 'high') for s in env.action_space], states=[])
+        fn = {'simple_spread': ref.local_obs_simple_spread, 'simple_reference': ref.local_obs_simple_reference,
+              'simple_speaker_listener': ref.local_obs_simple_speaker_listener}[name]
+        N, L = len(world.agents), len(world.landmarks)
+        for case in range(6):
+            pos, vel, lm = grid(N, 2), grid(N, 2) * 1.5, grid(L, 2)
+            po.set_world_state(world, pos, vel, lm)
+            st = dict(pos=pos.tolist(), vel=vel.tolist(), landmarks=lm.tolist())
+            if name != 'simple_spread':
+                comm = grid(N, world.dim_c) * 0.5 + 0.5
+                goal = rng.randint(0, L, N)
+                for i, a in enumerate(world.agents):
+                    a.state.c = comm[i].copy()
+                    if a.goal_b is not None:  # the speaker_listener listener has none (zeros in its row)
+                        a.goal_b = world.landmarks[int(goal[i])]
+                st.update(comm=comm.tolist(), goal=[int(g) for g in goal],
+                          landmark_colors=[[float(c) for c in l.color] for l in world.landmarks])
+            # the reference's functions, called the way make_env bound them (scenario.observation) AND directly
+            rows = [np.asarray(env.observation_callback(a, world)) for a in world.agents]
+            direct = [np.asarray(fn(env.observation_callback.__self__, a, world)) for a in world.agents]
+            assert all(np.array_equal(r, d) for r, d in zip(rows, direct))
+            st['obs'] = [r.tolist() for r in rows]
+            rec['states'].append(st)
+        # one env.step through the reference-built env: per-agent rewards (collaborative False), done flags, and that a soft
+        # action is arg-maxed (force_discrete_action True) -- positions after the step depend on it
+        np.random.seed(7)
+        obs0 = env.reset()
+        width = [s.n if not hasattr(s, 'high') else int(np.sum(s.high - s.low + 1)) for s in env.action_space]
+        soft = [rng.uniform(0.05, 1.0, w) for w in width]
+        st0 = po.get_world_state(world)
+        obs1, rew, done, info = env.step([a.copy() for a in soft])
+        st1 = po.get_world_state(world)
+        rec['step'] = dict(numpy_seed=7, reset_obs=[np.asarray(o).tolist() for o in obs0], soft_actions=[a.tolist() for a in soft],
+                           pos0=st0[0].tolist(), vel0=st0[1].tolist(), landmarks=st0[2].tolist(),
+                           goal=[world.landmarks.index(a.goal_b) if getattr(a, 'goal_b', None) is not None else -1
+                                 for a in world.agents],
+                           pos1=st1[0].tolist(), vel1=st1[1].tolist(), obs=[np.asarray(o).tolist() for o in obs1],
+                           rew=[float(r) for r in rew], done=[bool(d) for d in done], info_keys=sorted(info.keys()))
+        out[key] = rec
+    json.dump(out, open(os.path.join(HERE, 'reference_scenarios.json'), 'w'), indent=0)
+    print('reference_scenarios.json: %s' % {k: (v['n'], v['observation_space'][0]) for k, v in out.items()})
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'scenarios':
+        make_reference_scenarios()
+        sys.exit(0)
     make_run_trace()
     make_run_test_trace()
     make_multidiscrete_trace()
     make_replay()
     make_actor()
+    make_reference_scenarios()
