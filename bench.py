@@ -22,6 +22,10 @@ gather of replay rows sampled from each rank's chunk (``SampledTransitionGather`
 measures north_star's collective, the FULL gather of every transition to the root's ring
 (``FullTransitionGather``), and reports bytes per env-step and GB/s per xGMI link.
 
+Exit code: 0 only if every rank finished every part it started.  A run whose policy-in-the-loop extra timed out, whose
+peer died, or whose closing barrier never completed still prints the (already measured) headline line, then exits 3; a
+rank on which the extra raised exits 4 (it never enters a collective its peers are not in).
+
 Extra objects: ``roofline`` (HIP-event timed launches vs the 8 TB/s HBM peak; algorithmic bytes 678 B/env-step;
 counter traffic and the VALU issue share from the committed rocprofv3 summaries) and ``cpu_baseline`` (the
 upstream-structured scalar NumPy oracle on one host core, bounded sample; rank 0, N = 1 only).
@@ -40,6 +44,17 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s copy ceiling)
 STUB = bool(os.environ.get('PW_BENCH_STUB'))  # tests only: gloo + a no-op "kernel" (tests/test_bench_launcher.py)
+
+
+def _profiler_preload():
+    """rocprofv3 (and friends) preload a tool library that initialises the GPU before main() runs.  A process in that
+    state must neither exec a launcher (self_launch -> torch.distributed.run -> rank processes) nor fork worker pools
+    (on this pool an exec / fork hop from a GPU-initialised process can take the machine down)."""
+    for var in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'ROCPROFILER_REGISTER_LIBRARY', 'HSA_TOOLS_LIB'):
+        v = os.environ.get(var, '')
+        if any(t in v for t in ('rocprof', 'roctracer', 'rocprofiler', 'librocprof')):
+            return '%s=%s' % (var, v)
+    return None
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -224,7 +239,13 @@ def main():
                                                                     'abandoned (the line is printed without it)')
     args = ap.parse_args()
 
+    preload = _profiler_preload()
     if args.gpus > 1 and 'RANK' not in os.environ:
+        if preload:
+            raise SystemExit('bench.py --gpus %d under a profiler preload (%s): this process is already GPU-initialised and '
+                             'must not start the rank launcher.  Profile ONE rank directly instead, e.g.\n'
+                             '  PW_BENCH_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 rocprofv3 --kernel-trace --stats -- '
+                             'python3 bench.py --no-cpu-baseline   (profiles/README.md)' % (args.gpus, preload))
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get('RANK', '0'))
@@ -238,8 +259,11 @@ def main():
     if world == 1 and rank == 0 and not args.no_cpu_baseline and args.scenario == 'simple_spread' and not STUB:
         cpu_line = cpu_baseline(args.cpu_seconds, args.agents)
         cpu_line['c_oracle_f32_1core_env_steps_per_s'] = c_oracle_rate(args.envs, args.agents)
-        cpu_line['all_cores'] = cpu_baseline_all_cores(min(6.0, args.cpu_seconds), args.agents)
-        cpu_line['c_oracle_f32_all_cores'] = c_oracle_all_cores(args.envs, args.agents)
+        if preload:  # the all-core legs fork worker pools: not from a GPU-initialised (profiled) process
+            cpu_line['all_cores'] = cpu_line['c_oracle_f32_all_cores'] = dict(skipped='profiler preload detected: %s' % preload)
+        else:
+            cpu_line['all_cores'] = cpu_baseline_all_cores(min(6.0, args.cpu_seconds), args.agents)
+            cpu_line['c_oracle_f32_all_cores'] = c_oracle_all_cores(args.envs, args.agents)
         cpu_line['os_cpu_count'] = os.cpu_count()
 
     import torch
@@ -281,7 +305,8 @@ def main():
 
     # Output buffers of RING launches, reused round-robin (a launch's outputs are consumed -- here: sampled by the
     # exchange right after it -- long before RING - 1 more launches have run).  ~1 GB per 1000-step launch at C2.
-    RING = max(1, min(4, K))
+    slot_bytes = T * B * N * (2 * D * 4 + 4 + 4 + 1) + T * B * 5       # obs + final_obs + rew + action + done, + per-env planes
+    RING = max(1, min(4, K, int(96e9 // max(1, slot_bytes))))
     acts = torch.randint(0, 5, (RING * T, B, N), generator=gen, device=dev, dtype=torch.int32)
     outs = env.alloc_outputs(RING * T, coll=False)
     slots = []
@@ -395,21 +420,59 @@ def main():
     # thread prints the line without the extra and ends the process if the extra does not return in time (a peer that
     # died inside a point-to-point exchange would otherwise leave the root waiting in a device synchronisation, which no
     # Python exception or signal handler can interrupt).
+    # A rank on which the extra RAISES tells the others through the process group's key-value store (a TCP side channel,
+    # not a collective): the root's watchdog sees the flag within a fraction of a second, prints the line with that error
+    # and leaves; the failing rank leaves only after the line is out (a launcher that reaps every worker on the first
+    # non-zero exit must not take the root's line with it).
     line_holder = {}
     policy_line = None
     watchdog = None
+    store = None
+    if use_dist:
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            store = None
+    FAIL_KEY, LINE_KEY = 'pw_bench_failed', 'pw_bench_line_out'
     if args.scenario == 'simple_spread' and not os.environ.get('PW_BENCH_NO_POLICY'):
         import threading
 
-        def _give_up():
+        def _give_up(why):
             if rank == 0 and 'line' in line_holder:
                 ln = dict(line_holder['line'])
-                ln['policy_in_loop'] = dict(error='the policy-in-the-loop extra did not finish within %d s; headline unaffected'
-                                            % args.policy_timeout)
-                print(json.dumps(ln), flush=True)
-            os._exit(0)
-        watchdog = threading.Timer(args.policy_timeout + (0 if rank == 0 else 10), _give_up)
-        watchdog.daemon = True
+                ln['policy_in_loop'] = dict(error=why)
+                print(json.dumps(ln, allow_nan=False), flush=True)
+                if store is not None:
+                    try:
+                        store.set(LINE_KEY, '1')
+                    except Exception:
+                        pass
+            os._exit(3)   # the line is out, but this run did NOT finish: never report success (torchrun / the driver see it)
+
+        class _Watchdog(threading.Thread):
+            daemon = True
+
+            def __init__(self):
+                threading.Thread.__init__(self)
+                self.stop = threading.Event()
+
+            def cancel(self):
+                self.stop.set()
+
+            def run(self):
+                deadline = time.monotonic() + args.policy_timeout + (0 if rank == 0 else 10)
+                while not self.stop.wait(0.25):
+                    if time.monotonic() >= deadline:
+                        _give_up('the policy-in-the-loop extra did not finish within %d s; headline unaffected'
+                                 % args.policy_timeout)
+                    if store is not None:
+                        try:
+                            if store.check([FAIL_KEY]):
+                                _give_up('the policy-in-the-loop extra did not finish: %s; headline unaffected'
+                                         % store.get(FAIL_KEY).decode(errors='replace'))
+                        except Exception:
+                            pass
+        watchdog = _Watchdog()
     if rank == 0:
         value = world * B * T * K / elapsed
         # the dispatcher's own record of what it launched (pw_rollout_kernel)
@@ -444,9 +507,12 @@ def main():
                          'issue': issue,
                          'algorithmic_bytes_per_launch': bytes_per_launch, 'kernel': kernel, 'launch_ms': launch_ms,
                          'bytes_per_env_step': env.bytes_per_env_step, 'env_steps_per_launch': env_steps_per_launch,
-                         'note': 'achieved = 678 B x env-steps per launch / launch_ms (SURVEY 8(d) algorithmic bytes); the '
-                                 'T-step fused launch keeps state in registers, so counter traffic is BELOW that; at '
-                                 'B=4096 the kernel is bound by one wave\'s dependent chain, not by HBM (DESIGN.md 4)'},
+                         'limiter': 'latency: one wave\'s dependent instruction stream per step (DESIGN.md 4), not HBM '
+                                    'bandwidth -- frac_by_traffic is the share of the 8 TB/s this launch really moves'
+                                    if B * N <= 65536 else 'mix of VALU issue and the HBM write path (DESIGN.md 4)',
+                         'note': 'achieved = %d B (SURVEY 8(d) algorithmic bytes per env-step) x env-steps per launch / '
+                                 'launch_ms; the T-step fused launch keeps state in registers, so counter traffic is BELOW '
+                                 'the algorithmic bytes' % env.bytes_per_env_step},
         }
         if world == 1:
             line['cpu_baseline'] = cpu_line
@@ -459,7 +525,14 @@ def main():
                 torch.cuda.empty_cache()
             policy_line = policy_in_loop(args, env if STUB else None, rank, world, dev, use_dist, sync)
         except Exception as e:  # the headline must not depend on this extra
-            policy_line = dict(error=repr(e)[:300])
+            policy_line = dict(error=repr(e)[:300], fatal=bool(use_dist))
+        if isinstance(policy_line, dict) and policy_line.get('fatal') and store is not None:
+            try:
+                store.set(FAIL_KEY, 'rank %d: %s' % (rank, policy_line.get('error')))
+                if rank == 0:
+                    store.set(LINE_KEY, '1')   # the root prints its own line below, with the error in it
+            except Exception:
+                pass
         if world == 1 and rank == 0 and not STUB and not use_dist:
             try:
                 line_holder['line']['other_configs'] = other_configs(dev)
@@ -469,50 +542,99 @@ def main():
     if rank == 0:
         line = line_holder['line']
         line['policy_in_loop'] = policy_line
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line, allow_nan=False), flush=True)
+    if isinstance(policy_line, dict) and policy_line.get('fatal'):
+        # the extra raised on THIS rank: its peers are inside collectives it will not join -- leave, loudly, once the root's
+        # line is out (rank 0 printed it just above; another rank waits for the root's watchdog to have done so)
+        if store is not None and rank != 0:
+            try:
+                store.wait([LINE_KEY], __import__('datetime').timedelta(seconds=8))
+            except Exception:
+                pass
+        sys.stdout.flush()
+        os._exit(4)
     if use_dist:
-        # the line is out; a peer that died must not keep this process (and the launcher) alive in the closing barrier
+        # the line is out; a peer that died must not keep this process (and the launcher) alive in the closing barrier --
+        # and a closing barrier that never completes is a failed run: non-zero
         import threading
-        bye = threading.Timer(args.exit_timeout, lambda: os._exit(0))
+        bye = threading.Timer(args.exit_timeout, lambda: os._exit(3))
         bye.daemon = True
         bye.start()
         try:
             dist.barrier()
             dist.destroy_process_group()
-        except Exception:  # a peer already left (e.g. through its watchdog): nothing left to do but exit cleanly
-            pass
+        except Exception:  # a peer already left (e.g. through its watchdog or a failure of its own): the run failed
+            bye.cancel()
+            sys.stdout.flush()
+            os._exit(3)
         bye.cancel()
 
 
-def other_configs(dev):
-    """Not part of `value`: the other BASELINE.json configurations and the store-bound regime under the same clock
-    (1 GPU; 100-step pw_rollout launches, every output written, 10 launches timed after 2): C3 simple_tag 4+2 at
-    B = 8192, the C5 end point N = 48 at B = 4096, and N = 6 at B = 65536 (where the kernels stop being latency-bound)."""
+# The other BASELINE.json configurations, each at the longest launch its outputs allow: (label, scenario, B, kwargs, T)
+OTHER_CONFIGS = (
+    ('C3 simple_tag 4+2, B=8192', 'simple_tag', 8192, dict(num_adversaries=4, num_good=2), 1000),
+    ('C5 simple_spread N=3, B=4096', 'simple_spread', 4096, dict(num_agents=3), 1000),
+    ('C5 simple_spread N=12, B=4096', 'simple_spread', 4096, dict(num_agents=12), 1000),
+    ('C5 simple_spread N=24, B=4096', 'simple_spread', 4096, dict(num_agents=24), 500),
+    ('C5 simple_spread N=48, B=4096', 'simple_spread', 4096, dict(num_agents=48), 200),
+    ('simple_spread N=6, B=65536 (store-bound regime)', 'simple_spread', 65536, dict(num_agents=6), 100),
+)
+
+
+def measure_rollout(env, dev, T, K, W, ring_cap_bytes=64e9):
+    """The headline's method for any env: K pw_rollout launches of T steps, timed by ONE HIP-event pair on the launch
+    stream after W untimed ones, every output written, a ring of output buffers reused round-robin (up to 4 slots)."""
+    import torch
+    B, N, D = env.num_envs, env.n, env.obs_dim
+    slot_bytes = T * B * N * (2 * D * 4 + 4 + 4 + 1) + T * B * 5
+    ring = max(1, min(4, K, int(ring_cap_bytes // max(1, slot_bytes))))
+    acts = torch.randint(0, 5, (ring * T, B, N), device=dev, dtype=torch.int32)
+    outs = env.alloc_outputs(ring * T, coll=False)
+    launches = [env.plan_rollout(acts[i * T:(i + 1) * T], {k: v[i * T:(i + 1) * T] for k, v in outs.items()})
+                for i in range(ring)]
+    env.reset()
+    for i in range(W):
+        launches[i % ring]()
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(K):
+        launches[(W + i) % ring]()
+    ev[1].record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    launch_ms = ev[0].elapsed_time(ev[1]) / K
+    finite = bool(torch.isfinite(outs['obs'][(((W + K - 1) % ring) + 1) * T - 1]).all().item())
+    return dict(launch_ms=launch_ms, wall_s=wall, ring_slots=ring, outputs_finite=finite)
+
+
+def other_configs(dev, K=10, W=3):
+    """Not part of `value`: the other BASELINE.json configurations and the store-bound regime, measured the way the
+    headline is (measure_rollout: HIP-event bracket over K launches after W, multi-slot output ring, every output
+    written) at the longest launch that fits -- C3 and N <= 12: 1000 steps, N = 24: 500, N = 48: 200.  Each entry names the
+    kernel the dispatcher ran and, where profiles/ holds a rocprofv3 summary of THAT kernel on that workload, its counter
+    traffic per launch and the traffic-based fraction."""
     import torch
     from multiagent_rl_amd.env import BatchedParticleEnv
     out = []
-    for name, scen, B, kw in (('C3 simple_tag 4+2, B=8192', 'simple_tag', 8192, dict(num_adversaries=4, num_good=2)),
-                              ('C5 simple_spread N=48, B=4096', 'simple_spread', 4096, dict(num_agents=48)),
-                              ('simple_spread N=6, B=65536', 'simple_spread', 65536, dict(num_agents=6))):
+    for name, scen, B, kw, T in OTHER_CONFIGS:
         env = BatchedParticleEnv(scen, B, max_episode_len=25, auto_reset=True, seed=12345678, **kw)
-        T = 100
-        acts = torch.randint(0, 5, (T, B, env.n), device=dev, dtype=torch.int32)
-        outs = env.alloc_outputs(T, coll=False)
-        launch = env.plan_rollout(acts, outs)
-        env.reset()
-        for _ in range(2):
-            launch()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            launch()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        rate = B * T * 10 / dt
-        out.append(dict(config=name, value=rate, unit='env-steps/s', us_per_batched_env_step=dt / (10 * T) * 1e6,
-                        bytes_per_env_step=env.bytes_per_env_step,
-                        roofline_frac=rate * env.bytes_per_env_step / 1e9 / HBM_PEAK_GBPS))
-        del env, acts, outs, launch
+        m = measure_rollout(env, dev, T, K, W)
+        per_launch = B * T
+        rate = per_launch / (m['launch_ms'] * 1e-3)
+        kernel = env.last_kernel()
+        prof = _profile_lookup(scen, env.n, B, kernel)
+        traffic = None if prof is None else prof['traffic_bytes_per_env_step'] * per_launch
+        out.append(dict(config=name, value=rate, unit='env-steps/s', us_per_batched_env_step=m['launch_ms'] * 1e3 / T,
+                        batched_env_steps_per_launch=T, launches_timed=K, warmup=W, ring_slots=m['ring_slots'],
+                        kernel=kernel, launch_ms=m['launch_ms'], bytes_per_env_step=env.bytes_per_env_step,
+                        frac=rate * env.bytes_per_env_step / 1e9 / HBM_PEAK_GBPS, traffic=traffic,
+                        frac_by_traffic=None if traffic is None else traffic / (m['launch_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        traffic_source=None if prof is None else prof['_file'],
+                        profile_launch_ms=None if prof is None else prof.get('timed_avg_ns', prof.get('avg_ns', 0.0)) * 1e-6,
+                        outputs_finite=m['outputs_finite']))
+        del env
         torch.cuda.empty_cache()
     return out
 
@@ -576,8 +698,10 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
         if actor is not None:
             actor.rollout(penv, Tp, out)
         else:
-            if os.environ.get('PW_BENCH_STUB_FAIL_RANK') == str(rank) and k >= 2:  # tests: a rank dies mid-exchange
+            if os.environ.get('PW_BENCH_STUB_FAIL_RANK') == str(rank) and k >= 2:  # tests: a rank fails mid-exchange
                 raise RuntimeError('injected failure on rank %d' % rank)
+            if os.environ.get('PW_BENCH_STUB_HANG_RANK') == str(rank) and k >= 2:  # tests: a rank hangs mid-exchange
+                time.sleep(3600)
             penv.stub_policy_chunk(out, k)
             time.sleep(2e-4)
         full(obs0)
@@ -602,13 +726,15 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
         sync()
         tp = time.perf_counter() - tp
     except Exception as e:
-        err = repr(e)[:300]
-        tp = float('nan')
+        # A local failure: the peers are in the barrier / irecv of the exchange, NOT in the all_reduce below -- entering it
+        # would only trade one hang for another.  Report (rank 0 prints the line with this error) and leave with a non-zero
+        # code; the peers end through their own error path or watchdog.
+        return dict(error=repr(e)[:300], fatal=True, value=None, unit='env-steps/s', us_per_step=None, steps=n_chunks * Tp)
     t = torch.tensor([tp], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     tp = float(t.item())
     total = world * B * n_chunks * Tp
-    per_link = full.lay.total_bytes * n_chunks / tp / 1e9 if tp == tp else None
+    per_link = full.lay.total_bytes * n_chunks / tp / 1e9
     return dict(value=total / tp, unit='env-steps/s', us_per_step=tp / (n_chunks * Tp) * 1e6, steps=n_chunks * Tp,
                 policy=label,
                 loop='%d-step chunks, one pw_policy_rollout launch each per rank, outputs written into the wire block' % Tp,

@@ -40,7 +40,7 @@
  *
  * Numerics: IEEE float32, no IMPLICIT FMA contraction, correctly rounded / and sqrt, and
  *   a libm-free deterministic softplus/exp whose polynomial steps are explicit fmaf (definitions:
- *   pworld_math.h, revision 2).  A CPU implementation following pworld_math.h reproduces every
+ *   pworld_math.h, revision 3).  A CPU implementation following pworld_math.h reproduces every
  *   output bit for bit.
  */
 #ifndef PWORLD_H
@@ -53,7 +53,8 @@
 extern "C" {
 #endif
 
-#define PW_VERSION 102 /* 0.1.2: + pw_rollout_kernel (0.1.1: pw_replay_store grew act_heads / per_agent / head_width; wire-block entry points) */
+#define PW_VERSION 103 /* 0.1.3: + pw_dispatch (kernel selection frozen in the handle; no environment reads at launch)
+                          (0.1.2: + pw_rollout_kernel; 0.1.1: pw_replay_store grew act_heads / per_agent / head_width; wire-block entry points) */
 #define PW_MAX_AGENTS 64
 #define PW_MAX_LANDMARKS 64
 
@@ -170,6 +171,31 @@ int pw_reward(pw_handle *h, float *rew, uint64_t *coll, void *stream);
 int pw_step(pw_handle *h, const pw_step_io *io, void *stream);
 /* T consecutive steps in ONE launch (state stays in registers/LDS between steps). */
 int pw_rollout(pw_handle *h, const pw_step_io *io, int num_steps, void *stream);
+
+/* ---- kernel selection ------------------------------------------------------------------------------------------
+ * The dispatcher picks a kernel form per (scenario, N, L, B, outputs requested) from measured crossovers.  Every field
+ * below overrides one of those choices for ONE handle; the selection lives in the handle, is fixed by pw_create /
+ * pw_set_dispatch, and nothing on the pw_step / pw_rollout / pw_policy_rollout path reads the process environment.
+ * pw_create initialises it from pw_dispatch_default() overlaid, once, with the PWORLD_* environment variables of the
+ * creating process (for A/B runs of unmodified host programs: PWORLD_FORCE_GENERIC, PWORLD_NO_STREAM, PWORLD_NO_DUO,
+ * PWORLD_FORCE_DUO, PWORLD_NO_QUAD, PWORLD_FORCE_QUAD, PWORLD_OBS_BLOCK, PWORLD_SPREAD_TRIO / PWORLD_TAG_TRIO,
+ * PWORLD_P_PRIO, PWORLD_EPW, PWORLD_POLICY_V1 / PWORLD_POLICY_V2); pw_set_dispatch replaces it.  Results never depend
+ * on it: every form produces the same bits (tests/test_gpu_parity.py runs them all against the oracle). */
+typedef struct pw_dispatch {
+    uint32_t struct_size;  /* = sizeof(pw_dispatch); checked */
+    int32_t force_generic; /* 1: the generic kernel (pw_rollout_kernel) for every launch */
+    int32_t no_stream;     /* 1: no streaming family (quad / duo / stream): pw_spread_fast_kernel, generic simple_tag */
+    int32_t duo;           /* -1 auto (by grid size); 0: the one-wave stream form (and no quad form); 1: the two-wave duo form on any grid */
+    int32_t quad;          /* -1 auto; 0: off; 1: pw_spread_quad_kernel wherever it applies (N = L = 6, unit mass) */
+    int32_t obs_block;     /* -1 auto; 0: row-wise observation stores; 1: block-wise */
+    int32_t trio;          /* -1 auto; 0 / 1: the three-wave variants of the duo kernels (spread: block-store forms, N >= 6) */
+    int32_t p_prio;        /* -1 auto; >= 0: issue-priority bits of the duo kernels' waves (2 bits per wave; simple_tag: 0 / 1) */
+    int32_t envs_per_wave; /* 0 auto; n >= 1: envs per wave, clamped to 64 / N */
+    int32_t policy_form;   /* 0 auto; 1 / 2: pw_policy_rollout_kernel / pw_policy_rollout2_kernel */
+} pw_dispatch;
+int pw_dispatch_default(pw_dispatch *d);                    /* every choice automatic */
+int pw_set_dispatch(pw_handle *h, const pw_dispatch *d);    /* between launches; the bound state is untouched */
+int pw_get_dispatch(const pw_handle *h, pw_dispatch *out);
 
 /* Name of the device kernel the last pw_step / pw_rollout on this handle launched (a static string; "" before the
  * first launch).  The dispatcher picks a kernel per (scenario, N, L, B, outputs requested): measurement tools name the

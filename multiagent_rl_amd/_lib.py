@@ -47,6 +47,12 @@ class PwStepIO(C.Structure):
                 ('act_idx', 'act_vec', 'obs', 'final_obs', 'rew', 'rew_shared', 'done', 'terminal', 'coll', 'act_comm')]
 
 
+class PwDispatch(C.Structure):
+    """pw_dispatch: the kernel selection of one handle (include/pworld.h); -1 / 0 = automatic."""
+    _fields_ = [('struct_size', C.c_uint32)] + [(n, C.c_int32) for n in
+                ('force_generic', 'no_stream', 'duo', 'quad', 'obs_block', 'trio', 'p_prio', 'envs_per_wave', 'policy_form')]
+
+
 class PwRolloutSink(C.Structure):
     _fields_ = [('ring', C.c_void_p), ('ring_start', C.c_int64), ('episode_return', C.c_void_p),
                 ('finished_sum', C.c_void_p), ('finished_count', C.c_void_p), ('scratch', C.c_void_p)]
@@ -73,6 +79,9 @@ SIGNATURES = {
     'pw_obs_dim': (C.c_int, [C.c_void_p]),
     'pw_get_config': (C.c_int, [C.c_void_p, C.POINTER(PwConfig)]),
     'pw_set_force_discrete_action': (C.c_int, [C.c_void_p, C.c_int]),
+    'pw_dispatch_default': (C.c_int, [C.POINTER(PwDispatch)]),
+    'pw_set_dispatch': (C.c_int, [C.c_void_p, C.POINTER(PwDispatch)]),
+    'pw_get_dispatch': (C.c_int, [C.c_void_p, C.POINTER(PwDispatch)]),
     'pw_get_state_layout': (C.c_int, [C.c_void_p, C.POINTER(PwStateLayout)]),
     'pw_state_bytes': (C.c_size_t, [C.c_void_p]),
     'pw_bind_state': (C.c_int, [C.c_void_p, C.c_void_p]),

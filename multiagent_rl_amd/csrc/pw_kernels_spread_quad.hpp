@@ -40,7 +40,10 @@ __device__ __forceinline__ void quad_pair_of(const int q, int &i, int &j)
     j = q - (i == 0 ? 0 : i == 1 ? 5 : i == 2 ? 9 : i == 3 ? 12 : 14) + i + 1;
 }
 
-template <bool UNIT_MASS>
+// COLL: wave OA also stores the step's collision masks (pw_step_io.coll) -- it holds the six threshold tests anyway, so
+// the instantiation differs by one mask accumulation and one 8-byte store per lane and step; every other output is
+// bit-identical to the plain form (tests: the `quad+coll` path, and the bench-path test at C2 full size).
+template <bool UNIT_MASS, bool COLL = false>
 __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamParams A, const int T)
 {
     constexpr int N = 6, L = 6, D = 16, P2 = 15, EPP = 4, EPW = 8;
@@ -244,6 +247,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             const float2 mine = *reinterpret_cast<const float2 *>(slot + a);
             const float px = mine.x, py = mine.y;
             int cnt = 0;
+            uint32_t cmask = 0;
             float e2[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) {
@@ -251,6 +255,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
                 const float dx = q.x - px, dy = q.y - py;
                 const float d2 = dx * dx + dy * dy;
                 cnt += d2 < A.coll_thr2 ? 1 : 0;
+                if (COLL) cmask |= d2 < A.coll_thr2 ? 1u << j : 0u;
                 const float ex = q.x - olx, ey = q.y - oly;
                 e2[j] = ex * ex + ey * ey;
             }
@@ -274,6 +279,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             for (int i = 0; i < N; ++i) acc += __shfl(r, base + i, kWave);
             nt_store(A.rew + tBN + g, r);
             nt_store(A.rew_shared + (size_t)t * A.B + env, acc);   // (done / terminal: wave OB, which has the slack)
+            if (COLL) nt_store(A.coll + tBN + g, (uint64_t)cmask);  // is_collision bits of the state this step produced (pre-reset)
             if (t == t_reset) {  // workgroup-uniform, once per episode
                 if (t + 1 + ep_off >= A.max_episode_len) {
                     ep_count += 1;

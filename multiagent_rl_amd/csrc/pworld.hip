@@ -53,6 +53,7 @@ struct pw_handle {
     float *comm;    // simple_reference planes inside the bound state block
     int32_t *goal;
     const char *last_kernel;  // name of the kernel the last pw_step / pw_rollout launched (pw_rollout_kernel)
+    pw_dispatch disp;         // kernel selection: fixed by pw_create / pw_set_dispatch, never read from the environment at launch
 };
 
 namespace {
@@ -118,7 +119,7 @@ void setup_tag_path(pw_handle *h)
     const pw_config &c = h->cfg;
     const KParams &kp = h->kp;
     h->tag_fast = false;
-    if (std::getenv("PWORLD_FORCE_GENERIC")) return;
+    if (h->disp.force_generic) return;
     if (c.scenario != PW_SIMPLE_TAG || !c.landmark_collide || kp.N < 1) return;
     const int A = kp.A, N = kp.N;
     const int rep[2] = {A > 0 ? 0 : 0, A < N ? A : 0};  // representative agent of each class
@@ -164,7 +165,7 @@ void setup_fast_path(pw_handle *h)
     const pw_config &c = h->cfg;
     const KParams &kp = h->kp;
     h->fast = false;
-    if (std::getenv("PWORLD_FORCE_GENERIC")) return;
+    if (h->disp.force_generic) return;
     if (c.scenario != PW_SIMPLE_SPREAD || c.obs_mode != PW_OBS_LOCAL || c.landmark_collide) return;
     if (kp.L > kp.N) return;
     for (int i = 0; i < kp.N; ++i) {
@@ -183,6 +184,67 @@ void setup_fast_path(pw_handle *h)
     fc.near_thr2 = exact_near_thr2(dmin, kp.contact_margin);
     if (fc.coll_thr2 == 0.0f || fc.near_thr2 == 0.0f) return;
     h->fast = true;
+}
+
+void dispatch_defaults(pw_dispatch *d)
+{
+    std::memset(d, 0, sizeof(*d));
+    d->struct_size = sizeof(pw_dispatch);
+    d->duo = d->quad = d->obs_block = d->trio = d->p_prio = -1;
+}
+
+// The PWORLD_* variables of the creating process, read ONCE per handle (pw_create): A/B runs of unmodified host programs.
+void dispatch_from_environment(pw_dispatch *d)
+{
+    dispatch_defaults(d);
+    if (std::getenv("PWORLD_FORCE_GENERIC")) d->force_generic = 1;
+    if (std::getenv("PWORLD_NO_STREAM")) d->no_stream = 1;
+    if (std::getenv("PWORLD_FORCE_DUO")) d->duo = 1;
+    if (std::getenv("PWORLD_NO_DUO")) d->duo = 0;
+    if (std::getenv("PWORLD_FORCE_QUAD")) d->quad = 1;
+    if (std::getenv("PWORLD_NO_QUAD")) d->quad = 0;
+    if (const char *e = std::getenv("PWORLD_OBS_BLOCK")) d->obs_block = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PWORLD_SPREAD_TRIO")) d->trio = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PWORLD_TAG_TRIO")) d->trio = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PWORLD_P_PRIO")) d->p_prio = std::atoi(e) & 0xFFFF;
+    if (const char *e = std::getenv("PWORLD_EPW")) d->envs_per_wave = std::atoi(e) >= 1 ? std::atoi(e) : 0;
+    if (std::getenv("PWORLD_POLICY_V2")) d->policy_form = 2;
+    if (std::getenv("PWORLD_POLICY_V1")) d->policy_form = 1;
+}
+
+// Everything the selection decides ahead of a launch: envs per wave and which specialised paths apply.
+void apply_dispatch(pw_handle *h)
+{
+    KParams &kp = h->kp;
+    kp.epw = kWave / kp.N;
+    // Envs per wave.  Dense packing (64 / N) is not the fastest for the small N of the BASELINE configs: measured on
+    // MI355X (tools/sweep.py), 48-lane waves beat 60/63-lane ones at N = 6 (8 vs 10 envs per wave: +3.5 %
+    // at B = 4096, +7 % at 8192, +2-4 % up to 262144; simple_tag 4+2: +10-12 %) and N = 3 (16 vs 21: +14 % at
+    // B = 65536) -- fewer near-pair iterations per wave-step (max over the wave's lanes) and workgroup counts that are
+    // multiples of the 256 CUs -- while N = 9, 12, 24 are faster densely packed.
+    if (kp.N == 6) kp.epw = 8;
+    else if (kp.N == 3) kp.epw = 16;
+    // Small batches are latency bound (one wave per SIMD, the chip not even full): spread the envs over about
+    // 512 workgroups (2 waves each in the duo kernels = the 1024 SIMDs) instead of packing them densely.
+    {
+        const int spread = (kp.B + 511) / 512;
+        if (spread < kp.epw) kp.epw = spread < 1 ? 1 : spread;
+    }
+    if (h->disp.envs_per_wave >= 1)  // experiments / tests: e.g. 64 = the dense packing of large batches
+        kp.epw = h->disp.envs_per_wave < kWave / kp.N ? h->disp.envs_per_wave : kWave / kp.N;
+    setup_fast_path(h);
+    setup_tag_path(h);
+}
+
+// Kernels that ask for more than 64 KB of dynamic LDS need the opt-in once per (kernel, DEVICE): a process driving
+// several GPUs must not skip it on the second one.
+bool lds_optin_needed(unsigned long long *done_mask)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;  // unknown: set it every time (cheap)
+    if (*done_mask >> dev & 1ull) return false;
+    *done_mask |= 1ull << dev;
+    return true;
 }
 
 int check_ready(const pw_handle *h)
@@ -231,7 +293,8 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
     const dim3 grid((kp.B + kp.epw - 1) / kp.epw), block(kWave);
     const size_t shmem = smem_bytes(kp);
     if (h->tag_fast && io->act_idx && io->obs && io->rew && io->rew_shared && io->done && io->terminal &&
-        (size_t)kp.B * kp.N * kp.D * sizeof(float) < (1ull << 31) && !std::getenv("PWORLD_NO_STREAM")) {
+        (size_t)kp.B * kp.N * kp.D * sizeof(float) < (1ull << 31) && !h->disp.no_stream) {
+        const pw_dispatch &dp = h->disp;
         TagParams A = h->tp;
         A.pos_x = kp.pos_x; A.pos_y = kp.pos_y; A.vel_x = kp.vel_x; A.vel_y = kp.vel_y;
         A.lm_x = kp.lm_x; A.lm_y = kp.lm_y; A.ep_step = kp.ep_step; A.ep_count = kp.ep_count;
@@ -243,17 +306,17 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         const bool um = kp.mass == 1.0f;
         // two waves per env group, as for simple_spread.  With the block-wise observation stores (below) the duo form
         // leads on every grid measured: B = 8192: 1.69 vs 2.41 us per step, B = 65536: 10.3 vs 19.0 (profiles/r2_tag_block.txt)
-        const bool duo = (grid.x <= 8192 && !std::getenv("PWORLD_NO_DUO")) || std::getenv("PWORLD_FORCE_DUO");
+        const bool duo = dp.duo < 0 ? grid.x <= 8192 : dp.duo != 0;
         size_t shm2 = 3 * kWave * sizeof(float4) + 3 * kWave * sizeof(float) + 2 * (size_t)kp.epw * kp.L * sizeof(float2);
         // Block-wise observation stores of the duo kernel (rows staged in LDS): short rows only (LDS), chunks of 4 floats
-        // when every wave's block starts and ends on 16 bytes, else of 2 (D is even).  PWORLD_OBS_BLOCK=0/1 overrides.
+        // when every wave's block starts and ends on 16 bytes, else of 2 (D is even).  pw_dispatch.obs_block overrides.
         A.obs_block = 0;
         // the physics wave first where it shares a SIMD with output waves: -2..-4 % step time on grids up to 2048 workgroups
         // (C3, N = 3 / 12, B = 16384), +2..4 % on the larger ones (profiles/r2_priority.txt)
-        A.p_prio = std::getenv("PWORLD_P_PRIO") ? std::atoi(std::getenv("PWORLD_P_PRIO")) : (grid.x <= 2048 ? 1 : 0);
+        A.p_prio = dp.p_prio >= 0 ? dp.p_prio : (grid.x <= 2048 ? 1 : 0);
         if (duo && kp.D <= 32) {
             bool on = grid.x > 700;   // as for simple_spread (profiles/r2_obs_block_threshold.txt)
-            if (const char *e = std::getenv("PWORLD_OBS_BLOCK")) on = std::atoi(e) != 0;
+            if (dp.obs_block >= 0) on = dp.obs_block != 0;
             if (on) {
                 const bool v4 = ((size_t)kp.B * kp.N * kp.D) % 4 == 0 && ((size_t)kp.epw * kp.N * kp.D) % 4 == 0 &&
                                 (reinterpret_cast<uintptr_t>(io->obs) & 15) == 0 && kp.B % kp.epw == 0;
@@ -262,9 +325,9 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
             }
         }
         // Three waves per env group (the output wave split into a rewards wave and an observation wave) where the single
-        // output wave is the step's critical path: measured crossover in profiles/r2_tag_block.txt.  PWORLD_TAG_TRIO=0/1.
+        // output wave is the step's critical path: measured crossover in profiles/r2_tag_block.txt.  pw_dispatch.trio overrides.
         bool trio = duo && grid.x >= 512 && grid.x <= 1280;
-        if (const char *e = std::getenv("PWORLD_TAG_TRIO")) trio = duo && std::atoi(e) != 0;
+        if (dp.trio >= 0) trio = duo && dp.trio != 0;
         const dim3 block2((trio ? 3 : 2) * kWave);
 #define PW_TAG_LAUNCH(n, a, l, c)                                                                              \
     do {                                                                                                       \
@@ -288,12 +351,13 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         return PW_OK;
     }
     if (h->fast && io->act_idx && io->obs && io->rew && io->rew_shared && io->done && io->terminal &&
-        (size_t)kp.B * kp.N * kp.D * sizeof(float) < (1ull << 31) && !std::getenv("PWORLD_NO_STREAM")) {
+        (size_t)kp.B * kp.N * kp.D * sizeof(float) < (1ull << 31) && !h->disp.no_stream) {
+        const pw_dispatch &dp = h->disp;
         StreamParams A;
         A.B = kp.B; A.N = kp.N; A.L = kp.L; A.epw = kp.epw;
         // issue priority per wave, 2 bits each: the physics wave first where it shares a SIMD with output waves: -2..-4 % step
         // time on grids up to 2048 workgroups (N = 3 / 12, B = 16384), +2..4 % on the larger ones (profiles/r2_priority.txt)
-        A.p_prio = std::getenv("PWORLD_P_PRIO") ? std::atoi(std::getenv("PWORLD_P_PRIO")) : (grid.x <= 2048 ? 3 : 0);
+        A.p_prio = dp.p_prio >= 0 ? dp.p_prio : (grid.x <= 2048 ? 3 : 0);
         A.max_episode_len = kp.max_episode_len; A.auto_reset = kp.auto_reset;
         A.seed = kp.seed; A.env_id_base = kp.env_id_base;
         A.dt = kp.dt; A.damp = kp.damp; A.contact_force = kp.contact_force; A.contact_margin = kp.contact_margin;
@@ -312,37 +376,41 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         // block form is what the write path wants once the run is store-bound (B = 65536, N = 6: +58 %; N = 24 / 48 at
         // B = 4096: +59 % / +47 %), but it lengthens the output wave's step, which latency-bound small grids pay for
         // (C2: -5 %; N = 3, B = 16384: -38 %).  Measured crossover (profiles/r2_obs_block_threshold.txt): between 512
-        // and 820 workgroups for N = 6 ... 24, above 1024 for N = 3 (8-byte chunks).  PWORLD_OBS_BLOCK=0/1 overrides.
+        // and 820 workgroups for N = 6 ... 24, above 1024 for N = 3 (8-byte chunks).  pw_dispatch.obs_block overrides.
         bool blk = kp.N == 3 ? grid.x > 3000 : grid.x > 700;
-        if (const char *e = std::getenv("PWORLD_OBS_BLOCK")) blk = std::atoi(e) != 0;
+        if (dp.obs_block >= 0) blk = dp.obs_block != 0;
         const int key = kp.N != kp.L ? 0 : (wc && !(um && (kp.N == 3 || kp.N == 6))) ? 0 : kp.N;
         // N = L = 6 on small grids (BASELINE configs[1]): four cooperating waves per 8 envs, pair-parallel physics
         // (pw_kernels_spread_quad.hpp).  More total instructions than the duo form, shorter dependent chains: it pays
-        // while the chip is latency bound.  PWORLD_FORCE_QUAD / PWORLD_NO_QUAD override (tests, experiments).
+        // while the chip is latency bound.  pw_dispatch.quad overrides (tests, experiments).  With the collision-mask output
+        // requested it is the COLL instantiation: the same kernel plus one mask store in its reward wave.
         {
             const unsigned qgrid = (unsigned)((kp.B + 7) / 8);
-            bool quad = kp.N == 6 && kp.L == 6 && um && !wc && qgrid <= 1536 && !std::getenv("PWORLD_NO_DUO");  // B <= 12288: measured crossover (profiles/r2_sweeps_final.txt)
-            if (std::getenv("PWORLD_NO_QUAD")) quad = false;
-            if (std::getenv("PWORLD_FORCE_QUAD") && kp.N == 6 && kp.L == 6 && um && !wc) quad = true;
+            const bool quad_ok = kp.N == 6 && kp.L == 6 && um;
+            bool quad = quad_ok && qgrid <= 1536 && dp.duo != 0;  // B <= 12288: measured crossover (profiles/r2_sweeps_final.txt)
+            if (dp.quad >= 0) quad = quad_ok && dp.quad != 0;
             if (quad) {
                 const size_t qshm = 4 * kWave * sizeof(float4) + 2 * 4 * 6 * 6 * sizeof(float2) + 2 * kWave * sizeof(float) +
                                     8 * 6 * sizeof(float2) + kWave * sizeof(float4) + 2 * kActRingBytes + 2 * 8 * sizeof(float2);
-                PW_LAUNCH(h, (pw_spread_quad_kernel<true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
+                if (wc) PW_LAUNCH(h, (pw_spread_quad_kernel<true, true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
+                else PW_LAUNCH(h, (pw_spread_quad_kernel<true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
                 PW_HIP_CHECK(hipGetLastError());
                 return PW_OK;
             }
         }
         // two cooperating waves per env group pay off while the chip is latency bound (few workgroups
         // per CU); once every SIMD holds several waves the single-wave kernel issues fewer instructions
-        const bool duo = grid.x <= 8192 && !std::getenv("PWORLD_NO_DUO");
-        if (duo || std::getenv("PWORLD_FORCE_DUO")) {
+        const bool duo = dp.duo < 0 ? grid.x <= 8192 : dp.duo != 0;
+        if (duo) {
             const size_t shm2 = 3 * kWave * sizeof(float4) + (size_t)kp.epw * kp.L * sizeof(float2) +
                                 2 * kWave * sizeof(float) + 16 + kWave * sizeof(float4) + 8 * sizeof(float2);
             // three waves per env group (the output wave split in two) where the single output wave is the step's critical
-            // path: block-store instantiations on mid-size grids (measured: profiles/r2_trio.txt).  PWORLD_SPREAD_TRIO=0/1.
-            bool trio = um && blk && !wc && key >= 12 && grid.x >= 512 && grid.x <= 1280;
-            if (const char *e = std::getenv("PWORLD_SPREAD_TRIO")) trio = um && blk && !wc && key >= 6 && std::atoi(e) != 0;
-            if (trio && !std::getenv("PWORLD_P_PRIO")) A.p_prio = 3 | (3 << 4);  // three waves: physics and observation wave first (N = 12: -2.5 %)
+            // path: block-store instantiations on mid-size grids (measured: profiles/r2_trio.txt).  pw_dispatch.trio overrides.
+            // (only the compile-time instantiations below have the three-wave form: a runtime-N launch stays two waves wide)
+            const bool trio_inst = key == 6 || key == 9 || key == 12 || key == 24 || key == 48;
+            bool trio = um && blk && !wc && key >= 12 && trio_inst && grid.x >= 512 && grid.x <= 1280;
+            if (dp.trio >= 0) trio = um && blk && !wc && trio_inst && dp.trio != 0;
+            if (trio && dp.p_prio < 0) A.p_prio = 3 | (3 << 4);  // three waves: physics and observation wave first (N = 12: -2.5 %)
             const dim3 block2((trio ? 3 : 2) * kWave);
             if (wc) {
                 if (key == 3) PW_LAUNCH(h, (pw_spread_duo_kernel<3, 3, true, true>), grid, block2, shm2, st, A, T);
@@ -549,24 +617,6 @@ int pw_create(const pw_config *cfg, pw_handle **out)
     kp.B = cfg->num_envs; kp.N = cfg->num_agents; kp.L = cfg->num_landmarks;
     kp.A = cfg->scenario == PW_SIMPLE_TAG ? cfg->num_adversaries : 0;
     kp.D = obs_dim_of(*cfg);
-    kp.epw = kWave / kp.N;
-    // Envs per wave.  Dense packing (64 / N) is not the fastest for the small N of the BASELINE configs: measured on
-    // MI355X (tools/sweep.py, PWORLD_EPW), 48-lane waves beat 60/63-lane ones at N = 6 (8 vs 10 envs per wave: +3.5 %
-    // at B = 4096, +7 % at 8192, +2-4 % up to 262144; simple_tag 4+2: +10-12 %) and N = 3 (16 vs 21: +14 % at
-    // B = 65536) -- fewer near-pair iterations per wave-step (max over the wave's lanes) and workgroup counts that are
-    // multiples of the 256 CUs -- while N = 9, 12, 24 are faster densely packed.
-    if (kp.N == 6) kp.epw = 8;
-    else if (kp.N == 3) kp.epw = 16;
-    // Small batches are latency bound (one wave per SIMD, the chip not even full): spread the envs over about
-    // 512 workgroups (2 waves each in the duo kernels = the 1024 SIMDs) instead of packing them densely.
-    {
-        const int spread = (kp.B + 511) / 512;
-        if (spread < kp.epw) kp.epw = spread < 1 ? 1 : spread;
-    }
-    if (const char *e = std::getenv("PWORLD_EPW")) {  // experiments: fewer envs per wave (more, shorter waves)
-        const int v = std::atoi(e);
-        if (v >= 1) kp.epw = v < kWave / kp.N ? v : kWave / kp.N;  // e.g. 64 = the dense packing of large batches
-    }
     kp.max_episode_len = cfg->max_episode_len;
     kp.auto_reset = cfg->auto_reset;
     kp.force_discrete = cfg->force_discrete_action;
@@ -583,8 +633,8 @@ int pw_create(const pw_config *cfg, pw_handle **out)
                                  : 1.0f;
         kp.agent_max_speed[i] = cfg->agent_max_speed[i];
     }
-    setup_fast_path(h);
-    setup_tag_path(h);
+    dispatch_from_environment(&h->disp);
+    apply_dispatch(h);
     const size_t BN = (size_t)kp.B * kp.N, BL = (size_t)kp.B * kp.L;
     pw_state_layout &lo = h->layout;
     size_t off = 0;
@@ -614,6 +664,34 @@ int pw_get_config(const pw_handle *h, pw_config *out)
 {
     if (!h || !out) return fail(PW_EINVAL, "null argument");
     *out = h->cfg;
+    return PW_OK;
+}
+
+int pw_dispatch_default(pw_dispatch *d)
+{
+    if (!d) return fail(PW_EINVAL, "null argument");
+    dispatch_defaults(d);
+    return PW_OK;
+}
+
+int pw_set_dispatch(pw_handle *h, const pw_dispatch *d)
+{
+    if (!h || !d) return fail(PW_EINVAL, "null argument");
+    if (d->struct_size != sizeof(pw_dispatch)) return fail(PW_EINVAL, "pw_dispatch.struct_size mismatch (ABI)");
+    if (d->duo < -1 || d->duo > 1 || d->quad < -1 || d->quad > 1 || d->obs_block < -1 || d->obs_block > 1 || d->trio < -1 ||
+        d->trio > 1 || d->p_prio < -1 || d->p_prio > 0xFFFF || d->envs_per_wave < 0 || d->policy_form < 0 || d->policy_form > 2)
+        return fail(PW_EINVAL, "pw_dispatch field out of range");
+    h->disp = *d;
+    h->disp.force_generic = d->force_generic != 0;
+    h->disp.no_stream = d->no_stream != 0;
+    apply_dispatch(h);
+    return PW_OK;
+}
+
+int pw_get_dispatch(const pw_handle *h, pw_dispatch *out)
+{
+    if (!h || !out) return fail(PW_EINVAL, "null argument");
+    *out = h->disp;
     return PW_OK;
 }
 
@@ -1032,13 +1110,12 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
     const size_t shm = actor_lds_bytes(S1);
     const unsigned grid = (unsigned)((B + a.E - 1) / a.E);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static bool attr_set[9] = {};
+    static unsigned long long attr_set[9] = {};  // per kernel: bit = device
 #define PW_FUSED(C)                                                                                                      \
     case C:                                                                                                              \
-        if (!attr_set[C]) {                                                                                              \
+        if (lds_optin_needed(&attr_set[C])) {                                                                            \
             PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_actor_fused_kernel<C>),                   \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-            attr_set[C] = true;                                                                                          \
         }                                                                                                                \
         hipLaunchKernelGGL(pw_actor_fused_kernel<C>, dim3(grid), dim3(512), shm, st, a);                                 \
         break;
@@ -1109,11 +1186,10 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         hipStream_t tst = static_cast<hipStream_t>(stream);
 #define PW_TG3(C, SK)                                                                                                    \
     do {                                                                                                                 \
-        static bool attr_set = false;                                                                                    \
-        if (!attr_set) {                                                                                                 \
+        static unsigned long long attr_set = 0; /* bit = device */                                            \
+        if (lds_optin_needed(&attr_set)) {                                                                                \
             PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_tag_kernel<C, SK>),        \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-            attr_set = true;                                                                                             \
         }                                                                                                                \
         hipLaunchKernelGGL((pw_policy_rollout_tag_kernel<C, SK>), dim3(tgrid), dim3(512), tshm, tst, Q);                 \
     } while (0)
@@ -1156,13 +1232,13 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     // vector ALUs busy together, weights resident in registers -- with as many environments per workgroup as fit
     // 160 KB of LDS, so it also serves long observation rows (D <= 64: N <= 30).  Measured at B = 4096
     // (profiles/r2_policy_rollout.txt): N = 3: 15.4 vs 17.0 us/step; N = 6: 22.3 vs 23.4; N = 12: 69.1 vs 67.5; N = 16: 169 vs
-    // 120 -- so the second form runs where it wins (N <= 6) or where the first does not fit.  PWORLD_POLICY_V1 / PWORLD_POLICY_V2 override.
+    // 120 -- so the second form runs where it wins (N <= 6) or where the first does not fit.  pw_dispatch.policy_form overrides.
     const size_t shm = actor_lds_bytes(S1) + (size_t)kFusedRows * kp.D * sizeof(float) + kFusedRows * sizeof(int32_t) +
                        2 * kWave * sizeof(float2) + (size_t)a.E * kp.L * sizeof(float2) + 16 * (sizeof(double) + sizeof(int));
     const bool v1_fits = shm <= 160 * 1024;
     bool use_v2 = !v1_fits || kp.N <= 6;
-    if (std::getenv("PWORLD_POLICY_V2")) use_v2 = true;
-    if (std::getenv("PWORLD_POLICY_V1") && v1_fits) use_v2 = false;
+    if (h->disp.policy_form == 2) use_v2 = true;
+    if (h->disp.policy_form == 1 && v1_fits) use_v2 = false;
     int E2 = 0;
     if (use_v2) {
         for (int e = a.E; e >= 1; --e)
@@ -1175,11 +1251,10 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         const unsigned grid2 = (unsigned)((kp.B + E2 - 1) / E2);
 #define PW_R23(C, NT, SK)                                                                                                \
     do {                                                                                                                 \
-        static bool attr_set = false;                                                                                    \
-        if (!attr_set) {                                                                                                 \
+        static unsigned long long attr_set = 0; /* bit = device */                                            \
+        if (lds_optin_needed(&attr_set)) {                                                                                \
             PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout2_kernel<C, NT, SK>),       \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-            attr_set = true;                                                                                             \
         }                                                                                                                \
         hipLaunchKernelGGL((pw_policy_rollout2_kernel<C, NT, SK>), dim3(grid2), dim3(512), shm2, st, P);                 \
     } while (0)
@@ -1198,11 +1273,10 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     const unsigned grid = (unsigned)((kp.B + a.E - 1) / a.E);
 #define PW_PR3(C, NT, SK)                                                                                                \
     do {                                                                                                                 \
-        static bool attr_set = false;                                                                                    \
-        if (!attr_set) {                                                                                                 \
+        static unsigned long long attr_set = 0; /* bit = device */                                            \
+        if (lds_optin_needed(&attr_set)) {                                                                                \
             PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_kernel<C, NT, SK>),        \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-            attr_set = true;                                                                                             \
         }                                                                                                                \
         hipLaunchKernelGGL((pw_policy_rollout_kernel<C, NT, SK>), dim3(grid), dim3(512), shm, st, P);                    \
     } while (0)
@@ -1308,13 +1382,12 @@ int pw_actor_front(const float *X, const float *frag, const float *b1, const flo
     const size_t shm = (size_t)8 * 2 * 4 * 64 * sizeof(float4) + (size_t)(2 * S1 * 64 + 64 + 256 + 4 * 32 * 33) * sizeof(float);
     const long tiles = (rows + 127) / 128;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static bool attr_set[9] = {};
+    static unsigned long long attr_set[9] = {};  // per kernel: bit = device
 #define PW_FRONT(C)                                                                                                      \
     case C:                                                                                                              \
-        if (!attr_set[C]) { /* > 64 KB of dynamic LDS needs the opt-in */                                                \
+        if (lds_optin_needed(&attr_set[C])) { /* > 64 KB of dynamic LDS needs the opt-in */                              \
             PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_actor_front_kernel<C>),                   \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-            attr_set[C] = true;                                                                                          \
         }                                                                                                                \
         hipLaunchKernelGGL(pw_actor_front_kernel<C>, dim3((unsigned)tiles), dim3(256), shm, st, X, frag, b1, b_ih,       \
                            (long)rows, in_dim, G);                                                                       \

@@ -119,7 +119,7 @@ class BatchedParticleEnv(object):
     """
 
     def __init__(self, scenario_name='simple_spread', num_envs=1, device=None, config=None, want_coll=False,
-                 **kw):
+                 dispatch=None, **kw):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.PworldError('BatchedParticleEnv needs a GPU: libpworld has no CPU fallback')
@@ -129,6 +129,8 @@ class BatchedParticleEnv(object):
         h = C.c_void_p()
         check(self.lib.pw_create(C.byref(self.cfg), C.byref(h)))
         self._h = h
+        if dispatch:
+            self.set_dispatch(**dispatch)
         self.num_envs, self.n = self.cfg.num_envs, self.cfg.num_agents
         self.num_landmarks = self.cfg.num_landmarks
         self.obs_dim = self.lib.pw_obs_dim(h)
@@ -163,6 +165,23 @@ class BatchedParticleEnv(object):
         h, self._h = getattr(self, '_h', None), None
         if h:
             self.lib.pw_destroy(h)
+
+    # -- kernel selection (pw_dispatch): results never depend on it, only which kernel form runs
+    def get_dispatch(self):
+        d = _lib.PwDispatch()
+        check(self.lib.pw_get_dispatch(self._h, C.byref(d)))
+        return {n: int(getattr(d, n)) for n, _ in _lib.PwDispatch._fields_ if n != 'struct_size'}
+
+    def set_dispatch(self, **fields):
+        """Override the dispatcher's choices for this handle, e.g. ``set_dispatch(duo=0)`` (one-wave stream form),
+        ``set_dispatch(quad=1)``, ``set_dispatch(envs_per_wave=64)``; unnamed fields keep their current value."""
+        d = _lib.PwDispatch()
+        check(self.lib.pw_get_dispatch(self._h, C.byref(d)))
+        for k, v in fields.items():
+            if k == 'struct_size' or not hasattr(d, k):
+                raise TypeError('unknown pw_dispatch field %r' % k)
+            setattr(d, k, int(v))
+        check(self.lib.pw_set_dispatch(self._h, C.byref(d)))
 
     # -- helpers
     def _stream(self):

@@ -178,7 +178,7 @@ class COracle(object):
         return rew, coll
 
     def step(self, act_idx=None, act_vec=None):
-        """-> dict(obs, final_obs, rew, done, terminal, coll)"""
+        """-> dict(obs, final_obs, rew, rew_shared, done, terminal, coll)"""
         B, N, D = self.B, self.N, self.D
         out = dict(obs=np.zeros((B, N, D), self.dtype), final_obs=np.zeros((B, N, D), self.dtype),
                    rew=np.zeros((B, N), self.dtype), done=np.zeros((B, N), np.uint8),
@@ -192,6 +192,11 @@ class COracle(object):
             _p(out['obs'], self.ct), _p(out['final_obs'], self.ct), _p(out['rew'], self.ct),
             _p(out['done'], C.c_uint8), _p(out['terminal'], C.c_uint8), _p(out['coll'], C.c_uint64))
         assert rc == 0
+        # run.py:46 rew_shared = np.sum(rew_n): the agent-order sum, one rounding per addition in this dtype
+        shared = np.zeros(B, self.dtype)
+        for i in range(N):
+            shared = shared + out['rew'][:, i]
+        out['rew_shared'] = shared
         return out
 
 

@@ -7,7 +7,7 @@
  *          libm exp/log1p, i.e. np.logaddexp's stable form.
  *   *_f32  the SAME operation order in IEEE float32 with a deterministic,
  *          libm-free softplus/exp (only + - * / sqrt and explicit fmaf steps -- include/pworld_math.h
- *          revision 2 --, no implicit FMA contraction), so
+ *          revision 3 --, no implicit FMA contraction), so
  *          the HIP kernels can be compared BIT FOR BIT, integer collision
  *          masks included.
  *

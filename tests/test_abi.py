@@ -77,6 +77,52 @@ def test_handle_geometry_and_errors():
     assert lib.pw_config_default(C.byref(cfg), 7, 16, 6, -1, 0) == -1 and b'scenario' in lib.pw_last_error()
 
 
+def test_dispatch_lives_in_the_handle(monkeypatch):
+    """pw_dispatch (kernel selection): defaults, the one-time overlay of PWORLD_* at pw_create, set / get, range checks --
+    and the launch path of csrc/pworld.hip contains no getenv at all (the only reads are in dispatch_from_environment)."""
+    lib = _lib.load()
+    names = [n for n, _ in _lib.PwDispatch._fields_ if n != 'struct_size']
+    auto = dict(force_generic=0, no_stream=0, duo=-1, quad=-1, obs_block=-1, trio=-1, p_prio=-1, envs_per_wave=0, policy_form=0)
+    d = _lib.PwDispatch()
+    assert lib.pw_dispatch_default(C.byref(d)) == 0 and d.struct_size == C.sizeof(_lib.PwDispatch)
+    assert {n: getattr(d, n) for n in names} == auto
+    for k in [k for k in os.environ if k.startswith('PWORLD_')]:
+        monkeypatch.delenv(k)
+    cfg = _lib.PwConfig()
+    lib.pw_config_default(C.byref(cfg), _lib.PW_SIMPLE_SPREAD, 4096, 6, -1, 0)
+    h, h2 = C.c_void_p(), C.c_void_p()
+    assert lib.pw_create(C.byref(cfg), C.byref(h)) == 0
+    got = _lib.PwDispatch()
+    assert lib.pw_get_dispatch(h, C.byref(got)) == 0 and {n: getattr(got, n) for n in names} == auto
+    monkeypatch.setenv('PWORLD_NO_QUAD', '1')
+    monkeypatch.setenv('PWORLD_OBS_BLOCK', '1')
+    monkeypatch.setenv('PWORLD_POLICY_V1', '1')
+    assert lib.pw_create(C.byref(cfg), C.byref(h2)) == 0          # read once, here
+    monkeypatch.delenv('PWORLD_NO_QUAD')
+    lib.pw_get_dispatch(h2, C.byref(got))
+    assert {n: getattr(got, n) for n in names} == dict(auto, quad=0, obs_block=1, policy_form=1)
+    lib.pw_get_dispatch(h, C.byref(got))
+    assert {n: getattr(got, n) for n in names} == auto          # the older handle is untouched
+    got.duo, got.envs_per_wave = 0, 5
+    assert lib.pw_set_dispatch(h, C.byref(got)) == 0
+    back = _lib.PwDispatch()
+    lib.pw_get_dispatch(h, C.byref(back))
+    assert (back.duo, back.envs_per_wave) == (0, 5)
+    got.trio = 2
+    assert lib.pw_set_dispatch(h, C.byref(got)) == -1 and b'out of range' in lib.pw_last_error()
+    got.trio, got.struct_size = -1, 8
+    assert lib.pw_set_dispatch(h, C.byref(got)) == -1 and b'struct_size' in lib.pw_last_error()
+    lib.pw_destroy(h)
+    lib.pw_destroy(h2)
+    src = open(os.path.join(ROOT, 'multiagent_rl_amd', 'csrc', 'pworld.hip')).read()
+    body = src[src.index('void dispatch_from_environment'):]
+    body = body[:body.index('\n}\n')]
+    assert src.count('getenv') == body.count('getenv') > 0, 'getenv outside dispatch_from_environment'
+    for f in sorted(os.listdir(os.path.join(ROOT, 'multiagent_rl_amd', 'csrc'))):
+        if f != 'pworld.hip':
+            assert 'getenv' not in open(os.path.join(ROOT, 'multiagent_rl_amd', 'csrc', f)).read(), f
+
+
 def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):
     import torch
     from multiagent_rl_amd.env import BatchedParticleEnv

@@ -67,16 +67,39 @@ def test_bench_under_torchrun_env_does_not_relaunch():
 @pytest.mark.timeout(300)
 @pytest.mark.skipif(torch.cuda.device_count() > 0, reason='CPU-container test (stub kernel, gloo)')
 def test_a_dying_peer_in_the_policy_extra_does_not_cost_the_line():
-    """Rank 1 dies inside the full-gather extra; the root would wait for its block for ever.  The watchdog prints the
-    (already measured) headline line without the extra and every process exits 0."""
+    """Rank 1 fails inside the full-gather extra; the root would wait for its block for ever.  The failing rank flags it in
+    the process group's store, the root's watchdog prints the (already measured) headline line with that error within a
+    second -- not after the policy timeout -- and the run exits NON-ZERO: a run that did not finish is not a success."""
     p, lines = _run(['--gpus', '2', '--steps', '4', '--warmup', '1', '--envs', '8', '--agents', '3', '--chunk', '50',
-                     '--batch-size', '8', '--policy-steps', '400', '--policy-chunk', '50', '--policy-timeout', '6',
+                     '--batch-size', '8', '--policy-steps', '400', '--policy-chunk', '50', '--policy-timeout', '60',
                      '--exit-timeout', '4'], extra_env=dict(PW_BENCH_STUB_FAIL_RANK='1'), timeout=200)
-    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.returncode != 0, 'a run with a dead peer must not report success'
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])           # strict JSON: no NaN
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['config']['exchange']['error'] is None
+    err = line['policy_in_loop']['error']
+    assert 'did not finish' in err and 'rank 1' in err and 'injected failure' in err
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.skipif(torch.cuda.device_count() > 0, reason='CPU-container test (stub kernel, gloo)')
+def test_a_hung_policy_extra_times_out_with_the_line_and_a_nonzero_code():
+    """The same, but the store flag never arrives (the peer hangs instead of raising): the watchdog's deadline prints the
+    line and the exit code is non-zero."""
+    p, lines = _run(['--gpus', '2', '--steps', '4', '--warmup', '1', '--envs', '8', '--agents', '3', '--chunk', '50',
+                     '--batch-size', '8', '--policy-steps', '400', '--policy-chunk', '50', '--policy-timeout', '5',
+                     '--exit-timeout', '4'], extra_env=dict(PW_BENCH_STUB_HANG_RANK='1'), timeout=200)
+    assert p.returncode != 0
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
-    assert line['n_gpus'] == 2 and line['value'] > 0 and line['config']['exchange']['error'] is None
-    assert 'did not finish' in line['policy_in_loop']['error']
+    assert line['value'] > 0 and 'did not finish within 5 s' in line['policy_in_loop']['error']
+
+
+def test_profiler_preload_refuses_the_rank_launcher():
+    """bench.py --gpus N from a process a profiler has already GPU-initialised must not exec the launcher."""
+    p, lines = _run(['--gpus', '2', '--steps', '2'], extra_env=dict(LD_PRELOAD='librocprofiler-sdk-tool.so'))
+    assert p.returncode != 0 and not lines
+    assert 'profiler preload' in p.stderr and 'PW_BENCH_FORCE_DIST=1' in p.stderr
 
 
 def test_self_launch_command_line():

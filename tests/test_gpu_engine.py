@@ -396,7 +396,7 @@ def test_one_launch_actor_equals_three_launch_chain(monkeypatch):
 @pytest.mark.parametrize('form', ['default', 'v1', 'v2'])
 @pytest.mark.parametrize('B,N,T', [(16, 6, 3), (4096, 6, 30), (512, 6, 300), (100, 3, 60), (37, 7, 27), (5, 10, 4), (70, 2, 26),
                                    (9, 12, 26), (33, 16, 26), (7, 24, 5), (4, 30, 3)])
-def test_one_launch_policy_rollout_equals_the_step_loop(B, N, T, form, monkeypatch):
+def test_one_launch_policy_rollout_equals_the_step_loop(B, N, T, form):
     """pw_policy_rollout (T x (actor + sampling + env step) in ONE launch, everything resident on the CU) vs the
     loop of FusedActor() + env.step(): sampled actions, observations, rewards, terminals, pre-reset observations
     and the final world state must be IDENTICAL, across auto-resets, ragged batches and N that does not divide 96.
@@ -404,17 +404,12 @@ def test_one_launch_policy_rollout_equals_the_step_loop(B, N, T, form, monkeypat
     long for v1's LDS budget: N = 24, 30) and the default choice between them."""
     from multiagent_rl_amd import make_batched_env
     from multiagent_rl_amd.policy import ActorNetwork, FusedActor
-    monkeypatch.delenv('PWORLD_POLICY_V1', raising=False)
-    monkeypatch.delenv('PWORLD_POLICY_V2', raising=False)
-    if form == 'v1':
-        if N > 16:
-            pytest.skip('the phase-by-phase kernel holds observation rows of D <= 36 (N <= 16)')
-        monkeypatch.setenv('PWORLD_POLICY_V1', '1')
-    elif form == 'v2':
-        monkeypatch.setenv('PWORLD_POLICY_V2', '1')
+    if form == 'v1' and N > 16:
+        pytest.skip('the phase-by-phase kernel holds observation rows of D <= 36 (N <= 16)')
     torch.manual_seed(4)
     mk = lambda: make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=25, seed=21)  # noqa: E731
     env_a, env_b = mk(), mk()
+    env_b.set_dispatch(policy_form=dict(default=0, v1=1, v2=2)[form])   # pw_dispatch: the handle carries the selection
     actor = ActorNetwork(env_a.obs_dim, 5).cuda().eval()
     loop, one = FusedActor(actor, seed=9), FusedActor(actor, seed=9)
     obs = env_a.reset()

@@ -17,7 +17,7 @@ from oracle import c_oracle as co  # noqa: E402  (checker only)
 
 def _mk(scenario='simple_spread', num_envs=64, num_agents=3, num_landmarks=None, num_adversaries=0,
         obs_mode='local', max_episode_len=25, auto_reset=False, seed=12345678, env_id_base=0,
-        force_discrete_action=True, want_coll=True):
+        force_discrete_action=True, want_coll=True, dispatch=None):
     from multiagent_rl_amd.env import BatchedParticleEnv
     kw = dict(num_agents=num_agents, num_landmarks=num_landmarks, local_observation=obs_mode == 'local',
               max_episode_len=max_episode_len, auto_reset=auto_reset, seed=seed, env_id_base=env_id_base,
@@ -25,7 +25,7 @@ def _mk(scenario='simple_spread', num_envs=64, num_agents=3, num_landmarks=None,
     if scenario == 'simple_tag':
         kw.update(num_adversaries=num_adversaries, num_good=num_agents - num_adversaries)
         kw.pop('num_agents')
-    env = BatchedParticleEnv(scenario, num_envs, want_coll=want_coll, **kw)
+    env = BatchedParticleEnv(scenario, num_envs, want_coll=want_coll, dispatch=dispatch, **kw)
     cfg = co.make_config(scenario, num_agents, num_landmarks=num_landmarks, num_adversaries=num_adversaries,
                          obs_mode=obs_mode, max_episode_len=max_episode_len, auto_reset=auto_reset, seed=seed,
                          env_id_base=env_id_base, force_discrete_action=force_discrete_action)
@@ -43,6 +43,10 @@ def _rand_state(rng, B, N, L, crowded=True):
 
 def _np(t):
     return t.detach().cpu().numpy()
+
+
+# pw_dispatch with every choice automatic (what pw_create gives in a clean environment); dict(AUTO, quad=0) etc. override
+AUTO = dict(force_generic=0, no_stream=0, duo=-1, quad=-1, obs_block=-1, trio=-1, p_prio=-1, envs_per_wave=0, policy_form=0)
 
 
 def _coll(t):
@@ -85,63 +89,71 @@ CASES = [
 ]
 
 
-WANT_COLL = {'on': True}
+PATHS = ['duo', 'stream', 'duo+coll', 'stream+coll', 'duo+block', 'stream+block', 'fast', 'generic',
+         'duo-dense', 'stream-dense', 'duo+coll-dense', 'stream+coll-dense', 'duo+block-dense',
+         'stream+block-dense', 'fast-dense', 'generic-dense', 'quad', 'quad+coll', 'trio', 'trio+block', 'trio+block-dense']
 
 
-@pytest.fixture(params=['duo', 'stream', 'duo+coll', 'stream+coll', 'duo+block', 'stream+block', 'fast', 'generic',
-                        'duo-dense', 'stream-dense', 'duo+coll-dense', 'stream+coll-dense', 'duo+block-dense',
-                        'stream+block-dense', 'fast-dense', 'generic-dense', 'quad'])
-def kernel_path(request, monkeypatch):
+class KernelPath(object):
+    """One kernel form, as a pw_dispatch selection (no environment variables: the handle carries it) + whether the
+    optional collision-mask output is requested."""
+
+    def __init__(self, name):
+        self.name = name
+        param = name
+        d = dict(quad=0)                           # every path but 'quad*' keeps the duo / stream kernels' coverage at N = 6
+        if param.endswith('-dense'):
+            d['envs_per_wave'] = 64
+            param = param[:-6]
+        self.want_coll = param not in ('stream', 'duo', 'stream+block', 'duo+block', 'quad', 'trio', 'trio+block')
+        if param.startswith('quad'):
+            d['quad'] = 1
+            param = 'duo'
+        if param.endswith('+coll'):
+            param = param[:-5]
+        if param.endswith('+block'):
+            d['obs_block'] = 1
+            param = param[:-6]
+        if param == 'trio':
+            d['trio'] = 1
+            param = 'duo'
+        if param == 'stream':
+            d['duo'] = 0
+        elif param == 'generic':
+            d['force_generic'] = 1
+        elif param == 'fast':
+            d['no_stream'] = 1
+        self.dispatch = d
+
+
+@pytest.fixture(params=PATHS)
+def kernel_path(request):
     """Four kernels serve simple_spread with homogeneous agents; all must give the same bits.
     'duo'     pw_spread_duo_kernel    (default when all standard outputs are present),
-    'stream'  pw_spread_stream_kernel (PWORLD_NO_DUO),
-    'fast'    pw_spread_fast_kernel   (PWORLD_NO_STREAM),
-    'generic' pw_rollout_kernel       (PWORLD_FORCE_GENERIC, read by pw_create).
+    'stream'  pw_spread_stream_kernel (pw_dispatch.duo = 0),
+    'fast'    pw_spread_fast_kernel   (pw_dispatch.no_stream),
+    'generic' pw_rollout_kernel       (pw_dispatch.force_generic).
     'duo' / 'stream' run WITHOUT the optional collision-mask output (the bench path's instantiations);
-    'duo+coll' / 'stream+coll' are the instantiations that also store the masks (WANT_COLL tells the tests);
-    'quad' (N = L = 6 only; elsewhere it is the default choice again) forces pw_spread_quad_kernel, the four-wave
-    pair-parallel form small grids of BASELINE configs[1] run (PWORLD_FORCE_QUAD; every other path here sets
-    PWORLD_NO_QUAD so that the duo kernel keeps its coverage);
-    'duo+block' / 'stream+block' force the block-wise observation stores large grids use (PWORLD_OBS_BLOCK=1;
-    default here: only N >= 12, the test batches being small), '-dense' then gives 60- and 63-row blocks.
-    simple_tag has three: pw_tag_duo_kernel ('duo'), pw_tag_stream_kernel ('stream') and the generic kernel
+    'duo+coll' / 'stream+coll' are the instantiations that also store the masks;
+    'quad' / 'quad+coll' (N = L = 6 only; elsewhere the default choice again) force pw_spread_quad_kernel, the four-wave
+    pair-parallel form small grids of BASELINE configs[1] run, without / with the mask output (every other path here
+    sets quad = 0 so that the duo kernel keeps its coverage);
+    'duo+block' / 'stream+block' force the block-wise observation stores large grids use (default here: only N >= 12,
+    the test batches being small), '-dense' then gives 60- and 63-row blocks;
+    'trio' / 'trio+block' the three-wave variants of the duo kernels -- what BASELINE configs[2] (simple_tag, B = 8192)
+    and the N = 12 point of configs[4] dispatch by default: simple_tag in both, simple_spread in its block-store form
+    ('trio+block', N >= 6; 'trio' alone is the two-wave form there).
+    simple_tag has three: pw_tag_duo_kernel ('duo', 'trio'), pw_tag_stream_kernel ('stream') and the generic kernel
     ('fast'/'generic').
     Small batches are spread over ~512 workgroups (few envs per wave); '-dense' forces the packing large batches
-    get (64 // N envs per wave, PWORLD_EPW) so that the multi-env-per-wave indexing is exercised at test sizes."""
-    param = request.param
-    monkeypatch.delenv('PWORLD_EPW', raising=False)
-    if param.endswith('-dense'):
-        monkeypatch.setenv('PWORLD_EPW', '64')
-        param = param[:-6]
-    monkeypatch.delenv('PWORLD_OBS_BLOCK', raising=False)
-    monkeypatch.delenv('PWORLD_FORCE_QUAD', raising=False)
-    monkeypatch.setenv('PWORLD_NO_QUAD', '1')
-    WANT_COLL['on'] = param not in ('stream', 'duo', 'stream+block', 'duo+block', 'quad')
-    if param == 'quad':
-        monkeypatch.delenv('PWORLD_NO_QUAD')
-        monkeypatch.setenv('PWORLD_FORCE_QUAD', '1')
-        param = 'duo'
-    if param.endswith('+coll'):
-        param = param[:-5]
-    if param.endswith('+block'):
-        monkeypatch.setenv('PWORLD_OBS_BLOCK', '1')
-        param = param[:-6]
-    monkeypatch.delenv('PWORLD_FORCE_GENERIC', raising=False)
-    monkeypatch.delenv('PWORLD_NO_STREAM', raising=False)
-    monkeypatch.delenv('PWORLD_NO_DUO', raising=False)
-    if param == 'stream':
-        monkeypatch.setenv('PWORLD_NO_DUO', '1')
-    if param == 'generic':
-        monkeypatch.setenv('PWORLD_FORCE_GENERIC', '1')
-    elif param == 'fast':
-        monkeypatch.setenv('PWORLD_NO_STREAM', '1')
-    return param
+    get (64 // N envs per wave) so that the multi-env-per-wave indexing is exercised at test sizes."""
+    return KernelPath(request.param)
 
 
 @pytest.mark.parametrize('case', CASES, ids=lambda c: '%s-N%d-L%s-B%d-%s' % (
     c['scenario'], c['num_agents'], c.get('num_landmarks'), c['num_envs'], c.get('obs_mode', 'local')))
 def test_single_step_from_injected_states(case, kernel_path):
-    env, cfg = _mk(max_episode_len=0, want_coll=WANT_COLL['on'], **case)
+    env, cfg = _mk(max_episode_len=0, want_coll=kernel_path.want_coll, dispatch=kernel_path.dispatch, **case)
     B, N, L = env.num_envs, env.n, env.num_landmarks
     rng = np.random.RandomState(B * 131 + N)
     pos, vel, lm = _rand_state(rng, B, N, L)
@@ -193,11 +205,15 @@ def test_single_step_from_injected_states(case, kernel_path):
     dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=123),
     dict(scenario='simple_tag', num_agents=4, num_adversaries=3, num_envs=77),
     dict(scenario='simple_tag', num_agents=7, num_adversaries=3, num_landmarks=1, num_envs=50),
-], ids=['spread6', 'spread3full', 'tag4+2', 'tag3+1', 'tag3+4'])
+    dict(scenario='simple_spread', num_agents=3, num_envs=257),      # the C5 points: the duo kernel's 3-slot ring hand-off,
+    dict(scenario='simple_spread', num_agents=12, num_envs=333),     # the Philox auto-reset and the block-store path of
+    dict(scenario='simple_spread', num_agents=24, num_envs=300),     # every compile-time instantiation across two resets
+    dict(scenario='simple_spread', num_agents=48, num_envs=130),
+], ids=['spread6', 'spread3full', 'tag4+2', 'tag3+1', 'tag3+4', 'spread3', 'spread12', 'spread24', 'spread48'])
 def test_rollout_with_auto_reset_matches_oracle_bitwise(case, kernel_path):
     T, ep_len = 58, 25
     env, cfg = _mk(max_episode_len=ep_len, auto_reset=True, seed=99, env_id_base=1 << 33,
-                   want_coll=WANT_COLL['on'], **case)
+                   want_coll=kernel_path.want_coll, dispatch=kernel_path.dispatch, **case)
     B, N = env.num_envs, env.n
     rng = np.random.RandomState(5)
     acts = rng.randint(0, 5, (T, B, N)).astype(np.int32)
@@ -251,7 +267,7 @@ def test_rollout_equals_repeated_steps_and_onehot_equals_index():
 
 def test_soft_actions_without_force_discrete(kernel_path):
     env, cfg = _mk(num_agents=3, num_envs=50, max_episode_len=0, force_discrete_action=False,
-                   want_coll=WANT_COLL['on'])
+                   want_coll=kernel_path.want_coll, dispatch=kernel_path.dispatch)
     rng = np.random.RandomState(2)
     pos, vel, lm = _rand_state(rng, 50, 3, 3)
     soft = rng.uniform(0, 1, (50, 3, 5)).astype(np.float32)
@@ -285,7 +301,7 @@ def test_masked_reset_and_shard_invariance():
 
 
 def test_coincident_agents_propagate_nan_like_upstream(kernel_path):
-    env, cfg = _mk(num_agents=3, num_envs=2, max_episode_len=0, want_coll=WANT_COLL['on'])
+    env, cfg = _mk(num_agents=3, num_envs=2, max_episode_len=0, want_coll=kernel_path.want_coll, dispatch=kernel_path.dispatch)
     pos = np.array([[[0.1, 0.1], [0.1, 0.1], [0.7, 0.7]], [[0, 0], [0.5, 0.5], [-0.5, 0.5]]], np.float32)
     lm = np.zeros((2, 3, 2), np.float32)
     env.set_state(pos, None, lm)
@@ -329,19 +345,16 @@ def test_full_size_properties_c2():
     assert not _np(out['done']).any()
 
 
-def test_long_rollout_duo_equals_stream_bitwise(monkeypatch):
-    """Soak: 1500 steps (60 episodes with auto-reset) at C2 size through the two-wave duo kernel and the
-    single-wave stream kernel give identical outputs and final state -- the LDS ring / barrier hand-off of
-    the duo kernel never drops or reorders a step.  The stream kernel itself is checked against the oracle
-    on the first and last 30 steps."""
+def test_long_rollout_quad_and_duo_equal_stream_bitwise():
+    """Soak: 1500 steps (60 episodes with auto-reset) at C2 size through the four-wave quad kernel (the default there),
+    the two-wave duo kernel and the single-wave stream kernel give identical outputs and final state -- the LDS ring /
+    barrier hand-offs never drop or reorder a step.  The common result is anchored on the oracle over the first 30 steps."""
     T, B, N = 1500, 4096, 6
     acts = torch.randint(0, 5, (T, B, N), dtype=torch.int32, generator=torch.Generator().manual_seed(9)).cuda()
     outs = {}
-    for path in ('duo', 'stream'):
-        monkeypatch.delenv('PWORLD_NO_DUO', raising=False)
-        if path == 'stream':
-            monkeypatch.setenv('PWORLD_NO_DUO', '1')
-        env, cfg = _mk(num_agents=N, num_envs=B, max_episode_len=25, auto_reset=True, seed=5, want_coll=False)
+    want_kernel = dict(quad='pw_spread_quad_kernel', duo='pw_spread_duo_kernel', stream='pw_spread_stream_kernel')
+    for path, disp in (('quad', dict(AUTO)), ('duo', dict(AUTO, quad=0)), ('stream', dict(AUTO, duo=0))):
+        env, cfg = _mk(num_agents=N, num_envs=B, max_episode_len=25, auto_reset=True, seed=5, want_coll=False, dispatch=disp)
         env.reset()
         chunks = []
         for s0 in range(0, T, 300):                       # 5 launches of 300 steps
@@ -349,13 +362,16 @@ def test_long_rollout_duo_equals_stream_bitwise(monkeypatch):
             chunks.append((o['obs'].sum(dim=(2, 3)).double().sum(1), o['rew'].double().sum(dim=(1, 2)),
                            o['rew_shared'].double().sum(1), o['terminal'].sum(1), o['obs'][-1].clone(),
                            o['final_obs'][24].clone(), o['obs'][:30].clone() if s0 == 0 else None))
+        assert env.last_kernel().startswith(want_kernel[path]), env.last_kernel()
         outs[path] = (chunks, env.get_state())
-    (ca, sa), (cb, sb) = outs['duo'], outs['stream']
-    for x, y in zip(ca, cb):
-        for u, v in zip(x[:6], y[:6]):
-            assert torch.equal(u, v)
-    for k in ('pos', 'vel', 'landmarks', 'ep_step', 'ep_count'):
-        assert torch.equal(sa[k], sb[k])
+    (ca, sa) = outs['stream']
+    for other in ('quad', 'duo'):
+        cb, sb = outs[other]
+        for x, y in zip(ca, cb):
+            for u, v in zip(x[:6], y[:6]):
+                assert torch.equal(u, v), other
+        for k in ('pos', 'vel', 'landmarks', 'ep_step', 'ep_count'):
+            assert torch.equal(sa[k], sb[k]), (other, k)
     assert int(sa['ep_count'][0]) == 1 + T // 25
     # anchor the common result on the oracle: first 30 steps
     o32 = co.COracle(cfg, B, np.float32)
@@ -456,37 +472,89 @@ def test_scaling_free_division_chain_is_ieee_division_bitwise():
     _assert_same_bits(dev(8, xs), co.math_v(1, xs), 'softplus_fastdiv vs CPU contract')
 
 
-@pytest.mark.parametrize('case', [
-    dict(scenario='simple_spread', num_agents=6, num_envs=4096),                      # C2: pw_spread_duo_kernel<6,6,true,COLL>
-    dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192),      # C3: pw_tag_duo_kernel<6,4,2,true,COLL>
-], ids=['C2', 'C3'])
-def test_bench_path_collision_masks_full_size_bitwise(case, monkeypatch):
-    """The headline kernels (two-wave duo form) with the optional collision-mask output, at BASELINE's full sizes,
-    over 27 steps across an auto-reset: integer masks bit-exact against the float32 oracle at every step, and every
-    other output identical to the run WITHOUT the mask output (the bench's own instantiation)."""
-    for k in ('PWORLD_EPW', 'PWORLD_FORCE_GENERIC', 'PWORLD_NO_STREAM', 'PWORLD_NO_DUO'):
-        monkeypatch.delenv(k, raising=False)
+@pytest.mark.parametrize('case, disp, kernel, kernel_coll', [
+    (dict(scenario='simple_spread', num_agents=6, num_envs=4096), {},                  # C2 as the bench runs it
+     'pw_spread_quad_kernel<true>', 'pw_spread_quad_kernel<true,true>'),
+    (dict(scenario='simple_spread', num_agents=6, num_envs=4096), dict(quad=0),          # C2, two-wave form
+     'pw_spread_duo_kernel<6,6,true>', 'pw_spread_duo_kernel<6,6,true,true>'),
+    (dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192), {},  # C3 as the bench runs it: three waves
+     'pw_tag_duo_kernel<6,4,2,true,false,true>', 'pw_tag_duo_kernel<6,4,2,true,true,true>'),
+    (dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192), dict(trio=0),
+     'pw_tag_duo_kernel<6,4,2,true,false>', 'pw_tag_duo_kernel<6,4,2,true,true>'),
+], ids=['C2', 'C2-duo', 'C3', 'C3-duo'])
+def test_bench_path_full_size_every_output_bitwise(case, disp, kernel, kernel_coll):
+    """The headline kernels under the DEFAULT dispatch at BASELINE's full sizes, over 27 steps across an auto-reset,
+    without and with the optional collision-mask output: EVERY output of both instantiations (observations, rewards,
+    shared rewards, terminal / done flags, pre-reset observations, collision masks, final world state) equals the
+    float32 oracle bit for bit at every step -- and the dispatcher reports the kernels the bench names."""
     T = 27
-    env, cfg = _mk(max_episode_len=25, auto_reset=True, seed=77, want_coll=True, **case)
-    plain, _ = _mk(max_episode_len=25, auto_reset=True, seed=77, want_coll=False, **case)
+    plain, cfg = _mk(max_episode_len=25, auto_reset=True, seed=77, want_coll=False, dispatch=dict(AUTO, **disp), **case)
+    env, _ = _mk(max_episode_len=25, auto_reset=True, seed=77, want_coll=True, dispatch=dict(AUTO, **disp), **case)
     B, N = env.num_envs, env.n
     acts = np.random.RandomState(3).randint(0, 5, (T, B, N)).astype(np.int32)
-    env.reset()
-    plain.reset()
+    o32 = co.COracle(cfg, B, np.float32)
+    want0 = o32.reset()
+    _assert_same_bits(_np(env.reset()), want0, 'reset obs (coll form)')
+    _assert_same_bits(_np(plain.reset()), want0, 'reset obs')
     out = env.rollout(torch.from_numpy(acts))
     ref = plain.rollout(torch.from_numpy(acts))
+    assert plain.last_kernel() == kernel and env.last_kernel() == kernel_coll, (plain.last_kernel(), env.last_kernel())
     assert 'coll' in out and 'coll' not in ref
-    for k in ('obs', 'rew', 'rew_shared', 'terminal', 'done'):
-        assert torch.equal(out[k], ref[k]), k
-    assert torch.equal(out['final_obs'][24], ref['final_obs'][24])
-    o32 = co.COracle(cfg, B, np.float32)
-    o32.reset()
     hits = 0
     for t in range(T):
         w = o32.step(act_idx=acts[t])
+        for name, o in (('plain', ref), ('coll', out)):
+            _assert_same_bits(_np(o['obs'][t]), w['obs'], '%s obs[%d]' % (name, t))
+            _assert_same_bits(_np(o['rew'][t]), w['rew'], '%s rew[%d]' % (name, t))
+            _assert_same_bits(_np(o['rew_shared'][t]), w['rew_shared'], '%s rew_shared[%d]' % (name, t))
+            _assert_same_bits(_np(o['terminal'][t]).astype(np.uint8), w['terminal'], '%s terminal[%d]' % (name, t))
+            _assert_same_bits(_np(o['done'][t]).astype(np.uint8), w['done'], '%s done[%d]' % (name, t))
+            if w['terminal'].any():
+                _assert_same_bits(_np(o['final_obs'][t]), w['final_obs'], '%s final_obs[%d]' % (name, t))
         _assert_same_bits(_coll(out['coll'][t]), w['coll'], 'coll[%d]' % t)
         hits += int((w['coll'] != (np.uint64(1) << np.arange(N, dtype=np.uint64))[None, :]).sum())
     assert hits > 100        # real collisions were seen, not only the self bits
+    for e in (env, plain):
+        st = e.get_state()
+        _assert_same_bits(_np(st['pos']), o32.pos, 'pos')
+        _assert_same_bits(_np(st['vel']), o32.vel, 'vel')
+        _assert_same_bits(_np(st['landmarks']), o32.lm, 'landmarks')
+        assert np.array_equal(_np(st['ep_step']), o32.ep_step)
+
+
+@pytest.mark.parametrize('case, kernel', [
+    (dict(scenario='simple_spread', num_agents=3, num_envs=4096), 'pw_spread_duo_kernel<3,3,true>'),
+    (dict(scenario='simple_spread', num_agents=12, num_envs=4096), 'pw_spread_duo_kernel<12,12,true,false,true,true>'),  # three waves
+    (dict(scenario='simple_spread', num_agents=24, num_envs=4096), 'pw_spread_duo_kernel<24,24,true,false,true>'),
+    (dict(scenario='simple_spread', num_agents=48, num_envs=4096), 'pw_spread_duo_kernel<48,48,true,false,true>'),
+    (dict(scenario='simple_spread', num_agents=6, num_envs=16384), 'pw_spread_duo_kernel<6,6,true,false,true>'),
+], ids=['N3', 'N12', 'N24', 'N48', 'B16384'])
+def test_c5_points_default_dispatch_rollout_across_two_resets_bitwise(case, kernel):
+    """BASELINE configs[4] at full size under the DEFAULT dispatch (what bench.py's sweep times): 52 steps across two
+    auto-resets, every output and the final state bit-identical to the float32 oracle."""
+    T = 52
+    env, cfg = _mk(max_episode_len=25, auto_reset=True, seed=31, want_coll=False, dispatch=dict(AUTO), **case)
+    B, N = env.num_envs, env.n
+    acts = np.random.RandomState(N).randint(0, 5, (T, B, N)).astype(np.int32)
+    o32 = co.COracle(cfg, B, np.float32)
+    _assert_same_bits(_np(env.reset()), o32.reset(), 'reset obs')
+    out = env.rollout(torch.from_numpy(acts))
+    assert env.last_kernel() == kernel, env.last_kernel()
+    resets = 0
+    for t in range(T):
+        w = o32.step(act_idx=acts[t])
+        _assert_same_bits(_np(out['obs'][t]), w['obs'], 'obs[%d]' % t)
+        _assert_same_bits(_np(out['rew'][t]), w['rew'], 'rew[%d]' % t)
+        _assert_same_bits(_np(out['rew_shared'][t]), w['rew_shared'], 'rew_shared[%d]' % t)
+        _assert_same_bits(_np(out['terminal'][t]).astype(np.uint8), w['terminal'], 'terminal[%d]' % t)
+        if w['terminal'].any():
+            resets += 1
+            _assert_same_bits(_np(out['final_obs'][t]), w['final_obs'], 'final_obs[%d]' % t)
+    assert resets == 2
+    st = env.get_state()
+    _assert_same_bits(_np(st['pos']), o32.pos, 'pos')
+    _assert_same_bits(_np(st['vel']), o32.vel, 'vel')
+    _assert_same_bits(_np(st['landmarks']), o32.lm, 'landmarks')
 
 
 def test_c4_partition_full_size_equals_the_unsharded_batch():
@@ -518,7 +586,7 @@ def test_c4_partition_full_size_equals_the_unsharded_batch():
 
 
 @pytest.mark.parametrize('B,ep_len', [(4096, 25), (77, 3), (9, 1), (1000, 2)])
-def test_quad_kernel_equals_duo_with_desynchronised_episode_clocks(B, ep_len, monkeypatch):
+def test_quad_kernel_equals_duo_with_desynchronised_episode_clocks(B, ep_len):
     """pw_spread_quad_kernel keeps ONE ring-slot sequence per workgroup: a step in which any of its 8 envs resets makes
     every env publish two slots.  Envs whose episode clocks are out of step (masked resets, restored checkpoints)
     therefore reset in different -- also consecutive -- steps of one workgroup; episodes of 1, 2 and 3 steps stress the
@@ -527,10 +595,8 @@ def test_quad_kernel_equals_duo_with_desynchronised_episode_clocks(B, ep_len, mo
     acts = torch.randint(0, 5, (T, B, N), dtype=torch.int32, generator=torch.Generator().manual_seed(B)).cuda()
     res = {}
     for form in ('duo', 'quad'):
-        monkeypatch.delenv('PWORLD_NO_QUAD', raising=False)
-        monkeypatch.delenv('PWORLD_FORCE_QUAD', raising=False)
-        monkeypatch.setenv('PWORLD_NO_QUAD' if form == 'duo' else 'PWORLD_FORCE_QUAD', '1')
-        env, cfg = _mk(num_agents=N, num_envs=B, max_episode_len=ep_len, auto_reset=True, seed=41, want_coll=False)
+        env, cfg = _mk(num_agents=N, num_envs=B, max_episode_len=ep_len, auto_reset=True, seed=41, want_coll=False,
+                       dispatch=dict(AUTO, quad=0 if form == 'duo' else 1))
         env.reset()
         st = env.get_state()
         env.set_state(st['pos'], st['vel'], st['landmarks'],
@@ -555,15 +621,42 @@ def test_quad_kernel_equals_duo_with_desynchronised_episode_clocks(B, ep_len, mo
     (dict(scenario='simple_spread', num_agents=48, num_envs=4096), 'pw_spread_duo_kernel<48,48,true,false,true>'),
     (dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192), 'pw_tag_duo_kernel<6,4,2,true,false,true>'),   # three-wave form
 ], ids=['C2', 'B16384', 'N3', 'N48', 'C3'])
-def test_dispatcher_reports_the_kernel_it_launched(case, want, monkeypatch):
+def test_dispatcher_reports_the_kernel_it_launched(case, want):
     """pw_rollout_kernel(): bench.py and the profile tools name the dominant kernel from the dispatcher's own record, so the
     record has to be right -- the BASELINE configurations land on the kernels DESIGN.md says they do."""
-    for k in ('PWORLD_EPW', 'PWORLD_FORCE_GENERIC', 'PWORLD_NO_STREAM', 'PWORLD_NO_DUO', 'PWORLD_NO_QUAD', 'PWORLD_FORCE_QUAD',
-              'PWORLD_OBS_BLOCK', 'PWORLD_FORCE_DUO'):
-        monkeypatch.delenv(k, raising=False)
-    env, _ = _mk(max_episode_len=25, auto_reset=True, seed=5, want_coll=False, **case)
+    env, _ = _mk(max_episode_len=25, auto_reset=True, seed=5, want_coll=False, dispatch=dict(AUTO), **case)
     assert env.last_kernel() == ''            # nothing launched yet on this handle
     env.reset()
     acts = torch.randint(0, 5, (3, env.num_envs, env.n), dtype=torch.int32)
     env.rollout(acts)
     assert env.last_kernel().startswith(want), env.last_kernel()
+
+
+def test_dispatch_is_frozen_in_the_handle_not_read_from_the_environment_at_launch(monkeypatch):
+    """pw_create reads the PWORLD_* overrides ONCE; a later change of the process environment does not reach a live handle
+    (pw_step / pw_rollout never call getenv), pw_set_dispatch does, and a bad selection is refused."""
+    from multiagent_rl_amd import _lib
+    for k in ('PWORLD_EPW', 'PWORLD_FORCE_GENERIC', 'PWORLD_NO_STREAM', 'PWORLD_NO_DUO', 'PWORLD_NO_QUAD', 'PWORLD_FORCE_QUAD',
+              'PWORLD_OBS_BLOCK', 'PWORLD_FORCE_DUO', 'PWORLD_SPREAD_TRIO', 'PWORLD_TAG_TRIO', 'PWORLD_P_PRIO'):
+        monkeypatch.delenv(k, raising=False)
+    clean, _ = _mk(num_agents=6, num_envs=512, max_episode_len=25, auto_reset=True, want_coll=False)
+    assert clean.get_dispatch() == AUTO
+    monkeypatch.setenv('PWORLD_NO_DUO', '1')
+    monkeypatch.setenv('PWORLD_EPW', '64')
+    frozen, _ = _mk(num_agents=6, num_envs=512, max_episode_len=25, auto_reset=True, want_coll=False)
+    assert frozen.get_dispatch() == dict(AUTO, duo=0, envs_per_wave=64)
+    monkeypatch.delenv('PWORLD_NO_DUO')
+    monkeypatch.delenv('PWORLD_EPW')
+    acts = torch.randint(0, 5, (3, 512, 6), dtype=torch.int32)
+    for e in (clean, frozen):
+        e.reset()
+    a, b = clean.rollout(acts), frozen.rollout(acts)
+    assert clean.last_kernel().startswith('pw_spread_quad_kernel') and frozen.last_kernel().startswith('pw_spread_stream_kernel')
+    assert all(torch.equal(a[k], b[k]) for k in ('obs', 'rew', 'rew_shared', 'terminal'))
+    frozen.set_dispatch(duo=-1, envs_per_wave=0)
+    frozen.rollout(acts)
+    assert frozen.last_kernel().startswith('pw_spread_quad_kernel')
+    with pytest.raises(_lib.PworldError):
+        frozen.set_dispatch(duo=7)
+    with pytest.raises(TypeError):
+        frozen.set_dispatch(no_such_field=1)
