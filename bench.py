@@ -326,7 +326,7 @@ def main():
         shard = Gather(env, args.batch_size, rank, world, dev, every=1,
                        **({} if STUB else dict(side_stream=not os.environ.get('PW_BENCH_NO_SIDE_STREAM'))))
 
-    def run(n_launches, first, events=None):
+    def run(n_launches, first, events=None, exchange=True):
         # ONE HIP-event pair brackets all launches of the timed region on the launch stream (a pair per launch
         # would put two extra packets between dependent kernels and slow what it measures)
         if events is not None:
@@ -334,14 +334,14 @@ def main():
         for i in range(n_launches):
             launch, view, a = slots[(first + i) % RING]
             launch()
-            if shard is not None and exchange_state['error'] is None:
+            if exchange and shard is not None and exchange_state['error'] is None:
                 try:
                     shard(view, a)
                 except Exception as e:  # keep the sharded rollout measurable; the JSON line reports this
                     exchange_state['error'] = repr(e)[:200]
         if events is not None:
             events[1].record()
-        if shard is not None and exchange_state['error'] is None:
+        if exchange and shard is not None and exchange_state['error'] is None:
             try:
                 shard.finish()
             except Exception as e:
@@ -388,6 +388,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N > 1: what the sampled exchange costs the headline -- the same K launches once more WITHOUT it (same bracket);
+    # reported beside `value` in multi_gpu.sampled_exchange, never instead of it
+    elapsed_plain = None
+    if use_dist:
+        sync()
+        dist.barrier()
+        sync()
+        t1 = time.perf_counter()
+        run(K, W + K, None, exchange=False)
+        sync()
+        dist.barrier()
+        sync()
+        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_plain = float(t.item())
+
     # dominant kernel; HIP events on the launch stream.  Average launch duration = event-bracketed time of the K
     # launches / K (includes the inter-launch gaps, so it is an upper bound of the kernel's own duration; the
     # committed rocprofv3 kernel trace gives that one and must agree)
@@ -409,8 +425,9 @@ def main():
     # the last timed launch went to slot (W + K - 1) % RING; an env terminates at its 25th, 50th, ... step, and the
     # W + K launches ran T steps each from a fresh reset: step index s of that launch is global step
     # (W + K - 1) * T + s
-    last_view = slots[(W + K - 1) % RING][1]
-    s_term = (-((W + K - 1) * T + 1)) % 25
+    n_done = W + K + (K if use_dist else 0)   # launches since the reset (the exchange-free repeat included)
+    last_view = slots[(n_done - 1) % RING][1]
+    s_term = (-((n_done - 1) * T + 1)) % 25
     finite = bool(torch.isfinite(last_view['obs']).all().item())
     if s_term < T and not STUB:
         finite = finite and bool(last_view['terminal'][s_term].all().item())
@@ -542,6 +559,24 @@ def main():
     if rank == 0:
         line = line_holder['line']
         line['policy_in_loop'] = policy_line
+        if use_dist:
+            # what matters at N > 1, at the top level of the line: the FULL gather's per-link rate and completeness
+            # (north_star's collective, measured in the policy-in-the-loop extra) and the cost of the sampled exchange
+            g = policy_line.get('gather') if isinstance(policy_line, dict) else None
+            line['multi_gpu'] = dict(
+                full_gather=None if not g else dict(
+                    GBps_per_link=g['GBps_per_link'], GBps_root_ingest=g['GBps_root_ingest'], peers=world - 1,
+                    bytes_per_env_step=g['bytes_per_env_step'], transitions_ingested_root=g['transitions_ingested_root'],
+                    expected_transitions=g['expected_transitions'], complete=g['transitions_ingested_root'] == g['expected_transitions'],
+                    root_receive_bytes=2 * (world - 1) * g['bytes_per_chunk_per_rank'],
+                    env_steps_per_s=policy_line.get('value'), error=g['error']),
+                sampled_exchange=dict(value_with_exchange=line['value'],
+                                      value_without_exchange=world * B * T * K / elapsed_plain,
+                                      overhead_frac=1.0 - elapsed_plain / elapsed, launches_timed=K,
+                                      rows_per_exchange=None if shard is None else shard.R * world,
+                                      error=exchange_state['error']),
+                note='value = sharded rollout + sampled exchange (a full gather at this rate would need TB/s per peer: '
+                     'DESIGN.md 6); the full gather is measured with the policy in the loop')
         print(json.dumps(line, allow_nan=False), flush=True)
     if isinstance(policy_line, dict) and policy_line.get('fatal'):
         # the extra raised on THIS rank: its peers are inside collectives it will not join -- leave, loudly, once the root's

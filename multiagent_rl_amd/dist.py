@@ -317,6 +317,11 @@ class FullTransitionGather(object):
     def bytes_per_env_step(self):
         return self.lay.total_bytes / float(self.T * self.B)
 
+    @staticmethod
+    def root_receive_bytes(world, block_bytes):
+        """HBM the learner rank holds for incoming blocks: two slots (double buffer) x one block per peer."""
+        return 2 * (int(world) - 1) * int(block_bytes)
+
     # -- overridable pieces (the CPU gloo test substitutes torch stand-ins for the two HIP launches)
     def _make_memory(self):
         from .replay_buffer import ReplayBuffer

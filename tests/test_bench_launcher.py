@@ -50,6 +50,29 @@ def test_bench_gpus2_self_launch_prints_one_line():
     assert 'cpu_baseline' not in line  # N = 1 only
 
 
+@pytest.mark.timeout(400)
+@pytest.mark.skipif(torch.cuda.device_count() > 0, reason='CPU-container test (stub kernel, gloo)')
+def test_bench_gpus8_c4_shape_self_launch():
+    """BASELINE configs[3]'s rank count (8 x a small B): the sampled exchange of the headline and the 7-receive full gather
+    of the policy extra at the real fan-in, rank-ordered ingest, and the N > 1 line's top-level exchange summary."""
+    p, lines = _run(['--gpus', '8', '--steps', '6', '--warmup', '2', '--envs', '4', '--agents', '3', '--chunk', '50',
+                     '--batch-size', '16', '--policy-steps', '100', '--policy-chunk', '50'], timeout=380)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and line['config']['global_batch'] == 32 and line['config']['parallelism'] == 'env-shard x8'
+    ex = line['config']['exchange']
+    assert ex['error'] is None and ex['exchanges'] == 6 and ex['rows_ingested_root'] == 6 * 16
+    g = line['policy_in_loop']['gather']
+    assert g['error'] is None and g['transitions_ingested_root'] == g['expected_transitions'] == 8 * 4 * 100
+    mg = line['multi_gpu']
+    assert mg['full_gather']['transitions_ingested_root'] == mg['full_gather']['expected_transitions'] == 8 * 4 * 100
+    assert mg['full_gather']['GBps_per_link'] == g['GBps_per_link'] and mg['full_gather']['peers'] == 7
+    assert mg['full_gather']['root_receive_bytes'] == 2 * 7 * g['bytes_per_chunk_per_rank']
+    assert mg['sampled_exchange']['value_without_exchange'] > 0 and mg['sampled_exchange']['launches_timed'] == 6
+    assert abs(mg['sampled_exchange']['value_with_exchange'] - line['value']) < 1e-6 * line['value']
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.skipif(torch.cuda.device_count() > 0, reason='CPU-container test (stub kernel, gloo)')
 def test_bench_under_torchrun_env_does_not_relaunch():

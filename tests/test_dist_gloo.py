@@ -115,7 +115,7 @@ def _run_world(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=60) for _ in range(world)]
+    res = [q.get(timeout=60 + 15 * world) for _ in range(world)]
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
@@ -136,15 +136,16 @@ def world2():
     return _cached_world(2)
 
 
-@pytest.fixture(scope='module', params=[2, 4])
+@pytest.fixture(scope='module', params=[2, 4, 8])
 def worldn(request):
     return _cached_world(request.param)
 
 
 @pytest.mark.timeout(240)
 def test_full_transition_gather_world2(worldn):
-    """Every transition of every rank (2 and 4 ranks), in (exchange, rank, step, env) order, next_obs = the pre-reset
-    row."""
+    """Every transition of every rank (2, 4 and 8 ranks: the 8-rank case is BASELINE configs[3]'s fan-in -- seven
+    receives in one batch_isend_irecv group at the root, rank-ordered ingest), in (exchange, rank, step, env) order,
+    next_obs = the pre-reset row."""
     world, root = worldn
     ingested, ring = root[3], root[4]
     assert ingested == 3 * world * T * B and len(ring) == 3 * world
@@ -195,6 +196,32 @@ def test_sampled_transition_gather_world2(world2):
     # the selection changes from exchange to exchange
     r0 = [s[1:] for s in sels if s[0] == 0]
     assert r0[0] != r0[1] and r0[1] != r0[2]
+
+
+def test_root_receive_memory_at_c4():
+    """BASELINE configs[3] (C4): 8 ranks x B = 4096, N = 6, D = 16, 100-step chunks.  The root's receive side is two slots
+    of seven blocks; the block size comes from libpworld's own layout arithmetic (host code, no GPU): 414 B per env-step."""
+    import ctypes as C
+    from multiagent_rl_amd import _lib
+    from multiagent_rl_amd.dist import FullTransitionGather
+    lay = _lib.PwChunkWire()
+    assert _lib.load().pw_chunk_wire_layout(100, 4096, 6, 16, 25, C.byref(lay)) == 0
+    assert lay.F == 4 and lay.total_bytes % 256 == 0
+    per_env_step = lay.total_bytes / (100 * 4096.0)
+    assert 413.0 < per_env_step < 416.0                       # 395 B + (1 + F) / T observation batches (DESIGN.md 6)
+    got = FullTransitionGather.root_receive_bytes(8, lay.total_bytes)
+    assert got == 2 * 7 * lay.total_bytes and 2.3e9 < got < 2.5e9       # ~2.4 GB of the root's 288 GB
+    # the constructor allocates exactly that (checked on the CPU stand-in at a small shape, every rank count)
+    class E(object):
+        num_envs, n, obs_dim, max_episode_len = 8, 3, 10, 3
+    for world in (2, 8):
+        g = CpuFullGather.__new__(CpuFullGather)
+        g.rank, g.world, g.device, g.group = 0, world, torch.device('cpu'), None
+        g.B, g.N, g.D, g.T, g.max_episode_len = 8, 3, 10, 5, 3
+        small = g._layout(_lib.PwChunkWire)
+        full = CpuFullGather(E(), 5, 0, world, 'cpu')
+        held = sum(b.numel() for slot in full.recv for b in slot if b is not None)
+        assert held == FullTransitionGather.root_receive_bytes(world, small.total_bytes)
 
 
 def test_shard_env_ids():
