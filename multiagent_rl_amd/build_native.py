@@ -5,26 +5,50 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = os.path.join(HERE, 'csrc', 'pworld.hip')
+SRCS = [os.path.join(HERE, 'csrc', 'pworld.hip'), os.path.join(HERE, 'csrc', 'pworld_policy.hip')]
 OUT = os.path.join(HERE, 'libpworld.so')
-DEPS = [os.path.join(HERE, 'csrc', f) for f in sorted(os.listdir(os.path.join(HERE, 'csrc')))] + \
+OBJ_DIR = os.path.join(HERE, 'csrc', '_obj')  # git-ignored (*.o); objects are kept so that one unit rebuilds alone
+DEPS = [os.path.join(HERE, 'csrc', f) for f in sorted(os.listdir(os.path.join(HERE, 'csrc'))) if f.endswith(('.hip', '.hpp'))] + \
        [os.path.join(ROOT, 'include', 'pworld.h'), os.path.join(ROOT, 'include', 'pworld_math.h')]
 
 # -ffp-contract=off + correctly rounded div/sqrt: the kernels must reproduce the float32
 # oracle bit for bit (HIP's device default is fp-contract=fast).
-FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared',
+FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC',
          '-ffp-contract=off', '-fno-fast-math', '-fhip-fp32-correctly-rounded-divide-sqrt',
          '-Wall', '-Wno-unused-function', '-Wno-cuda-compat', '-Wno-pass-failed', '-I', os.path.join(ROOT, 'include')]
+
+
+def _unit_deps(src):
+    """pworld.hip does not include the policy headers: an actor experiment leaves the env unit alone and vice versa."""
+    env_only = os.path.basename(src) == 'pworld.hip'
+    return [d for d in DEPS if not (env_only and 'policy' in os.path.basename(d))
+            and not (not env_only and os.path.basename(d) in ('pworld.hip', 'pw_kernels_spread_quad.hpp', 'pw_kernels_generic.hpp',
+                                                             'pw_kernels_reference.hpp', 'pw_kernels_replay.hpp'))]
 
 
 def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in DEPS):
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + [f for f in FLAGS if f] + ['-o', OUT, SRC]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    procs = []
+    objs = []
+    for src in SRCS:  # the two units compile in parallel
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + '.o')
+        objs.append(obj)
+        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _unit_deps(src)):
+            continue
+        cmd = [hipcc] + FLAGS + ['-c', '-o', obj, src]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
     if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
+        print(' '.join(link))
+    subprocess.check_call(link)
     return OUT
 
 

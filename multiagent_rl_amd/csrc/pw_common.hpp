@@ -2,13 +2,15 @@
 // Error plumbing, kernel parameter blocks, lane mapping, the shared device functions (collision force, observation, reward/masks, reset).
 #pragma once
 
-namespace {
+// libpworld.so is two translation units (pworld.hip: environment, replay ring, wire blocks; pworld_policy.hip: actor and
+// policy-in-the-loop rollouts).  The thread-local error text lives in pworld.hip; both reach it through this hook.
+extern "C" __attribute__((visibility("hidden"))) void pw_internal_set_error(const char *msg);
 
-thread_local std::string g_last_error;
+namespace {
 
 int fail(int code, const std::string &msg)
 {
-    g_last_error = msg;
+    pw_internal_set_error(msg.c_str());
     return code;
 }
 

@@ -1,0 +1,46 @@
+// pw_handle.hpp -- part of libpworld.so: the handle and the host-side helpers both translation units use.
+#pragma once
+
+struct pw_handle {
+    pw_config cfg;
+    KParams kp;
+    pw_state_layout layout;
+    bool bound;
+    bool fast;      // pw_spread_fast_kernel applies
+    FastConsts fc;
+    bool tag_fast;  // pw_tag_stream_kernel applies
+    TagParams tp;   // its constant part (pointers are filled per launch)
+    float *comm;    // simple_reference planes inside the bound state block
+    int32_t *goal;
+    const char *last_kernel;  // name of the kernel the last pw_step / pw_rollout launched (pw_rollout_kernel)
+    pw_dispatch disp;         // kernel selection: fixed by pw_create / pw_set_dispatch, never read from the environment at launch
+};
+
+namespace {
+
+int check_ready(const pw_handle *h)
+{
+    if (!h) return fail(PW_EINVAL, "null handle");
+    if (!h->bound) return fail(PW_ESTATE, "state block not bound: call pw_bind_state first");
+    return PW_OK;
+}
+
+// Kernels that ask for more than 64 KB of dynamic LDS need the opt-in once per (kernel, DEVICE): a process driving
+// several GPUs must not skip it on the second one.
+bool lds_optin_needed(unsigned long long *done_mask)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;  // unknown: set it every time (cheap)
+    if (*done_mask >> dev & 1ull) return false;
+    *done_mask |= 1ull << dev;
+    return true;
+}
+
+// The chunk / tail / packed / wire entry points and the rollout sink write the plain ring layout only.
+int plain_ring_only(const pw_replay_store *st, const char *who)
+{
+    if (st && (st->act_heads > 1 || st->per_agent))
+        return fail(PW_EINVAL, std::string(who) + ": two-head / per-agent rings are served by pw_replay_add and pw_replay_gather only");
+    return PW_OK;
+}
+}  // namespace

@@ -53,11 +53,16 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
     float *s_min = reinterpret_cast<float *>(s_ftab + 2 * EPP * N * N);    // [64] OA
     float *s_rew = s_min + kWave;                                          // [64] OA
     float2 *s_lmB = reinterpret_cast<float2 *>(s_rew + kWave);             // [8 * 6] OB (16-byte aligned)
-    float4 *s_rowB = reinterpret_cast<float4 *>(s_lmB + EPW * L);          // [64] OB: {pos, vel} of every row
+    float4 *s_rowB = reinterpret_cast<float4 *>(s_lmB + EPW * L);          // [64] (unused since round 3: OB reads the ring slot itself)
     int32_t *s_act = reinterpret_cast<int32_t *>(s_rowB + kWave);          // [2 P waves][4 steps][64] action indices
     float2 *s_utab = reinterpret_cast<float2 *>(s_act + 2 * 4 * kWave);    // [2 P waves][8] action force per index
 
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // Roles by wave index, swapped in every other batch of 256 workgroups: the hardware places a workgroup's waves 0..3 on
+    // the CU's SIMDs in order, and with two workgroups per CU (B = 4096: 512 workgroups on 256 CUs, workgroup j and j + 256
+    // on one CU) equal roles would share a SIMD -- the two physics waves, the step's critical path, competing for issue
+    // while two output waves with hundreds of cycles of slack share another.  Swapped, every SIMD holds one physics and one
+    // output wave: -2.2 % step time (A/B, profiles/r3_quad_waves.txt).
+    const int wave = __builtin_amdgcn_readfirstlane((((int)threadIdx.x >> 6) + 2 * (((int)blockIdx.x >> 8) & 1)) & 3);
     const int lane = (int)threadIdx.x & 63;
     const int env0 = (int)blockIdx.x * EPW;
     const int envs_here = A.B - env0 < EPW ? A.B - env0 : EPW;
@@ -87,6 +92,10 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
     };
     int cur = 0;  // ring slot of the current state: workgroup-uniform
 
+    // Measured and NOT kept (round 3, profiles/r3_quad_waves.txt): LDS step counters instead of the per-step s_barrier (the
+    // physics waves polling-free, the output waves polling with s_sleep).  With the output waves shortened the barrier costs
+    // a physics wave little beyond the LDS wait it needs anyway (its next operands), and the counters' own reads and writes
+    // cost more: 0.656 instead of 0.615 us per step.
     if (wave < 2) {
         // ================================ waves P0, P1: pair-parallel physics ================================
         // the physics waves are the step's critical path, the output waves have slack: where one of each shares a SIMD
@@ -158,6 +167,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             act_fetch_wait3();  // step t's indices are in LDS
             PW_STAMP(3);
             const uint32_t ai = (uint32_t)act_ring[(t & 3) * kWave + lane];
+            fetch_act(t + 4);  // into the slot just read (its wait for the read above is the one the table lookup needs anyway)
             const float2 u0 = utab[ai < 5u ? ai : 5u];  // {u_x + 0, u_y + 0}: the accumulators' starting values
             const bool two_slots = t == t_reset;        // workgroup-uniform: some env of the workgroup resets in this step
             // ---- pair phase: every unordered pair of the wave's envs at once
@@ -172,7 +182,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             *f_ji = make_float2(-Fx, -Fy);
             PW_STAMP(0);
             float fx = u0.x, fy = u0.y;
-            fetch_act(t + 4);  // into the slot just read; also the program-order point between table writes and row reads
+            asm volatile("" ::: "memory");  // program-order point between table writes and row reads
             // ---- U5: the agent's row, ascending partner order
 #pragma unroll
             for (int j = 0; j < N - 1; ++j) {
@@ -232,26 +242,36 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
     float olx = A.lm_x[(size_t)env * L + a], oly = A.lm_y[(size_t)env * L + a];  // the landmark this lane owns
 
     if (wave == 2) {
-        // with the physics waves at priority 3 this wave had become the longest of the four (1356 busy cycles against OB's
-        // 1044): it goes first too -- the observation wave fills the slots the other three leave (C2 -2.2 % step time)
-        __builtin_amdgcn_s_setprio(3);
+        // (round 2 ran this wave at priority 3 too, when it was as long as the physics waves; software-pipelined it has
+        // several hundred cycles of slack per step and yields to them)
         // ---------------- OA: masks, rewards, small stores ----------------
-        PW_STAMP_DECL;
-        for (int t = 0; t < T; ++t) {
-            const size_t tBN = (size_t)t * BN;
-            PW_STAMP_START;
-            duo_barrier();
-            PW_STAMP(0);
-            int nxt = (cur + 1) & 3;
+        // A step's work has two halves: A(t) -- read the published slot, the six collision tests, the owned landmark's
+        // minimum over the agents, its sqrt -- and B(t) -- the ordered per-env sums through two rounds of wave shuffles,
+        // the stores.  Each half is a chain of long-latency operations (LDS round trips, shuffles, sqrt) with little to
+        // issue in between, and B(t) needs nothing but A(t)'s three registers: so the loop is software-pipelined, iteration
+        // t running B(t - 1) interleaved with A(t) (the shuffles of one fly while the arithmetic of the other issues).
+        // Same operations on the same values: the bits do not change.
+        float own_p = 0.0f;   // A(t - 1): sqrt of the owned landmark's minimum squared distance
+        int cnt_p = 0;        //           number of agents within the collision threshold (self included)
+        uint32_t cmask_p = 0; //           their mask (COLL)
+        // the pieces, in the order an iteration interleaves them
+        float2 mine, q6[N];
+        auto a_reads = [&](const int nxt) __attribute__((always_inline)) {
             const float4 *slot = s_ring + nxt * kWave + base;
-            const float2 mine = *reinterpret_cast<const float2 *>(slot + a);
+            mine = *reinterpret_cast<const float2 *>(slot + a);
+#pragma unroll
+            for (int j = 0; j < N; ++j) q6[j] = *reinterpret_cast<const float2 *>(slot + j);
+        };
+        float best, e0;
+        int cnt;
+        uint32_t cmask;
+        auto a_dist = [&]() __attribute__((always_inline)) {
             const float px = mine.x, py = mine.y;
-            int cnt = 0;
-            uint32_t cmask = 0;
             float e2[N];
+            cnt = 0; cmask = 0;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                const float2 q = *reinterpret_cast<const float2 *>(slot + j);
+                const float2 q = q6[j];
                 const float dx = q.x - px, dy = q.y - py;
                 const float d2 = dx * dx + dy * dy;
                 cnt += d2 < A.coll_thr2 ? 1 : 0;
@@ -261,25 +281,15 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             }
             // min() keeps its first argument unless a later one is smaller: a NaN in front stays, NaNs behind are
             // skipped -- i.e. the NaN-ignoring minimum of all six unless the first one is NaN (e2 is never -0): a tree
-            float best = __builtin_fminf(__builtin_fminf(__builtin_fminf(e2[0], e2[1]), __builtin_fminf(e2[2], e2[3])),
-                                         __builtin_fminf(e2[4], e2[5]));
-            best = e2[0] != e2[0] ? e2[0] : best;
-            // per-env reductions by wave shuffle (ds_bpermute: one trip each, no LDS write -> wait -> read)
-            const float own = sqrtf(best);  // branch-free expansion: the guarded fast form (a vector compare feeding exec) measured 8 % slower on this chain
-            float r = 0.0f;
-#pragma unroll
-            for (int l = 0; l < L; ++l) r -= __shfl(own, base + l, kWave);
-            // "rew -= 1" once per colliding agent (itself included): the subtrahends are all the same, so only their
-            // number matters; r - 0 is r, so the six steps are selects of the subtrahend, not branches (a loop up to the
-            // wave's largest count was measured: a vector compare feeding a scalar branch per iteration costs more)
-#pragma unroll
-            for (int k2 = 0; k2 < N; ++k2) r -= k2 < cnt ? 1.0f : 0.0f;
-            float acc = 0.0f;
-#pragma unroll
-            for (int i = 0; i < N; ++i) acc += __shfl(r, base + i, kWave);
-            nt_store(A.rew + tBN + g, r);
-            nt_store(A.rew_shared + (size_t)t * A.B + env, acc);   // (done / terminal: wave OB, which has the slack)
-            if (COLL) nt_store(A.coll + tBN + g, (uint64_t)cmask);  // is_collision bits of the state this step produced (pre-reset)
+            best = __builtin_fminf(__builtin_fminf(__builtin_fminf(e2[0], e2[1]), __builtin_fminf(e2[2], e2[3])),
+                                   __builtin_fminf(e2[4], e2[5]));
+            e0 = e2[0];
+        };
+        auto a_sqrt = [&]() __attribute__((always_inline)) -> float {
+            const float b = e0 != e0 ? e0 : best;
+            return sqrtf(b);  // branch-free expansion: the guarded fast form (a vector compare feeding exec) measured 8 % slower on this chain
+        };
+        auto a_clock = [&](const int t, int nxt) __attribute__((always_inline)) {  // episode clocks; the slot A(t + 1) reads
             if (t == t_reset) {  // workgroup-uniform, once per episode
                 if (t + 1 + ep_off >= A.max_episode_len) {
                     ep_count += 1;
@@ -290,8 +300,64 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
                 nxt = (nxt + 1) & 3;
             }
             cur = nxt;
+        };
+        float sh_own[L], sh_r[N], r;
+        auto b_shfl_own = [&]() __attribute__((always_inline)) {  // per-env reductions by wave shuffle (ds_bpermute: one trip each, no LDS write -> wait -> read)
+#pragma unroll
+            for (int l = 0; l < L; ++l) sh_own[l] = __shfl(own_p, base + l, kWave);
+        };
+        auto b_reward = [&]() __attribute__((always_inline)) {
+            r = 0.0f;
+#pragma unroll
+            for (int l = 0; l < L; ++l) r -= sh_own[l];
+            // "rew -= 1" once per colliding agent (itself included): the subtrahends are all the same, so only their
+            // number matters; r - 0 is r, so the six steps are selects of the subtrahend, not branches (a loop up to the
+            // wave's largest count was measured: a vector compare feeding a scalar branch per iteration costs more)
+#pragma unroll
+            for (int k2 = 0; k2 < N; ++k2) r -= k2 < cnt_p ? 1.0f : 0.0f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) sh_r[i] = __shfl(r, base + i, kWave);
+        };
+        auto b_store = [&](const int tb) __attribute__((always_inline)) {
+            const size_t tBN = (size_t)tb * BN;
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc += sh_r[i];
+            nt_store(A.rew + tBN + g, r);
+            nt_store(A.rew_shared + (size_t)tb * A.B + env, acc);   // (done / terminal: wave OB, which has the slack)
+            if (COLL) nt_store(A.coll + tBN + g, (uint64_t)cmask_p);  // is_collision bits of the state step tb produced (pre-reset)
+        };
+        PW_STAMP_DECL;
+        // prologue: A(0)
+        {
+            PW_STAMP_START;
+            duo_barrier();
+            PW_STAMP(0);
+            const int nxt = (cur + 1) & 3;
+            a_reads(nxt);
+            a_dist();
+            own_p = a_sqrt(); cnt_p = cnt; cmask_p = cmask;
+            a_clock(0, nxt);
             PW_STAMP(1);
         }
+        for (int t = 1; t < T; ++t) {  // A(t) interleaved with B(t - 1): no branch but the (rare) reset step's
+            PW_STAMP_START;
+            duo_barrier();
+            PW_STAMP(0);
+            const int nxt = (cur + 1) & 3;
+            a_reads(nxt);
+            b_shfl_own();
+            a_dist();
+            b_reward();
+            const float own = a_sqrt();
+            b_store(t - 1);
+            own_p = own; cnt_p = cnt; cmask_p = cmask;
+            a_clock(t, nxt);
+            PW_STAMP(1);
+        }
+        b_shfl_own();  // epilogue: B(T - 1)
+        b_reward();
+        b_store(T - 1);
 #ifdef PW_STAMPS
         if (blockIdx.x == 0 && lane == 0)
             for (int i_ = 0; i_ < 2; ++i_) g_pw_stamps[4 + i_] = st_acc[i_];
@@ -300,26 +366,49 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
     }
 
     // ---------------- OB: observation rows ----------------
-    // The wave's 48 rows are contiguous in the obs plane: stored as ONE block (stream_write_obs_block: 1 KiB per store
-    // instruction instead of a quarter cache line per lane and instruction) -- at 5e9 env-steps/s the write path matters
-    // at this batch size too.
+    // The wave's 48 rows are contiguous in the obs plane and are stored as ONE block: 192 chunks of 16 bytes, chunk
+    // q = row * 4 + column group, lane l stores chunks l, l + 64, l + 128 -- 1 KiB contiguous per store instruction.
+    // With D = 16 a lane's column group c = l & 3 never changes and its rows are l / 4, + 16, + 32: c = 0 is the row's
+    // {vel, pos}, c >= 1 the landmarks 2c - 2, 2c - 1 relative to the row's agent (stream_write_obs's subtractions, only
+    // the storing lane differs).  The rows' {pos, vel} are read STRAIGHT from the ring slot (its index is the row index),
+    // and a lane's three landmark pairs live in registers for the whole episode (they change in reset steps only): a
+    // step is three 16-byte LDS reads, the subtractions and three stores.
     const int rows_here = envs_here * N;
+    const int cgrp = lane & 3;
+    int row_u[3];
+    bool ok_u[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int r = (lane >> 2) + 16 * u;
+        ok_u[u] = r < rows_here;
+        row_u[u] = ok_u[u] ? r : 0;  // chunks past the block read row 0 (and store nothing)
+    }
+    float4 lm_u[3];
+    auto load_landmarks = [&]() {  // the two landmarks of this lane's column group, per row's env
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            lm_u[u] = *reinterpret_cast<const float4 *>(s_lmB + (row_u[u] / N) * L + (cgrp > 0 ? 2 * cgrp - 2 : 0));
+    };
     s_lmB[me] = make_float2(olx, oly);
     wave_lds_sync();
+    load_landmarks();
+    float4 *const blk4 = reinterpret_cast<float4 *>(A.obs + ((size_t)env0 * N) * D) + lane;
     PW_STAMP_DECL;
     for (int t = 0; t < T; ++t) {
         const size_t tBN = (size_t)t * BN;
         PW_STAMP_START;
+        nt_store(A.done + tBN + g, (uint8_t)0);
         duo_barrier();
         PW_STAMP(0);
         int nxt = (cur + 1) & 3;
-        float4 st = s_ring[nxt * kWave + me];
-        nt_store(A.done + tBN + g, (uint8_t)0);
         nt_store(A.terminal + (size_t)t * A.B + env, (uint8_t)(A.max_episode_len > 0 && t + 1 + ep_off >= A.max_episode_len ? 1 : 0));
         if (t == t_reset) {  // workgroup-uniform, once per episode
             const bool rst = t + 1 + ep_off >= A.max_episode_len;
             if (rst) {
-                if (A.final_obs) stream_write_obs<L>(A.final_obs + (tBN + g) * D, L, s_lmB + base, st.x, st.y, st.z, st.w);
+                if (A.final_obs) {
+                    const float4 st = s_ring[nxt * kWave + me];  // this lane's own (env, agent) row, pre-reset
+                    stream_write_obs<L>(A.final_obs + (tBN + g) * D, L, s_lmB + base, st.x, st.y, st.z, st.w);
+                }
                 ep_count += 1;
                 ep_off = -(t + 1);
                 pw_reset_xy(A.seed, env_id, ep_count, (uint32_t)(N + a), -1.0f, 1.0f, &olx, &oly);
@@ -327,14 +416,20 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             reset_step_update(t);
             wave_lds_sync();     // the pre-reset rows have read the old landmarks
             if (rst) s_lmB[me] = make_float2(olx, oly);
-            nxt = (nxt + 1) & 3;
-            st = s_ring[nxt * kWave + me];  // post-reset state (the same state for envs that did not reset)
+            wave_lds_sync();
+            load_landmarks();
+            nxt = (nxt + 1) & 3;  // the post-reset slot (the same state for envs that did not reset)
         }
         cur = nxt;
-        s_rowB[me] = st;
-        wave_lds_sync();
-        stream_write_obs_block<N, L>(A.obs + (tBN + (size_t)env0 * N) * D, rows_here, lane, s_rowB, s_lmB);
-        wave_lds_sync();  // the block's LDS reads are done before s_rowB / s_lmB change again
+        const float4 *slot = s_ring + nxt * kWave;
+        float4 *const out4 = blk4 + tBN * (D / 4);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const float4 st = slot[row_u[u]];
+            const float4 o = cgrp == 0 ? make_float4(st.z, st.w, st.x, st.y)
+                                       : make_float4(lm_u[u].x - st.x, lm_u[u].y - st.y, lm_u[u].z - st.x, lm_u[u].w - st.y);
+            if (ok_u[u]) nt_store(out4 + 64 * u, o);
+        }
         PW_STAMP(1);
     }
 #ifdef PW_STAMPS

@@ -1,4 +1,7 @@
-// libpworld.so -- batched particle world for MI355X (gfx950, wave64).
+// libpworld.so -- batched particle world for MI355X (gfx950, wave64).  This translation unit: the environment (every
+// pw_step / pw_rollout kernel and the dispatcher), the replay ring and the wire blocks; pworld_policy.hip: the actor and
+// the policy-in-the-loop rollouts.  Two units only so that they compile in parallel (and an env-kernel experiment
+// rebuilds one of them).
 //
 // One fused kernel advances all B envs: _set_action -> apply_action_force ->
 // apply_environment_force (pairwise get_collision_force) -> integrate_state ->
@@ -37,24 +40,8 @@
 #include "pw_kernels_reference.hpp"
 #include "pw_kernels_generic.hpp"
 #include "pw_kernels_replay.hpp"
-#include "pw_kernels_policy.hpp"
-#include "pw_kernels_policy2.hpp"
-#include "pw_kernels_policy_tag.hpp"
 
-struct pw_handle {
-    pw_config cfg;
-    KParams kp;
-    pw_state_layout layout;
-    bool bound;
-    bool fast;      // pw_spread_fast_kernel applies
-    FastConsts fc;
-    bool tag_fast;  // pw_tag_stream_kernel applies
-    TagParams tp;   // its constant part (pointers are filled per launch)
-    float *comm;    // simple_reference planes inside the bound state block
-    int32_t *goal;
-    const char *last_kernel;  // name of the kernel the last pw_step / pw_rollout launched (pw_rollout_kernel)
-    pw_dispatch disp;         // kernel selection: fixed by pw_create / pw_set_dispatch, never read from the environment at launch
-};
+#include "pw_handle.hpp"
 
 namespace {
 
@@ -234,24 +221,6 @@ void apply_dispatch(pw_handle *h)
         kp.epw = h->disp.envs_per_wave < kWave / kp.N ? h->disp.envs_per_wave : kWave / kp.N;
     setup_fast_path(h);
     setup_tag_path(h);
-}
-
-// Kernels that ask for more than 64 KB of dynamic LDS need the opt-in once per (kernel, DEVICE): a process driving
-// several GPUs must not skip it on the second one.
-bool lds_optin_needed(unsigned long long *done_mask)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;  // unknown: set it every time (cheap)
-    if (*done_mask >> dev & 1ull) return false;
-    *done_mask |= 1ull << dev;
-    return true;
-}
-
-int check_ready(const pw_handle *h)
-{
-    if (!h) return fail(PW_EINVAL, "null handle");
-    if (!h->bound) return fail(PW_ESTATE, "state block not bound: call pw_bind_state first");
-    return PW_OK;
 }
 
 // every env-step launch records which kernel it was (pw_rollout_kernel: bench.py and the profile tools name the
@@ -512,7 +481,13 @@ int launch_aux(pw_handle *h, int mode, const uint8_t *env_mask, float *obs, floa
 
 }  // namespace
 
+namespace {
+thread_local std::string g_last_error;
+}
+
 extern "C" {
+
+void pw_internal_set_error(const char *msg) { g_last_error = msg ? msg : ""; }
 
 int pw_version(void) { return PW_VERSION; }
 
@@ -824,16 +799,6 @@ int pw_counter_add(int64_t *counter, int64_t delta, int64_t modulo, void *stream
     return PW_OK;
 }
 
-namespace {
-// The chunk / tail / packed / wire entry points and the rollout sink write the plain ring layout only.
-int plain_ring_only(const pw_replay_store *st, const char *who)
-{
-    if (st && (st->act_heads > 1 || st->per_agent))
-        return fail(PW_EINVAL, std::string(who) + ": two-head / per-agent rings are served by pw_replay_add and pw_replay_gather only");
-    return PW_OK;
-}
-}  // namespace
-
 int pw_replay_add(const pw_replay_store *st, int64_t start, const int64_t *start_dev, int32_t B, const float *obs,
                   const int32_t *act_idx, const float *rew_shared, const float *next_obs, const float *final_obs,
                   const uint8_t *terminal, const float *done, void *stream)
@@ -1059,343 +1024,6 @@ int pw_replay_add_wire(const pw_replay_store *st, int64_t start, const pw_chunk_
     else
         hipLaunchKernelGGL(pw_replay_add_wire_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                            *st, start, *w, wire);
-    PW_HIP_CHECK(hipGetLastError());
-    return PW_OK;
-}
-
-int pw_bilstm_forward(const float *G, const float *w_hh_fw, const float *w_hh_bw, int32_t B, int32_t N,
-                      int32_t relu_out, float *H, void *stream)
-{
-    if (!G || !w_hh_fw || !w_hh_bw || !H) return fail(PW_EINVAL, "null argument");
-    if (B < 1 || N < 1) return fail(PW_EINVAL, "bad sizes");
-    if ((reinterpret_cast<uintptr_t>(w_hh_fw) | reinterpret_cast<uintptr_t>(w_hh_bw)) & 15)
-        return fail(PW_EINVAL, "w_hh must be 16-byte aligned");
-    const long seqs = 2L * B;
-    hipLaunchKernelGGL(pw_bilstm_kernel, dim3((unsigned)((seqs + 7) / 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       G, w_hh_fw, w_hh_bw, B, N, relu_out, H);
-    PW_HIP_CHECK(hipGetLastError());
-    return PW_OK;
-}
-
-int pw_actor_head(const float *H, const float *w2, const float *b2, int64_t rows, uint64_t seed, uint64_t step,
-                  const int64_t *step_dev, float *logits, int32_t *act, void *stream)
-{
-    if (!H || !w2 || !b2 || (!logits && !act)) return fail(PW_EINVAL, "null argument");
-    if (rows < 1) return fail(PW_EINVAL, "bad sizes");
-    if (reinterpret_cast<uintptr_t>(H) & 15) return fail(PW_EINVAL, "H must be 16-byte aligned");
-    hipLaunchKernelGGL(pw_actor_head_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), H, w2, b2, (long)rows, seed, step, step_dev, logits, act);
-    PW_HIP_CHECK(hipGetLastError());
-    return PW_OK;
-}
-
-int pw_actor_fused(const float *X, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
-                   const float *w_hh_bw, const float *w2, const float *b2, int32_t n_out0, int32_t n_out1, int64_t B,
-                   int32_t N, int32_t in_dim, int32_t relu_out, uint64_t seed, uint64_t step, const int64_t *step_dev,
-                   float *H, float *logits, int32_t *act, void *stream)
-{
-    if (n_out0 < 1 || n_out1 < 0 || n_out0 + n_out1 > 16) return fail(PW_EINVAL, "head sizes: n_out0 >= 1, n_out0 + n_out1 <= 16");
-    if (!X || !frag || !b1 || !b_ih || !w_hh_fw || !w_hh_bw || !w2 || !b2 || (!H && !logits && !act))
-        return fail(PW_EINVAL, "null argument");
-    if (B < 1 || N < 1 || N > 96 || B > (int64_t)0x7fffffff) return fail(PW_EINVAL, "N must be in [1, 96]");
-    if (in_dim < 1 || in_dim > 64) return fail(PW_EINVAL, "in_dim must be in [1, 64]");
-    if ((reinterpret_cast<uintptr_t>(frag) | reinterpret_cast<uintptr_t>(w_hh_fw) | reinterpret_cast<uintptr_t>(w_hh_bw)) & 15)
-        return fail(PW_EINVAL, "frag and w_hh must be 16-byte aligned");
-    ActorFusedArgs a;
-    a.X = X; a.frag = frag; a.b1 = b1; a.bih = b_ih; a.whh_f = w_hh_fw; a.whh_r = w_hh_bw; a.w2 = w2; a.b2 = b2;
-    a.B = (int)B; a.N = N; a.D = in_dim; a.relu_out = relu_out; a.n_out0 = n_out0; a.n_out1 = n_out1;
-    a.E = 96 / N < 16 ? 96 / N : 16;
-    a.seed = seed; a.step = step; a.step_dev = step_dev; a.H = H; a.logits = logits; a.act = act;
-    const int S1C = (in_dim + 7) / 8, S1 = 4 * S1C;
-    const size_t shm = actor_lds_bytes(S1);
-    const unsigned grid = (unsigned)((B + a.E - 1) / a.E);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    static unsigned long long attr_set[9] = {};  // per kernel: bit = device
-#define PW_FUSED(C)                                                                                                      \
-    case C:                                                                                                              \
-        if (lds_optin_needed(&attr_set[C])) {                                                                            \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_actor_fused_kernel<C>),                   \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
-        hipLaunchKernelGGL(pw_actor_fused_kernel<C>, dim3(grid), dim3(512), shm, st, a);                                 \
-        break;
-    switch (S1C) {
-        PW_FUSED(1) PW_FUSED(2) PW_FUSED(3) PW_FUSED(4) PW_FUSED(5) PW_FUSED(6) PW_FUSED(7) PW_FUSED(8)
-    }
-#undef PW_FUSED
-    PW_HIP_CHECK(hipGetLastError());
-    return PW_OK;
-}
-
-int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
-                      const float *w_hh_bw, const float *w2, const float *b2, int32_t relu_out, uint64_t seed,
-                      uint64_t step, const int64_t *step_dev, const pw_step_io *io, int32_t *act_out, int32_t num_steps,
-                      const pw_rollout_sink *sink, void *stream)
-{
-    if (int rc = check_ready(h)) return rc;
-    if (!frag || !b1 || !b_ih || !w_hh_fw || !w_hh_bw || !w2 || !b2 || !io) return fail(PW_EINVAL, "null argument");
-    if (num_steps < 1) return fail(PW_EINVAL, "num_steps must be >= 1");
-    const KParams &kp = h->kp;
-    const bool tag = h->cfg.scenario == PW_SIMPLE_TAG && h->tag_fast;
-    if (!h->fast && !tag)
-        return fail(PW_EINVAL, "pw_policy_rollout serves the simple_spread fast-path configurations (local observation, "
-                               "homogeneous agents, L <= N) and simple_tag with homogeneous roles");
-    if (kp.N > 64 || kp.D > 64) return fail(PW_EINVAL, "N and the observation length must be <= 64");
-    if (io->act_idx || io->act_vec || io->act_comm || io->coll)
-        return fail(PW_EINVAL, "pw_policy_rollout produces the actions itself (act_out) and has no coll output");
-    const bool have_sink = sink && sink->ring;
-    if (!have_sink && (!act_out || !io->obs || !io->rew || !io->rew_shared || !io->done || !io->terminal))
-        return fail(PW_EINVAL, "without a ring sink, act_out and the obs, rew, rew_shared, done, terminal outputs are required");
-    if (sink) {
-        if (int rc = plain_ring_only(sink->ring, "pw_policy_rollout sink")) return rc;
-        if (sink->ring && (sink->ring->num_agents != kp.N || sink->ring->obs_dim != kp.D || sink->ring->capacity < 1 ||
-                           sink->ring_start < 0 || (int64_t)num_steps * kp.B > sink->ring->capacity))
-            return fail(PW_EINVAL, "ring sink: shape mismatch or the chunk does not fit the ring");
-        if (sink->episode_return && (!sink->finished_sum || !sink->finished_count || !sink->scratch))
-            return fail(PW_EINVAL, "bookkeeping needs episode_return, finished_sum, finished_count and scratch");
-    }
-    if ((reinterpret_cast<uintptr_t>(io->obs) | reinterpret_cast<uintptr_t>(io->final_obs) | reinterpret_cast<uintptr_t>(frag) |
-         reinterpret_cast<uintptr_t>(w_hh_fw) | reinterpret_cast<uintptr_t>(w_hh_bw) |
-         (have_sink ? reinterpret_cast<uintptr_t>(sink->ring->next_obs) | reinterpret_cast<uintptr_t>(sink->ring->obs) : 0)) & 15)
-        return fail(PW_EINVAL, "obs, final_obs, frag, w_hh and the ring planes must be 16-byte aligned");
-    if (tag) {
-        PolicyRolloutTagArgs Q;
-        std::memset(&Q, 0, sizeof(Q));
-        ActorFusedArgs &qa = Q.A;
-        qa.frag = frag; qa.b1 = b1; qa.bih = b_ih; qa.whh_f = w_hh_fw; qa.whh_r = w_hh_bw; qa.w2 = w2; qa.b2 = b2;
-        qa.B = kp.B; qa.N = kp.N; qa.D = kp.D; qa.relu_out = relu_out; qa.n_out0 = 5; qa.n_out1 = 0;
-        qa.E = 96 / kp.N < 16 ? 96 / kp.N : 16;
-        qa.seed = seed; qa.step = step; qa.step_dev = step_dev;
-        Q.V = h->tp;
-        TagParams &tv = Q.V;
-        tv.pos_x = kp.pos_x; tv.pos_y = kp.pos_y; tv.vel_x = kp.vel_x; tv.vel_y = kp.vel_y;
-        tv.lm_x = kp.lm_x; tv.lm_y = kp.lm_y; tv.ep_step = kp.ep_step; tv.ep_count = kp.ep_count;
-        tv.obs = io->obs; tv.final_obs = io->final_obs; tv.rew = io->rew; tv.rew_shared = io->rew_shared;
-        tv.done = io->done; tv.terminal = io->terminal;
-        Q.T = num_steps; Q.act_out = act_out;
-        if (have_sink) { Q.ring = *sink->ring; Q.has_ring = 1; Q.ring_start = sink->ring_start; }
-        if (sink && sink->episode_return) {
-            Q.episode_return = sink->episode_return; Q.finished_sum = sink->finished_sum;
-            Q.finished_count = sink->finished_count; Q.scratch = static_cast<unsigned long long *>(sink->scratch);
-        }
-        const int tS1C = (kp.D + 7) / 8;
-        const size_t tshm = policy_tag_lds_bytes(4 * tS1C, kp.D, qa.E, kp.L);
-        if (tshm > 160 * 1024 || tS1C < 2 || tS1C > 6)
-            return fail(PW_EINVAL, "simple_tag one-launch rollout: observation length must be in [9, 48] and fit the LDS");
-        const unsigned tgrid = (unsigned)((kp.B + qa.E - 1) / qa.E);
-        hipStream_t tst = static_cast<hipStream_t>(stream);
-#define PW_TG3(C, SK)                                                                                                    \
-    do {                                                                                                                 \
-        static unsigned long long attr_set = 0; /* bit = device */                                            \
-        if (lds_optin_needed(&attr_set)) {                                                                                \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_tag_kernel<C, SK>),        \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
-        hipLaunchKernelGGL((pw_policy_rollout_tag_kernel<C, SK>), dim3(tgrid), dim3(512), tshm, tst, Q);                 \
-    } while (0)
-#define PW_TG(C) case C: if (sink) PW_TG3(C, true); else PW_TG3(C, false); break;
-        switch (tS1C) { PW_TG(2) PW_TG(3) PW_TG(4) PW_TG(5) PW_TG(6) }
-#undef PW_TG3
-#undef PW_TG
-        PW_HIP_CHECK(hipGetLastError());
-        return PW_OK;
-    }
-    PolicyRolloutArgs P;
-    std::memset(&P, 0, sizeof(P));
-    ActorFusedArgs &a = P.A;
-    a.frag = frag; a.b1 = b1; a.bih = b_ih; a.whh_f = w_hh_fw; a.whh_r = w_hh_bw; a.w2 = w2; a.b2 = b2;
-    a.B = kp.B; a.N = kp.N; a.D = kp.D; a.relu_out = relu_out; a.n_out0 = 5; a.n_out1 = 0;
-    a.E = 96 / kp.N < 16 ? 96 / kp.N : 16;
-    a.seed = seed; a.step = step; a.step_dev = step_dev;
-    StreamParams &A = P.V;
-    A.B = kp.B; A.N = kp.N; A.L = kp.L; A.epw = kp.epw;
-    A.max_episode_len = kp.max_episode_len; A.auto_reset = kp.auto_reset;
-    A.seed = kp.seed; A.env_id_base = kp.env_id_base;
-    A.dt = kp.dt; A.damp = kp.damp; A.contact_force = kp.contact_force; A.contact_margin = kp.contact_margin;
-    A.mass = kp.mass;
-    A.dist_min = h->fc.dist_min; A.coll_thr2 = h->fc.coll_thr2; A.near_thr2 = h->fc.near_thr2;
-    A.sens = h->fc.sens; A.fscale = h->fc.fscale;
-    A.pos_x = kp.pos_x; A.pos_y = kp.pos_y; A.vel_x = kp.vel_x; A.vel_y = kp.vel_y;
-    A.lm_x = kp.lm_x; A.lm_y = kp.lm_y; A.ep_step = kp.ep_step; A.ep_count = kp.ep_count;
-    A.obs = io->obs; A.final_obs = io->final_obs; A.rew = io->rew; A.rew_shared = io->rew_shared;
-    A.done = io->done; A.terminal = io->terminal;
-    P.T = num_steps; P.act_out = act_out;
-    if (have_sink) { P.ring = *sink->ring; P.has_ring = 1; P.ring_start = sink->ring_start; }
-    if (sink && sink->episode_return) {
-        P.episode_return = sink->episode_return; P.finished_sum = sink->finished_sum;
-        P.finished_count = sink->finished_count; P.scratch = static_cast<unsigned long long *>(sink->scratch);
-    }
-    const int S1C = (kp.D + 7) / 8, S1 = 4 * S1C;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    // Two forms.  pw_policy_rollout_kernel: workgroup-wide phases, 16 envs per workgroup, LDS bounds the observation
-    // length (D <= 36).  pw_policy_rollout2_kernel (pw_kernels_policy2.hpp): role-specialised waves -- matrix cores and
-    // vector ALUs busy together, weights resident in registers -- with as many environments per workgroup as fit
-    // 160 KB of LDS, so it also serves long observation rows (D <= 64: N <= 30).  Measured at B = 4096
-    // (profiles/r2_policy_rollout.txt): N = 3: 15.4 vs 17.0 us/step; N = 6: 22.3 vs 23.4; N = 12: 69.1 vs 67.5; N = 16: 169 vs
-    // 120 -- so the second form runs where it wins (N <= 6) or where the first does not fit.  pw_dispatch.policy_form overrides.
-    const size_t shm = actor_lds_bytes(S1) + (size_t)kFusedRows * kp.D * sizeof(float) + kFusedRows * sizeof(int32_t) +
-                       2 * kWave * sizeof(float2) + (size_t)a.E * kp.L * sizeof(float2) + 16 * (sizeof(double) + sizeof(int));
-    const bool v1_fits = shm <= 160 * 1024;
-    bool use_v2 = !v1_fits || kp.N <= 6;
-    if (h->disp.policy_form == 2) use_v2 = true;
-    if (h->disp.policy_form == 1 && v1_fits) use_v2 = false;
-    int E2 = 0;
-    if (use_v2) {
-        for (int e = a.E; e >= 1; --e)
-            if (roll2_lds_bytes(e, kp.N, kp.L, kp.D, S1) <= 160 * 1024) { E2 = e; break; }
-        if (E2 == 0 && !v1_fits) return fail(PW_EINVAL, "observation too long for the one-launch rollout (LDS)");
-    }
-    if (E2 > 0) {
-        a.E = E2;
-        const size_t shm2 = roll2_lds_bytes(E2, kp.N, kp.L, kp.D, S1);
-        const unsigned grid2 = (unsigned)((kp.B + E2 - 1) / E2);
-#define PW_R23(C, NT, SK)                                                                                                \
-    do {                                                                                                                 \
-        static unsigned long long attr_set = 0; /* bit = device */                                            \
-        if (lds_optin_needed(&attr_set)) {                                                                                \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout2_kernel<C, NT, SK>),       \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
-        hipLaunchKernelGGL((pw_policy_rollout2_kernel<C, NT, SK>), dim3(grid2), dim3(512), shm2, st, P);                 \
-    } while (0)
-#define PW_R22(C, NT) do { if (sink) PW_R23(C, NT, true); else PW_R23(C, NT, false); } while (0)
-#define PW_R2(C) case C: PW_R22(C, 0); break;
-        if (kp.N == 6 && kp.L == 6) PW_R22(2, 6);        // BASELINE configs[1]: D = 16
-        else switch (S1C) {
-            PW_R2(1) PW_R2(2) PW_R2(3) PW_R2(4) PW_R2(5) PW_R2(6) PW_R2(7) PW_R2(8)
-        }
-#undef PW_R23
-#undef PW_R22
-#undef PW_R2
-        PW_HIP_CHECK(hipGetLastError());
-        return PW_OK;
-    }
-    const unsigned grid = (unsigned)((kp.B + a.E - 1) / a.E);
-#define PW_PR3(C, NT, SK)                                                                                                \
-    do {                                                                                                                 \
-        static unsigned long long attr_set = 0; /* bit = device */                                            \
-        if (lds_optin_needed(&attr_set)) {                                                                                \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_kernel<C, NT, SK>),        \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
-        hipLaunchKernelGGL((pw_policy_rollout_kernel<C, NT, SK>), dim3(grid), dim3(512), shm, st, P);                    \
-    } while (0)
-#define PW_PR2(C, NT) do { if (sink) PW_PR3(C, NT, true); else PW_PR3(C, NT, false); } while (0)
-#define PW_PR(C) case C: PW_PR2(C, 0); break;
-    if (kp.N == 6 && kp.L == 6) PW_PR2(2, 6);        // BASELINE configs[1]: D = 16
-    else if (kp.N == 3 && kp.L == 3) PW_PR2(2, 3);   // configs[0]: D = 10
-    else switch (S1C) {
-        PW_PR(1) PW_PR(2) PW_PR(3) PW_PR(4) PW_PR(5) PW_PR(6) PW_PR(7) PW_PR(8)
-    }
-#undef PW_PR3
-#undef PW_PR2
-#undef PW_PR
-    PW_HIP_CHECK(hipGetLastError());
-    return PW_OK;
-}
-
-int pw_rollout_tail(const float *rew_shared, const uint8_t *terminal, int32_t B, float *episode_return,
-                    double *finished_sum, int64_t *finished_count, int64_t *counter0, int64_t delta0, int64_t modulo0,
-                    int64_t *counter1, int64_t delta1, int64_t modulo1, void *stream)
-{
-    if (!rew_shared || !terminal || !episode_return || !finished_sum || !finished_count)
-        return fail(PW_EINVAL, "null argument");
-    if (B < 1) return fail(PW_EINVAL, "bad sizes");
-    TailCounters tc;
-    tc.c0 = counter0; tc.d0 = delta0; tc.m0 = modulo0;
-    tc.c1 = counter1; tc.d1 = delta1; tc.m1 = modulo1;
-    hipLaunchKernelGGL(pw_episode_stats_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), rew_shared,
-                       terminal, B, episode_return, finished_sum, finished_count, tc);
-    PW_HIP_CHECK(hipGetLastError());
-    return PW_OK;
-}
-
-int pw_episode_stats(const float *rew_shared, const uint8_t *terminal, int32_t B, float *episode_return,
-                     double *finished_sum, int64_t *finished_count, void *stream)
-{
-    return pw_rollout_tail(rew_shared, terminal, B, episode_return, finished_sum, finished_count, nullptr, 0, 0, nullptr, 0,
-                           0, stream);
-}
-
-int pw_dense(const float *X, const float *W, const float *b, int64_t rows, int32_t in_dim, int32_t out_dim,
-             int32_t relu, float *Y, void *stream)
-{
-    if (!X || !W || !b || !Y) return fail(PW_EINVAL, "null argument");
-    if (rows < 1 || in_dim < 1 || in_dim > 64) return fail(PW_EINVAL, "in_dim must be in [1, 64]");
-    if (out_dim < 64 || (out_dim & 63)) return fail(PW_EINVAL, "out_dim must be a positive multiple of 64");
-    const int chunks = out_dim / 64;
-    // ~2048 waves (two per SIMD) when there are enough rows, at least 8 rows per wave
-    long rpw = (rows * chunks + 2047) / 2048;
-    if (rpw < 8) rpw = 8;
-    const long waves = ((rows + rpw - 1) / rpw) * chunks;
-    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-#define PW_DENSE_LAUNCH(k)                                                                                          \
-    do {                                                                                                            \
-        if (relu) hipLaunchKernelGGL((pw_dense_kernel<k, true>), grid, block, 0, st, X, W, b, (long)rows, in_dim,   \
-                                     out_dim, (int)rpw, Y);                                                         \
-        else hipLaunchKernelGGL((pw_dense_kernel<k, false>), grid, block, 0, st, X, W, b, (long)rows, in_dim,       \
-                                out_dim, (int)rpw, Y);                                                              \
-    } while (0)
-    switch (in_dim) {
-    case 10: PW_DENSE_LAUNCH(10); break;
-    case 16: PW_DENSE_LAUNCH(16); break;
-    case 22: PW_DENSE_LAUNCH(22); break;
-    case 64: PW_DENSE_LAUNCH(64); break;
-    default: PW_DENSE_LAUNCH(0);
-    }
-#undef PW_DENSE_LAUNCH
-    PW_HIP_CHECK(hipGetLastError());
-    return PW_OK;
-}
-
-int pw_debug_math(int32_t fn, const float *x, float aux, float *y, int64_t n, void *stream)
-{
-    if (!x || !y || n < 1 || fn < 0 || fn > 9) return fail(PW_EINVAL, "bad argument");
-    hipLaunchKernelGGL(pw_debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), fn, x, aux, y, (long)n);
-    PW_HIP_CHECK(hipGetLastError());
-    return PW_OK;
-}
-
-size_t pw_actor_front_pack_floats(int32_t in_dim) { return (size_t)8 * 2 * 4 * 64 * 4 + (size_t)2 * (((in_dim + 7) / 8) * 4) * 64; }
-
-int pw_actor_front_pack(const float *w1, const float *w_ih, int32_t in_dim, float *frag, void *stream)
-{
-    if (!w1 || !w_ih || !frag) return fail(PW_EINVAL, "null argument");
-    if (in_dim < 1 || in_dim > 64) return fail(PW_EINVAL, "in_dim must be in [1, 64]");
-    if ((reinterpret_cast<uintptr_t>(w_ih) | reinterpret_cast<uintptr_t>(frag)) & 15)
-        return fail(PW_EINVAL, "w_ih and frag must be 16-byte aligned");
-    hipLaunchKernelGGL(pw_actor_front_pack_kernel, dim3(16), dim3(256), 0, static_cast<hipStream_t>(stream), w1, w_ih, in_dim, frag);
-    PW_HIP_CHECK(hipGetLastError());
-    return PW_OK;
-}
-
-int pw_actor_front(const float *X, const float *frag, const float *b1, const float *b_ih, int64_t rows, int32_t in_dim,
-                   float *G, void *stream)
-{
-    if (!X || !frag || !b1 || !b_ih || !G) return fail(PW_EINVAL, "null argument");
-    if (rows < 1 || in_dim < 1 || in_dim > 64) return fail(PW_EINVAL, "in_dim must be in [1, 64]");
-    if ((reinterpret_cast<uintptr_t>(frag) | reinterpret_cast<uintptr_t>(G)) & 15)
-        return fail(PW_EINVAL, "frag and G must be 16-byte aligned");
-    const int S1C = (in_dim + 7) / 8, S1 = 4 * S1C;
-    const size_t shm = (size_t)8 * 2 * 4 * 64 * sizeof(float4) + (size_t)(2 * S1 * 64 + 64 + 256 + 4 * 32 * 33) * sizeof(float);
-    const long tiles = (rows + 127) / 128;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    static unsigned long long attr_set[9] = {};  // per kernel: bit = device
-#define PW_FRONT(C)                                                                                                      \
-    case C:                                                                                                              \
-        if (lds_optin_needed(&attr_set[C])) { /* > 64 KB of dynamic LDS needs the opt-in */                              \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_actor_front_kernel<C>),                   \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
-        hipLaunchKernelGGL(pw_actor_front_kernel<C>, dim3((unsigned)tiles), dim3(256), shm, st, X, frag, b1, b_ih,       \
-                           (long)rows, in_dim, G);                                                                       \
-        break;
-    switch (S1C) {
-        PW_FRONT(1) PW_FRONT(2) PW_FRONT(3) PW_FRONT(4) PW_FRONT(5) PW_FRONT(6) PW_FRONT(7) PW_FRONT(8)
-    }
-#undef PW_FRONT
     PW_HIP_CHECK(hipGetLastError());
     return PW_OK;
 }

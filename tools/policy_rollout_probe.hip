@@ -3,6 +3,7 @@
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -I include tools/policy_rollout_probe.hip -o tools/policy_rollout_probe.bin
 #define PW_STAMPS 1
 #include "../multiagent_rl_amd/csrc/pworld.hip"
+#include "../multiagent_rl_amd/csrc/pworld_policy.hip"
 #include <vector>
 
 int main(int argc, char **argv)
