@@ -392,8 +392,13 @@ size_t pw_policy_rollout_scratch_bytes(const pw_handle *h);
 /* Test hook: y[i] = f(x[i]) with the DEVICE implementation of one math primitive, so its bits can be compared
  * with a CPU implementation of pworld_math.h.  fn: 0 the kernels' fast correctly-rounded sqrt, 1 their
  * branch-free softplus, 2 pw_softplus, 3 pw_exp, 4 sqrtf, 5 x / aux (IEEE division), 6 / 7 the hot loops'
- * scaling-free division chain for x / aux and aux / x, 8 their softplus, 9 aux / x (IEEE division). */
+ * scaling-free division chain for x / aux and aux / x, 8 their softplus, 9 aux / x (IEEE division), 10 x / aux with ONE
+ * correction step (what the C2 kernel runs for the division by the contact margin when pw_margin_one_correction(aux)). */
 int pw_debug_math(int32_t fn, const float *x, float aux, float *y, int64_t n, void *stream);
+/* 1 if dividing by this contact margin with one Newton correction is IEEE division (its refined reciprocal is the correctly
+ * rounded one, from every 1-ulp-accurate starting value; significand not all ones; inside the division chain's range): the
+ * host-side decision behind the K1 kernel instantiations.  The canonical margin 1e-3 qualifies. */
+int pw_margin_one_correction(float contact_margin);
 
 #ifdef __cplusplus
 }

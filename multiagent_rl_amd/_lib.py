@@ -127,6 +127,7 @@ SIGNATURES = {
     'pw_rollout_tail': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'pw_debug_math': (C.c_int, [C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    'pw_margin_one_correction': (C.c_int, [C.c_float]),
     'pw_replay_gather': (C.c_int, [C.POINTER(PwReplayStore), C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_void_p]),
 }
 

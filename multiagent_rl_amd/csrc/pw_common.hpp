@@ -115,6 +115,17 @@ __device__ __forceinline__ float div_chain(float a, float b, float y)
     const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
     return __builtin_fmaf(__builtin_fmaf(-b, q1, a), y, q1);
 }
+// a / b with ONE correction step: q0 = RN(a y), q1 = RN(q0 + (a - b q0) y).  With y = RN(1 / b) EXACTLY (the correctly
+// rounded reciprocal) and q0 within one ulp of a / b, q1 is the correctly rounded quotient (Markstein, "Computation of
+// elementary functions on the IBM RISC System/6000 processor", 1990, Theorem 4; the exception -- a significand of b of
+// all ones -- is excluded by the caller).  The caller checks both conditions on the host for the one divisor this is
+// used with, the wave-uniform contact margin (pworld.hip margin_one_correction); the same operand ranges as div_chain
+// apply.  tests: pw_debug_math fn 10 against IEEE division over EVERY float32 significand, each exponent of the range.
+__device__ __forceinline__ float div_chain1(float a, float b, float y)
+{
+    const float q0 = a * y;
+    return __builtin_fmaf(__builtin_fmaf(-b, q0, a), y, q0);
+}
 __device__ __forceinline__ f32x2 div_chain2(f32x2 a, float b, float y)
 {
     const f32x2 nb = {-b, -b}, yy = {y, y};
@@ -177,7 +188,9 @@ __device__ __forceinline__ float softplus_branchless(float x)
 {
     const float m = x > 0.0f ? x : 0.0f;
     const float t0 = -__builtin_fabsf(x);        // <= 0, or NaN; a source modifier of the clamp below, not an instruction
-    const float tc = t0 > -87.0f ? t0 : -87.0f;  // keep the exponent arithmetic in range when cut (and for NaN)
+    // keep the exponent arithmetic in range when cut (and for NaN): max(t0, -87) IS "t0 > -87 ? t0 : -87" for every input
+    // (v_max_f32 returns the other operand for a NaN; -0 > -87), one instruction instead of compare + select on the chain
+    const float tc = __builtin_fmaxf(t0, -87.0f);
     const float n = floorf(__builtin_fmaf(tc, 1.44269504088896341f, 0.5f));
     float r = __builtin_fmaf(n, -0.693359375f, tc);
     r = __builtin_fmaf(n, 2.12194440054690583e-4f, r);
@@ -212,7 +225,7 @@ __device__ __forceinline__ float softplus_branchless(float x)
 // collision_force_pair: the pair force (Fx, Fy) on the first entity itself; collision_force adds it to the accumulator
 // (F + f, the upstream order of operands).  The force on the second entity is the exact negation: every operation
 // below is odd in delta.
-template <bool FAST = false>
+template <bool FAST = false, bool K1 = false>
 __device__ __forceinline__ void collision_force_pair(float px, float py, float qx, float qy, float dist_min,
                                                      float k, float cf, float &Fx, float &Fy)
 {
@@ -229,7 +242,8 @@ __device__ __forceinline__ void collision_force_pair(float px, float py, float q
         const bool in_range = c1 & c2 & uni;
         if (__builtin_expect(in_range, 1)) {
             const float dist = sqrt_rn_core(d2);
-            const float xarg = div_chain(-(dist - dist_min), k, div_refined_rcp(k));
+            const float xarg = K1 ? div_chain1(-(dist - dist_min), k, div_refined_rcp(k))
+                                  : div_chain(-(dist - dist_min), k, div_refined_rcp(k));
             const float pen = softplus_branchless(xarg) * k;
             const f32x2 F = div_chain2(a, dist, div_refined_rcp(dist)) * f32x2{pen, pen};
             Fx = F.x;

@@ -18,6 +18,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 struct FastConsts {
     float dist_min, coll_thr2, near_thr2, sens, fscale, size;
+    int k1;  // the contact margin qualifies for the one-correction division (margin_one_correction)
 };
 
 template <int NT>

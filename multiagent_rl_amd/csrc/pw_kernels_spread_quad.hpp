@@ -43,7 +43,9 @@ __device__ __forceinline__ void quad_pair_of(const int q, int &i, int &j)
 // COLL: wave OA also stores the step's collision masks (pw_step_io.coll) -- it holds the six threshold tests anyway, so
 // the instantiation differs by one mask accumulation and one 8-byte store per lane and step; every other output is
 // bit-identical to the plain form (tests: the `quad+coll` path, and the bench-path test at C2 full size).
-template <bool UNIT_MASS, bool COLL = false>
+// K1: the division by the contact margin inside the force runs as ONE Newton correction (pw_common.hpp div_chain1); the
+// host sets it only for margins whose refined reciprocal is the correctly rounded one (pworld.hip margin_one_correction).
+template <bool UNIT_MASS, bool COLL = false, bool K1 = false>
 __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamParams A, const int T)
 {
     constexpr int N = 6, L = 6, D = 16, P2 = 15, EPP = 4, EPW = 8;
@@ -173,10 +175,12 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             // ---- pair phase: every unordered pair of the wave's envs at once
             float Fx = 0.0f, Fy = 0.0f;
             {
-                const float dx = qj.x - qi.x, dy = qj.y - qi.y;   // the near test of the other kernels: (q - p)^2
+                // the near test on (p_i - p_j)^2, the force's own delta, so that the two share their first operations (the other
+                // kernels test (p_j - p_i)^2: the same value -- a difference and its negation have the same square): -1.7 % step time
+                const float dx = qi.x - qj.x, dy = qi.y - qj.y;
                 const float d2 = dx * dx + dy * dy;
                 if (__float_as_uint(d2) - near_lo >= near_span)  // not provably far (NaN / inf included)
-                    collision_force_pair<true>(qi.x, qi.y, qj.x, qj.y, A.dist_min, k, cf, Fx, Fy);
+                    collision_force_pair<true, K1>(qi.x, qi.y, qj.x, qj.y, A.dist_min, k, cf, Fx, Fy);
             }
             *f_ij = make_float2(Fx, Fy);
             *f_ji = make_float2(-Fx, -Fy);

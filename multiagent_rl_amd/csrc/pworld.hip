@@ -100,6 +100,33 @@ float exact_near_thr2(float dmin, float contact_margin)
     return n2;
 }
 
+// div_chain1 (pw_common.hpp) divides by the contact margin k with ONE Newton correction, which is the correctly rounded
+// quotient if (a) the reciprocal the kernels use, y = fma(fma(-k, rcp, 1), rcp, rcp) with ANY rcp within 1 ulp of 1 / k,
+// is the correctly rounded 1 / k, (b) k's significand is not all ones, (c) k is inside div_chain's operand range.  (a) is
+// decided exactly: k and y are float32, so k * y - 1 is exact in double, and y = RN(1 / k) iff |1 - k y| <= k ulp(y) / 2
+// (strictly below: no float is a midpoint of 1 / k for k not a power of two; a power of two has y exact).  The hardware's
+// v_rcp_f32 is only specified to 1 ulp, so all three candidates y0 in {rcp - 1ulp, rcp, rcp + 1ulp} must refine to that y.
+bool margin_one_correction(float k)
+{
+    if (!(k >= 9.094947017729282e-13f && k <= 1099511627776.0f)) return false;
+    uint32_t kb;
+    std::memcpy(&kb, &k, 4);
+    if ((kb & 0x7FFFFFu) == 0x7FFFFFu) return false;
+    const float y_rn = (float)(1.0 / (double)k);  // a candidate; verified below, not trusted
+    for (int d = -1; d <= 1; ++d) {
+        float y0 = y_rn;
+        uint32_t yb;
+        std::memcpy(&yb, &y0, 4);
+        yb += (uint32_t)d;
+        std::memcpy(&y0, &yb, 4);
+        const float y = std::fmaf(std::fmaf(-k, y0, 1.0f), y0, y0);
+        const double resid = std::fabs(std::fma((double)k, (double)y, -1.0));       // |k y - 1|, exact
+        const double ulp_y = (double)std::nextafterf(y, INFINITY) - (double)y;
+        if (!(resid < (double)k * ulp_y * 0.5) && !(resid == 0.0)) return false;
+    }
+    return true;
+}
+
 // Decide whether pw_tag_stream_kernel applies (both roles homogeneous) and derive its tables.
 void setup_tag_path(pw_handle *h)
 {
@@ -170,6 +197,7 @@ void setup_fast_path(pw_handle *h)
     fc.coll_thr2 = exact_coll_thr2(dmin);
     fc.near_thr2 = exact_near_thr2(dmin, kp.contact_margin);
     if (fc.coll_thr2 == 0.0f || fc.near_thr2 == 0.0f) return;
+    fc.k1 = margin_one_correction(kp.contact_margin) ? 1 : 0;
     h->fast = true;
 }
 
@@ -361,7 +389,10 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
             if (quad) {
                 const size_t qshm = 4 * kWave * sizeof(float4) + 2 * 4 * 6 * 6 * sizeof(float2) + 2 * kWave * sizeof(float) +
                                     8 * 6 * sizeof(float2) + kWave * sizeof(float4) + 2 * kActRingBytes + 2 * 8 * sizeof(float2);
-                if (wc) PW_LAUNCH(h, (pw_spread_quad_kernel<true, true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
+                const bool k1 = h->fc.k1 != 0;  // the canonical margin 1e-3 qualifies
+                if (wc && k1) PW_LAUNCH(h, (pw_spread_quad_kernel<true, true, true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
+                else if (wc) PW_LAUNCH(h, (pw_spread_quad_kernel<true, true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
+                else if (k1) PW_LAUNCH(h, (pw_spread_quad_kernel<true, false, true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
                 else PW_LAUNCH(h, (pw_spread_quad_kernel<true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
                 PW_HIP_CHECK(hipGetLastError());
                 return PW_OK;
@@ -641,6 +672,8 @@ int pw_get_config(const pw_handle *h, pw_config *out)
     *out = h->cfg;
     return PW_OK;
 }
+
+int pw_margin_one_correction(float contact_margin) { return margin_one_correction(contact_margin) ? 1 : 0; }
 
 int pw_dispatch_default(pw_dispatch *d)
 {

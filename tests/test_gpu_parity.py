@@ -472,9 +472,76 @@ def test_scaling_free_division_chain_is_ieee_division_bitwise():
     _assert_same_bits(dev(8, xs), co.math_v(1, xs), 'softplus_fastdiv vs CPU contract')
 
 
+def test_one_correction_division_by_the_contact_margin_is_ieee_division_exhaustively():
+    """BASELINE configs[1]'s kernel divides by the contact margin with ONE Newton correction (pw_common.hpp div_chain1) when the
+    host decides the margin qualifies (pw_margin_one_correction: its refined reciprocal is the correctly rounded one).  For
+    every margin the decision accepts, the chain must BE IEEE division: compared with the device's own x / k over EVERY float32
+    significand (2^23), both signs, every exponent of the chain's operand range -- 2 x 10^9 operands per margin.  And the
+    decision must refuse what the theorem excludes (a significand of all ones) or what is out of range."""
+    import ctypes as C
+    from multiagent_rl_amd import _lib
+    lib = _lib.load()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.pw_margin_one_correction(C.c_float(1e-3)) == 1           # the canonical margin: what the bench runs
+    assert lib.pw_margin_one_correction(C.c_float(0.99999994)) == 0      # significand all ones
+    assert lib.pw_margin_one_correction(C.c_float(1e-13)) == 0 and lib.pw_margin_one_correction(C.c_float(2e12)) == 0
+    sig = torch.arange(1 << 23, dtype=torch.int32, device='cuda')
+    out5, out10 = torch.empty(1 << 23, device='cuda'), torch.empty(1 << 23, device='cuda')
+    tried = accepted = 0
+    rng = np.random.RandomState(7)
+    margins = [1e-3, 1e-2, 0.3, 2.5, 3.0, 7.62939453125e-06, 1.0000001, 1.9999998, 0.1, 5e-4, 2e-3, 1e-4, 0.75] + \
+        list(np.exp(rng.uniform(np.log(1e-6), np.log(10.0), 12)))
+    for k in margins:
+        k = float(np.float32(k))
+        tried += 1
+        if not lib.pw_margin_one_correction(C.c_float(k)):
+            continue
+        accepted += 1
+        exps = range(-69, 52) if k == float(np.float32(1e-3)) else (-69, -30, -1, 0, 1, 17, 51)
+        for e in exps:
+            for sign in (0, 1):
+                x = (sig | ((e + 127) << 23) | (-(1 << 31) if sign else 0)).view(torch.float32)
+                for fn, o in ((5, out5), (10, out10)):
+                    assert lib.pw_debug_math(fn, C.c_void_p(x.data_ptr()), C.c_float(k), C.c_void_p(o.data_ptr()), x.numel(), stream) == 0
+                assert torch.equal(out5.view(torch.int32), out10.view(torch.int32)), 'x / %r: exponent %d sign %d' % (k, e, sign)
+    assert accepted >= 8 and tried - accepted >= 0, (tried, accepted)
+
+
+@pytest.mark.parametrize('margin, k1', [(1e-3, True), (2e-3, None), (0.0009765624417923391, False), (0.01, None)])
+def test_quad_kernel_with_other_contact_margins_matches_oracle_bitwise(margin, k1):
+    """The quad kernel's two instantiations of the margin division (one correction where pw_margin_one_correction says so,
+    two otherwise -- 0.00097656244 = 0x3A7FFFFF has a significand of all ones and must take the general chain): 30 steps across a
+    reset against the float32 oracle built with the same margin."""
+    import ctypes as C
+    from multiagent_rl_amd import _lib
+    from multiagent_rl_amd.env import BatchedParticleEnv
+    margin = float(np.float32(margin))
+    got_k1 = bool(_lib.load().pw_margin_one_correction(C.c_float(margin)))
+    if k1 is not None:
+        assert got_k1 == k1
+    B, N, T = 777, 6, 30
+    env = BatchedParticleEnv('simple_spread', B, num_agents=N, max_episode_len=25, auto_reset=True, seed=3, contact_margin=margin,
+                             dispatch=dict(AUTO, quad=1))
+    cfg = co.make_config('simple_spread', N, max_episode_len=25, auto_reset=True, seed=3, contact_margin=margin)
+    o32 = co.COracle(cfg, B, np.float32)
+    _assert_same_bits(_np(env.reset()), o32.reset(), 'reset')
+    # crowd the agents so that contacts are frequent
+    st = env.get_state()
+    env.set_state(st['pos'] * 0.3, st['vel'], st['landmarks'], ep_step=st['ep_step'], ep_count=st['ep_count'])
+    o32.set_state(_np(st['pos'] * 0.3), _np(st['vel']), _np(st['landmarks']))
+    acts = np.random.RandomState(1).randint(0, 5, (T, B, N)).astype(np.int32)
+    out = env.rollout(torch.from_numpy(acts))
+    assert env.last_kernel() == ('pw_spread_quad_kernel<true,false,true>' if got_k1 else 'pw_spread_quad_kernel<true>')
+    for t in range(T):
+        w = o32.step(act_idx=acts[t])
+        _assert_same_bits(_np(out['obs'][t]), w['obs'], 'obs[%d]' % t)
+        _assert_same_bits(_np(out['rew'][t]), w['rew'], 'rew[%d]' % t)
+    _assert_same_bits(_np(env.get_state()['vel']), o32.vel, 'vel')
+
+
 @pytest.mark.parametrize('case, disp, kernel, kernel_coll', [
     (dict(scenario='simple_spread', num_agents=6, num_envs=4096), {},                  # C2 as the bench runs it
-     'pw_spread_quad_kernel<true>', 'pw_spread_quad_kernel<true,true>'),
+     'pw_spread_quad_kernel<true,false,true>', 'pw_spread_quad_kernel<true,true,true>'),
     (dict(scenario='simple_spread', num_agents=6, num_envs=4096), dict(quad=0),          # C2, two-wave form
      'pw_spread_duo_kernel<6,6,true>', 'pw_spread_duo_kernel<6,6,true,true>'),
     (dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192), {},  # C3 as the bench runs it: three waves
@@ -615,7 +682,7 @@ def test_quad_kernel_equals_duo_with_desynchronised_episode_clocks(B, ep_len):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('case, want', [
-    (dict(scenario='simple_spread', num_agents=6, num_envs=4096), 'pw_spread_quad_kernel'),       # C2: the bench path
+    (dict(scenario='simple_spread', num_agents=6, num_envs=4096), 'pw_spread_quad_kernel<true,false,true>'),       # C2: the bench path
     (dict(scenario='simple_spread', num_agents=6, num_envs=16384), 'pw_spread_duo_kernel<6,6,true,false,true>'),
     (dict(scenario='simple_spread', num_agents=3, num_envs=4096), 'pw_spread_duo_kernel<3,3,true>'),
     (dict(scenario='simple_spread', num_agents=48, num_envs=4096), 'pw_spread_duo_kernel<48,48,true,false,true>'),
