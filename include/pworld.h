@@ -393,7 +393,8 @@ size_t pw_policy_rollout_scratch_bytes(const pw_handle *h);
  * with a CPU implementation of pworld_math.h.  fn: 0 the kernels' fast correctly-rounded sqrt, 1 their
  * branch-free softplus, 2 pw_softplus, 3 pw_exp, 4 sqrtf, 5 x / aux (IEEE division), 6 / 7 the hot loops'
  * scaling-free division chain for x / aux and aux / x, 8 their softplus, 9 aux / x (IEEE division), 10 x / aux with ONE
- * correction step (what the C2 kernel runs for the division by the contact margin when pw_margin_one_correction(aux)). */
+ * correction step (what the C2 kernel runs for the division by the contact margin when pw_margin_one_correction(aux)),
+ * 11 / 12 the hot loops' correctly rounded sqrt for x in [2^-90, 2^90) (one fused correction) / the two-test form it replaced. */
 int pw_debug_math(int32_t fn, const float *x, float aux, float *y, int64_t n, void *stream);
 /* 1 if dividing by this contact margin with one Newton correction is IEEE division (its refined reciprocal is the correctly
  * rounded one, from every 1-ulp-accurate starting value; significand not all ones; inside the division chain's range): the

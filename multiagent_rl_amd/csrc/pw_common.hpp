@@ -71,11 +71,22 @@ __device__ __forceinline__ Lane make_lane(const KParams &P)
 }
 
 // Correctly rounded sqrtf for the hot loops.  The compiler's expansion of sqrtf spends half of its
-// ~22 instructions on scaling subnormal-range inputs and on the 0 / inf / NaN pass-through.  For
-// x in [2^-90, 2^90) neither is needed: v_sqrt_f32 is within 1 ulp, and two fused residual tests
-// pick between {s-1ulp, s, s+1ulp} -- the same correction step the compiler emits.  Anything
-// outside that range (never reached from finite, non-coincident states) takes the general sqrtf.
+// ~22 instructions on scaling subnormal-range inputs and on the 0 / inf / NaN pass-through, and corrects the hardware
+// estimate with two residual tests and two selects.  For x in [2^-90, 2^90) neither wrapper is needed, and ONE fused
+// correction is exact: g = v_sqrt_f32(x) is within 1 ulp, h = 0.5 * v_rsq_f32(x) is computed beside it, and
+//   s = RN(g + (x - g^2) * h)          (x - g^2 exact in the fma)
+// is the correctly rounded root -- Markstein's final step for sqrt -- with two dependent operations behind the hardware
+// estimate instead of five.  It is not taken on trust: tests/test_gpu_parity.py compares it with sqrtf over EVERY float32
+// of the range (1.5 x 10^9 arguments, tools/sqrt_probe.py: 0 mismatches on gfx950), and sqrt_rn_core_tests, the two-test
+// form it replaced, stays behind pw_debug_math for that comparison.  Anything outside the range (never reached from finite,
+// non-coincident states) takes the general sqrtf.
 __device__ __forceinline__ float sqrt_rn_core(float x)  // x in [2^-90, 2^90)
+{
+    const float g = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+    return __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
+}
+__device__ __forceinline__ float sqrt_rn_core_tests(float x)  // the round-1/2 form: v_sqrt_f32 + two residual tests
 {
     float s = __builtin_amdgcn_sqrtf(x);
     const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);

@@ -865,7 +865,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_kernel(const PolicyRoll
 // against the CPU contract (include/pworld_math.h, restated in oracle/pworld_oracle.c) over millions of
 // inputs.  fn: 0 sqrt_rn_fast, 1 softplus_branchless, 2 pw_softplus, 3 pw_exp, 4 sqrtf, 5 x / aux (IEEE),
 // 6 div_chain(x, aux), 7 div_chain(aux, x) (the scaling-free division of the hot loops), 8 softplus_branchless (kept: the round-2 chain form had its own number),
-// 9 aux / x (IEEE), 10 div_chain1(x, aux) (one correction; exact only for divisors pw_margin_one_correction accepts)
+// 9 aux / x (IEEE), 10 div_chain1(x, aux) (one correction; exact only for divisors pw_margin_one_correction accepts),
+// 11 sqrt_rn_core(x) (the hot loops' one-correction sqrt; x in [2^-90, 2^90)), 12 sqrt_rn_core_tests(x) (the two-test form)
 __global__ void pw_debug_math_kernel(const int fn, const float *x, const float aux, float *y, const long n)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -883,6 +884,8 @@ __global__ void pw_debug_math_kernel(const int fn, const float *x, const float a
     case 8: r = softplus_branchless(v); break;
     case 9: r = aux / v; break;
     case 10: r = div_chain1(v, aux, div_refined_rcp(aux)); break;
+    case 11: r = sqrt_rn_core(v); break;
+    case 12: r = sqrt_rn_core_tests(v); break;
     default: r = v / aux; break;
     }
     y[i] = r;

@@ -314,7 +314,7 @@ int pw_dense(const float *X, const float *W, const float *b, int64_t rows, int32
 
 int pw_debug_math(int32_t fn, const float *x, float aux, float *y, int64_t n, void *stream)
 {
-    if (!x || !y || n < 1 || fn < 0 || fn > 10) return fail(PW_EINVAL, "bad argument");
+    if (!x || !y || n < 1 || fn < 0 || fn > 12) return fail(PW_EINVAL, "bad argument");
     hipLaunchKernelGGL(pw_debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), fn, x, aux, y, (long)n);
     PW_HIP_CHECK(hipGetLastError());

@@ -472,6 +472,27 @@ def test_scaling_free_division_chain_is_ieee_division_bitwise():
     _assert_same_bits(dev(8, xs), co.math_v(1, xs), 'softplus_fastdiv vs CPU contract')
 
 
+def test_one_correction_sqrt_is_the_correctly_rounded_sqrt_exhaustively():
+    """The hot loops' sqrt (pw_common.hpp sqrt_rn_core: hardware estimate + ONE fused correction) against the device's sqrtf and
+    against the two-test form it replaced, over EVERY float32 of its range [2^-90, 2^90): 1.5 x 10^9 arguments; one binade also
+    against the CPU's correctly rounded sqrt."""
+    import ctypes as C
+    from multiagent_rl_amd import _lib
+    lib = _lib.load()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sig = torch.arange(1 << 23, dtype=torch.int32, device='cuda')
+    o4, o11, o12 = [torch.empty(1 << 23, device='cuda') for _ in range(3)]
+    for e in range(-90, 90):
+        x = (sig | ((e + 127) << 23)).view(torch.float32)
+        for fn, o in ((4, o4), (11, o11), (12, o12)):
+            assert lib.pw_debug_math(fn, C.c_void_p(x.data_ptr()), C.c_float(1.0), C.c_void_p(o.data_ptr()), x.numel(), stream) == 0
+        assert torch.equal(o4.view(torch.int32), o11.view(torch.int32)), 'one-correction sqrt, exponent %d' % e
+        assert torch.equal(o4.view(torch.int32), o12.view(torch.int32)), 'two-test sqrt, exponent %d' % e
+        if e in (-90, -3, 0, 1, 89):
+            want = np.sqrt(x.cpu().numpy().astype(np.float64)).astype(np.float32)   # float64 sqrt of a float32, rounded: correctly rounded
+            _assert_same_bits(o11.cpu().numpy(), want, 'sqrt vs CPU, exponent %d' % e)
+
+
 def test_one_correction_division_by_the_contact_margin_is_ieee_division_exhaustively():
     """BASELINE configs[1]'s kernel divides by the contact margin with ONE Newton correction (pw_common.hpp div_chain1) when the
     host decides the margin qualifies (pw_margin_one_correction: its refined reciprocal is the correctly rounded one).  For
