@@ -260,9 +260,11 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_tag_duo_kernel(cons
     float *s_rew = reinterpret_cast<float *>(s_mhi + kWave);               // [64] (wave O)
     float2 *s_lm_p = reinterpret_cast<float2 *>(s_rew + kWave);            // [epw * L] wave P's landmarks
     float2 *s_lm_o = s_lm_p + P.epw * L;                                   // [epw * L] wave O's landmarks
+    // [4][64] wave P's action indices, fetched four steps ahead by LDS-direct loads (pw_common.hpp act_fetch_issue)
+    int32_t *s_act = reinterpret_cast<int32_t *>(smem_raw + ((3 * kWave * sizeof(float4) + 3 * kWave * sizeof(float) +
+                                                              2 * (size_t)P.epw * L * sizeof(float2) + 15) & ~(size_t)15));
     // [64][D] the wave's observation rows, staged for the block-wise store (only when P.obs_block; 16-byte aligned)
-    float *s_rows = reinterpret_cast<float *>(smem_raw + ((3 * kWave * sizeof(float4) + 3 * kWave * sizeof(float) +
-                                                          2 * (size_t)P.epw * L * sizeof(float2) + 15) & ~(size_t)15));
+    float *s_rows = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(s_act) + kActRingBytes);
 
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = (int)threadIdx.x & 63;
@@ -311,15 +313,27 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_tag_duo_kernel(cons
         };
         near_pass(s_ring + base);
         const float k = P.contact_margin, cf = P.contact_force, dt = P.dt, damp = P.damp, mass = P.mass;
-        int act_next = P.act[g];
+        // Action indices: four steps ahead by LDS-direct loads, as in pw_spread_quad_kernel.  Stamps at C3 (B = 8192,
+        // profiles/r3_tag_prefetch.txt): the index loaded ONE step ahead into a register still cost this wave 1020 of its
+        // 3140 cycles per step -- HBM latency under the output waves' write stream exceeds a step.  This wave has no other
+        // vector memory operation in its loop; every load the compiler counts is consumed before the first fetch.
+        const int32_t *act_g = P.act + g;
+        const uint32_t act_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(s_act));
+        auto fetch_act = [&](int t) {  // indices of step t (clamped: the tail re-fetches the last step) -> slot t & 3
+            act_fetch_issue(act_g + (size_t)(t < T ? t : T - 1) * BN, act_lds + (uint32_t)(t & 3) * (kWave * 4));
+        };
+        // Measured over B (profiles/r3_tag_prefetch.txt): B = 8192 -7 %, 4096 -13 %; 16384 ... 65536 unchanged (several
+        // workgroups per SIMD already cover the load); only a chip that is not full pays (B = 2048: +3.7 %).  One form for
+        // every grid: a run-time choice between the two fetches inside this loop compiled badly (the counted load's wait then
+        // also drains the other form's fetches: 1.82 instead of 1.37 us per step at C3).
+        asm volatile("" :: "v"(ep_step), "v"(ep_count), "v"(px), "v"(py), "v"(vx), "v"(vy), "v"(near_a), "v"(near_l) : "memory");
+        fetch_act(0); fetch_act(1); fetch_act(2); fetch_act(3);
         PW_STAMP_DECL;
         for (int t = 0; t < T; ++t) {
             PW_STAMP_START;
-            const int ai = act_next;
-            {
-                const int tn = t + 1 < T ? t + 1 : t;
-                act_next = P.act[(size_t)tn * BN + g];
-            }
+            act_fetch_wait3();  // step t's indices are in LDS
+            const int ai = s_act[(t & 3) * kWave + lane];
+            fetch_act(t + 4);   // into the slot just read
             float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
             float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
             ux *= my_sens; uy *= my_sens;
@@ -385,6 +399,7 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_tag_duo_kernel(cons
             near_pass(s_ring + cur * kWave + base);
             PW_STAMP(4);
         }
+        act_fetch_drain();  // the tail's fetches have landed before the wave ends
         PW_STAMP_FLUSH;
         P.pos_x[g] = px; P.pos_y[g] = py;
         P.vel_x[g] = vx; P.vel_y[g] = vy;

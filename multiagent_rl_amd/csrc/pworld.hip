@@ -304,7 +304,8 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         // two waves per env group, as for simple_spread.  With the block-wise observation stores (below) the duo form
         // leads on every grid measured: B = 8192: 1.69 vs 2.41 us per step, B = 65536: 10.3 vs 19.0 (profiles/r2_tag_block.txt)
         const bool duo = dp.duo < 0 ? grid.x <= 8192 : dp.duo != 0;
-        size_t shm2 = 3 * kWave * sizeof(float4) + 3 * kWave * sizeof(float) + 2 * (size_t)kp.epw * kp.L * sizeof(float2);
+        size_t shm2 = ((3 * kWave * sizeof(float4) + 3 * kWave * sizeof(float) + 2 * (size_t)kp.epw * kp.L * sizeof(float2) + 15) &
+                       ~(size_t)15) + kActRingBytes;  // ring, masks, rewards, both waves' landmarks | wave P's action ring
         // Block-wise observation stores of the duo kernel (rows staged in LDS): short rows only (LDS), chunks of 4 floats
         // when every wave's block starts and ends on 16 bytes, else of 2 (D is even).  pw_dispatch.obs_block overrides.
         A.obs_block = 0;
@@ -318,7 +319,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
                 const bool v4 = ((size_t)kp.B * kp.N * kp.D) % 4 == 0 && ((size_t)kp.epw * kp.N * kp.D) % 4 == 0 &&
                                 (reinterpret_cast<uintptr_t>(io->obs) & 15) == 0 && kp.B % kp.epw == 0;
                 A.obs_block = v4 ? 4 : 2;
-                shm2 = ((shm2 + 15) & ~(size_t)15) + (size_t)kWave * kp.D * sizeof(float);
+                shm2 += (size_t)kWave * kp.D * sizeof(float);
             }
         }
         // Three waves per env group (the output wave split into a rewards wave and an observation wave) where the single
