@@ -213,8 +213,8 @@ size_t pw_algorithmic_bytes_per_env_step(const pw_handle *h);
  *     experiments/run.py:39-41; head_width = {5, dim_c} sizes the one-hot rows pw_replay_gather returns
  *     (head_width[0] = 0 means 5);
  *   per_agent = 1: rew and done are [cap,N] f32 -- the BiCNet tuple of experiments/run_BIC.py:46,50.
- * pw_replay_add and pw_replay_gather serve every variant; the chunk / tail / packed / wire entry points and the
- * pw_policy_rollout sink take the plain ring only (PW_EINVAL otherwise). */
+ * pw_replay_add and pw_replay_gather serve every variant, pw_replay_add_rollout the plain and the two-head ring; the tail /
+ * packed / wire entry points and the pw_policy_rollout sink take the plain ring only (PW_EINVAL otherwise). */
 typedef struct pw_replay_store {
     float *obs, *next_obs, *rew, *done;
     uint8_t *act;
@@ -251,7 +251,8 @@ int pw_replay_add_tail(const pw_replay_store *st, int64_t start, const int64_t *
 /* A whole rollout chunk (pw_policy_rollout / pw_rollout outputs, [T, ...]) into the ring in one launch: transition
  * (t, e) goes to slot (start + t*B + e) % capacity -- the order of T pw_replay_add calls -- with obs = obs0 [B,N,D]
  * for t = 0 and the chunk's obs[t-1] after that, next_obs = final_obs where terminal.  io needs obs, rew_shared,
- * terminal (final_obs optional); act [T,B,N] int32.  episode_return / finished_sum / finished_count / scratch
+ * terminal (final_obs optional); act [T,B,N] int32 ([T,B,N,2] for a two-head ring, st->act_heads = 2: the MultiDiscrete chunks
+ * of pw_policy_rollout on simple_reference).  episode_return / finished_sum / finished_count / scratch
  * (all or none): the chunk's episode-return bookkeeping, as T pw_episode_stats calls up to float64 summation
  * order (fixed, so reproducible); scratch = pw_replay_add_rollout_scratch_bytes(B) device bytes, zeroed once. */
 int pw_replay_add_rollout(const pw_replay_store *st, int64_t start, int32_t B, int32_t T, const float *obs0,
@@ -382,7 +383,11 @@ typedef struct pw_rollout_sink {
  * the results equal a loop of pw_actor_fused + pw_step (+ pw_replay_add_tail).
  * simple_spread fast-path configurations (local observation, homogeneous agents, L <= N; observation rows up to
  * D = 64, i.e. N <= 30) and simple_tag with homogeneous roles (9 <= D <= 48; good agents' rows zero-padded to D), one
- * 5-logit head; weights as for pw_actor_fused. */
+ * 5-logit head; weights as for pw_actor_fused.
+ * simple_reference (the MultiDiscrete scenario of main.py:24,52-54; 3 landmarks, D = 21): the two-head actor -- w2 [5 + PW_DIM_C,
+ * 64] / b2 = dense2_1 and dense2_2 concatenated, one Gumbel-argmax per head exactly as pw_actor_fused(n_out0 = 5, n_out1 =
+ * PW_DIM_C) -- and act_out [num_steps,B,N,2] = (movement, symbol); no ring sink (sink must be NULL: the chunk goes into a
+ * two-head ring with pw_replay_add_rollout); results equal a loop of pw_actor_fused + pw_step(act_idx, act_comm). */
 int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
                       const float *w_hh_bw, const float *w2, const float *b2, int32_t relu_out, uint64_t seed,
                       uint64_t step, const int64_t *step_dev /* device, or NULL */, const pw_step_io *io,

@@ -18,6 +18,20 @@ struct pw_handle {
 
 namespace {
 
+// kernel parameter block of the communication scenarios (pw_kernels_reference.hpp) from a handle
+RefParams ref_params(const pw_handle *h)
+{
+    const KParams &kp = h->kp;
+    RefParams R;
+    std::memset(&R, 0, sizeof(R));
+    R.B = kp.B; R.L = kp.L; R.D = kp.D; R.max_episode_len = kp.max_episode_len; R.auto_reset = kp.auto_reset;
+    R.force_discrete = kp.force_discrete; R.seed = kp.seed; R.env_id_base = kp.env_id_base;
+    R.dt = kp.dt; R.damp = kp.damp; R.mass = kp.mass; R.sens = kp.agent_sens[0];
+    R.pos_x = kp.pos_x; R.pos_y = kp.pos_y; R.vel_x = kp.vel_x; R.vel_y = kp.vel_y; R.lm_x = kp.lm_x; R.lm_y = kp.lm_y;
+    R.comm = h->comm; R.goal = h->goal; R.ep_step = kp.ep_step; R.ep_count = kp.ep_count;
+    return R;
+}
+
 int check_ready(const pw_handle *h)
 {
     if (!h) return fail(PW_EINVAL, "null handle");

@@ -1,0 +1,141 @@
+// pw_kernels_policy_ref.hpp -- part of libpworld.so (translation unit csrc/pworld_policy.hip).
+// Policy-in-the-loop rollout as ONE launch for simple_reference, the MultiDiscrete scenario of the reference's sweep
+// (main.py:24, :52-54: a two-head actor [5 movement | 10 communication logits]; experiments/run.py:39-41 concatenates
+// the heads' one-hots into the env action).
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// T x (two-head actor forward + one Gumbel-argmax per head + environment step + auto-reset) per workgroup of 16
+// environments (32 observation rows: N = 2), observations / sampled (movement, symbol) pairs / world state resident on the
+// CU between steps -- the simple_reference counterpart of pw_policy_rollout_kernel.  The actor pass is actor_forward_wg
+// (the arithmetic and Philox keying of pw_actor_fused with n_out0 = 5, n_out1 = 10); the environment step is
+// pw_reference_rollout_kernel's arithmetic on the workgroup's first wave (lane = (env, agent), the partner is lane ^ 1,
+// every exchange a shuffle), so the results equal the loop "act = pw_actor_fused(obs); pw_step(act)" bit for bit.
+// Outputs as pw_rollout's; act_out [T,B,N,2] int32 = (movement index, symbol index).
+// ------------------------------------------------------------------------------------------
+struct PolicyRolloutRefArgs {
+    ActorFusedArgs A;   // weights, B, N = 2, D = 21, E, heads (5, dim_c), seed, step / step_dev (Philox step of the FIRST pass)
+    RefParams V;        // world constants and state planes
+    int T;
+    int32_t *act_out;   // [T,B,N,2] (or NULL)
+    float *obs, *final_obs, *rew, *rew_shared;
+    uint8_t *done, *terminal;
+};
+
+template <int S1C>
+__global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const PolicyRolloutRefArgs P)
+{
+    constexpr int DC = kDimC, N = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const ActorFusedArgs &A = P.A;
+    const RefParams &V = P.V;
+    const ActorLds S = actor_carve(smem_raw, 4 * S1C);
+    const int D = A.D;
+    float *s_obs = reinterpret_cast<float *>(S.end);                       // [96][D] observation rows
+    int32_t *s_act = reinterpret_cast<int32_t *>(s_obs + kFusedRows * D);  // [96][2] (movement, symbol)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long env0 = (long)blockIdx.x * A.E;
+    const int envs_here = (int)((long)A.B - env0 < (long)A.E ? (long)A.B - env0 : (long)A.E);
+    const int rows_here = envs_here * N;
+    const long row_base = env0 * N;
+    const size_t BN = (size_t)A.B * N;
+
+    // ---- environment lanes: wave 0, lane = el * 2 + a (E <= 16 envs: 32 lanes)
+    const bool env_wave = wave == 0;
+    int el = lane >> 1;
+    const int a = lane & 1;
+    const bool live = env_wave && el < envs_here;
+    if (!live) el = 0;                  // idle lanes shadow env 0 of the workgroup (same agent parity: shuffles stay paired)
+    const int r = el * N + a;
+    const int env = (int)(env0 + el);
+    const size_t g = (size_t)env * N + a;
+    RefLane<DC> s;
+    int ep_step = 0;
+    uint32_t ep_count = 0;
+    if (env_wave) {
+        ref_load<DC>(V, env, a, s);
+        ep_step = V.ep_step[env];
+        ep_count = V.ep_count[env];
+        float co[DC];
+#pragma unroll
+        for (int q = 0; q < DC; ++q) co[q] = __shfl_xor(s.c[q], 1, kWave);
+        if (live) ref_write_obs<DC, false>(V, s, co, a, s_obs + r * D);
+    }
+    const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
+    wg_lds_barrier();
+
+    for (int t = 0; t < P.T; ++t) {
+        // ---- policy: observation rows (LDS) -> one sampled index per head and row (LDS)
+        actor_forward_wg<S1C>(A, S, s_obs, rows_here, envs_here, row_base, t == 0, t == 0, step0 + (uint64_t)t, nullptr, s_act);
+        wg_lds_barrier();
+        // ---- environment step (pw_reference_rollout_kernel's arithmetic, index actions)
+        if (env_wave) {
+            const size_t row = (size_t)t * BN + g;
+            const int ai = s_act[2 * r], ci = s_act[2 * r + 1];
+            const float a1 = ai == 1, a2 = ai == 2, a3 = ai == 3, a4 = ai == 4;
+            float cn[DC];
+#pragma unroll
+            for (int q = 0; q < DC; ++q) cn[q] = q == ci ? 1.0f : 0.0f;
+            {
+                float ux = 0.0f + (a1 - a2), uy = 0.0f + (a3 - a4);
+                ux *= V.sens; uy *= V.sens;
+                const float fx = ux + 0.0f, fy = uy + 0.0f;
+                s.vx = s.vx * V.damp; s.vy = s.vy * V.damp;
+                s.vx = s.vx + (fx / V.mass) * V.dt;
+                s.vy = s.vy + (fy / V.mass) * V.dt;
+                s.px = s.px + s.vx * V.dt;
+                s.py = s.py + s.vy * V.dt;
+            }
+#pragma unroll
+            for (int q = 0; q < DC; ++q) s.c[q] = cn[q] + 0.0f;
+            const float ox = __shfl_xor(s.px, 1, kWave), oy = __shfl_xor(s.py, 1, kWave);
+            float co[DC];
+#pragma unroll
+            for (int q = 0; q < DC; ++q) co[q] = __shfl_xor(s.c[q], 1, kWave);
+            float glx = s.lmx[0], gly = s.lmy[0];
+            if (s.goal == 1) { glx = s.lmx[1]; gly = s.lmy[1]; }
+            if (s.goal == 2) { glx = s.lmx[2]; gly = s.lmy[2]; }
+            const float dx = ox - glx, dy = oy - gly;
+            const float rw = -(dx * dx + dy * dy);
+            const float r_other = __shfl_xor(rw, 1, kWave);
+            const float acc = (0.0f + (a == 0 ? rw : r_other)) + (a == 0 ? r_other : rw);  // agent order
+            ep_step += 1;
+            const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
+            if (live) {
+                if (P.act_out) { P.act_out[2 * row] = ai; P.act_out[2 * row + 1] = ci; }
+                if (P.rew) P.rew[row] = rw;
+                if (P.done) P.done[row] = 0;
+                if (a == 0) {
+                    if (P.rew_shared) P.rew_shared[(size_t)t * A.B + env] = acc;
+                    if (P.terminal) P.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+                }
+            }
+            if (term && V.auto_reset) {
+                if (live && P.final_obs) ref_write_obs<DC, false>(V, s, co, a, P.final_obs + row * D);
+                ep_count += 1;
+                ep_step = 0;
+                ref_reset<DC, false>(V, V.env_id_base + (uint64_t)env, ep_count, a, s);
+#pragma unroll
+                for (int q = 0; q < DC; ++q) co[q] = 0.f;  // the other agent reset too
+            }
+            if (live) {
+                if (P.obs) ref_write_obs<DC, false>(V, s, co, a, P.obs + row * D);
+                ref_write_obs<DC, false>(V, s, co, a, s_obs + r * D);
+            }
+        } else if (t + 1 < P.T) {
+            // the other waves fetch the next pass's forward-direction weights meanwhile (their LDS tiles are idle)
+            actor_fill_dir(A, S, 0, tid - kWave, 7 * kWave);
+        }
+        wg_lds_barrier();
+    }
+    if (live) {
+        ref_store<DC>(V, env, a, s);
+        if (a == 0) { V.ep_step[env] = ep_step; V.ep_count[env] = ep_count; }
+    }
+}
+
+}  // namespace

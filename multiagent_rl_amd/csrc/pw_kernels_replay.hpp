@@ -144,7 +144,8 @@ __global__ void __launch_bounds__(256) pw_replay_add_rollout_kernel(const pw_rep
             st.obs[slot * ND + c] = t == 0 ? obs0[rem] : io.obs[i - per_step];
             const bool fin = io.final_obs && io.terminal[te];
             st.next_obs[slot * ND + c] = fin ? io.final_obs[i] : io.obs[i];
-            if (c < (size_t)N) st.act[slot * N + c] = (uint8_t)act[te * N + c];
+            const size_t NA = (size_t)N * (st.act_heads == 2 ? 2 : 1);  // two-head ring: act [cap,N,2], chunk act [T,B,N,2]
+            if (c < NA) st.act[slot * NA + c] = (uint8_t)act[te * NA + c];
             if (c == 0) {
                 st.rew[slot] = io.rew_shared[te];
                 st.done[slot] = 0.0f;

@@ -55,19 +55,6 @@ int obs_dim_of(const pw_config &c)
     return 4 + 2 * L + 2 * (N - 1) + 2 * (c.num_adversaries > 0 ? G : G - 1);
 }
 
-RefParams ref_params(const pw_handle *h)
-{
-    const KParams &kp = h->kp;
-    RefParams R;
-    std::memset(&R, 0, sizeof(R));
-    R.B = kp.B; R.L = kp.L; R.D = kp.D; R.max_episode_len = kp.max_episode_len; R.auto_reset = kp.auto_reset;
-    R.force_discrete = kp.force_discrete; R.seed = kp.seed; R.env_id_base = kp.env_id_base;
-    R.dt = kp.dt; R.damp = kp.damp; R.mass = kp.mass; R.sens = kp.agent_sens[0];
-    R.pos_x = kp.pos_x; R.pos_y = kp.pos_y; R.vel_x = kp.vel_x; R.vel_y = kp.vel_y; R.lm_x = kp.lm_x; R.lm_y = kp.lm_y;
-    R.comm = h->comm; R.goal = h->goal; R.ep_step = kp.ep_step; R.ep_count = kp.ep_count;
-    return R;
-}
-
 bool is_comm_scenario(int scenario) { return scenario == PW_SIMPLE_REFERENCE || scenario == PW_SIMPLE_SPEAKER_LISTENER; }
 int dim_c_of(int scenario) { return scenario == PW_SIMPLE_REFERENCE ? PW_DIM_C : scenario == PW_SIMPLE_SPEAKER_LISTENER ? PW_SL_DIM_C : 0; }
 
@@ -882,10 +869,11 @@ int pw_replay_add_rollout(const pw_replay_store *st, int64_t start, int32_t B, i
                           int64_t *finished_count, void *scratch, void *stream)
 {
     if (!st || !obs0 || !io || !act || !io->obs || !io->rew_shared || !io->terminal) return fail(PW_EINVAL, "null argument");
-    if (int rc = plain_ring_only(st, "pw_replay_add_rollout")) return rc;
+    if (st->per_agent) return fail(PW_EINVAL, "pw_replay_add_rollout: per-agent rings are served by pw_replay_add and pw_replay_gather only");
     if (st->capacity < 1 || B < 1 || T < 1 || (int64_t)B * T > st->capacity || start < 0)
         return fail(PW_EINVAL, "bad ring arguments (the chunk must fit the ring)");
     if (st->obs_dim < 5) return fail(PW_EINVAL, "obs_dim must be >= 5");
+    if (st->act_heads == 2 && st->num_agents * st->obs_dim < 2 * st->num_agents) return fail(PW_EINVAL, "two-head ring: rows too short");
     if (episode_return && (!finished_sum || !finished_count || !scratch))
         return fail(PW_EINVAL, "bookkeeping needs episode_return, finished_sum, finished_count and scratch");
     const size_t total = (size_t)T * B * st->num_agents * st->obs_dim;

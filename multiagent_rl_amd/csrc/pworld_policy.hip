@@ -19,10 +19,12 @@
 #include "pw_common.hpp"
 #include "pw_kernels_spread.hpp"
 #include "pw_kernels_tag.hpp"
+#include "pw_kernels_reference.hpp"
 #include "pw_handle.hpp"
 #include "pw_kernels_policy.hpp"
 #include "pw_kernels_policy2.hpp"
 #include "pw_kernels_policy_tag.hpp"
+#include "pw_kernels_policy_ref.hpp"
 
 extern "C" {
 
@@ -99,6 +101,40 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     if (!frag || !b1 || !b_ih || !w_hh_fw || !w_hh_bw || !w2 || !b2 || !io) return fail(PW_EINVAL, "null argument");
     if (num_steps < 1) return fail(PW_EINVAL, "num_steps must be >= 1");
     const KParams &kp = h->kp;
+    if (h->cfg.scenario == PW_SIMPLE_REFERENCE) {
+        // the MultiDiscrete scenario: two-head actor [5 | PW_DIM_C] (w2 [15,64], b2 [15]), act_out [T,B,N,2]
+        if (sink) return fail(PW_EINVAL, "pw_policy_rollout on simple_reference has no ring sink (the two-head ring is filled by "
+                                         "pw_replay_add_rollout from the chunk's outputs)");
+        if (io->act_idx || io->act_vec || io->act_comm || io->coll)
+            return fail(PW_EINVAL, "pw_policy_rollout produces the actions itself (act_out) and has no coll output");
+        if (!act_out || !io->obs || !io->rew || !io->rew_shared || !io->done || !io->terminal)
+            return fail(PW_EINVAL, "act_out and the obs, rew, rew_shared, done, terminal outputs are required");
+        if ((reinterpret_cast<uintptr_t>(io->obs) | reinterpret_cast<uintptr_t>(io->final_obs) | reinterpret_cast<uintptr_t>(frag) |
+             reinterpret_cast<uintptr_t>(w_hh_fw) | reinterpret_cast<uintptr_t>(w_hh_bw)) & 15)
+            return fail(PW_EINVAL, "obs, final_obs, frag and w_hh must be 16-byte aligned");
+        PolicyRolloutRefArgs R;
+        std::memset(&R, 0, sizeof(R));
+        ActorFusedArgs &ra = R.A;
+        ra.frag = frag; ra.b1 = b1; ra.bih = b_ih; ra.whh_f = w_hh_fw; ra.whh_r = w_hh_bw; ra.w2 = w2; ra.b2 = b2;
+        ra.B = kp.B; ra.N = 2; ra.D = kp.D; ra.relu_out = relu_out; ra.n_out0 = 5; ra.n_out1 = PW_DIM_C;
+        ra.E = 16;
+        ra.seed = seed; ra.step = step; ra.step_dev = step_dev;
+        R.V = ref_params(h);
+        R.T = num_steps; R.act_out = act_out;
+        R.obs = io->obs; R.final_obs = io->final_obs; R.rew = io->rew; R.rew_shared = io->rew_shared;
+        R.done = io->done; R.terminal = io->terminal;
+        const int rS1C = (kp.D + 7) / 8;
+        if (rS1C != 3) return fail(PW_EINVAL, "simple_reference one-launch rollout: the observation is 21 numbers (3 landmarks)");
+        const size_t rshm = actor_lds_bytes(4 * rS1C) + (size_t)kFusedRows * kp.D * sizeof(float) + 2 * kFusedRows * sizeof(int32_t);
+        static unsigned long long attr_set = 0; /* bit = device */
+        if (lds_optin_needed(&attr_set))
+            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_ref_kernel<3>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((pw_policy_rollout_ref_kernel<3>), dim3((unsigned)((kp.B + 15) / 16)), dim3(512), rshm,
+                           static_cast<hipStream_t>(stream), R);
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
     const bool tag = h->cfg.scenario == PW_SIMPLE_TAG && h->tag_fast;
     if (!h->fast && !tag)
         return fail(PW_EINVAL, "pw_policy_rollout serves the simple_spread fast-path configurations (local observation, "

@@ -226,15 +226,22 @@ class FusedActor(object):
         ``stats`` = (episode_return [B], finished_sum, finished_count) tensors: the episode bookkeeping too.  With a
         sink, ``out=False`` skips the step outputs altogether (only the ring / statistics are written)."""
         from ._lib import PwRolloutSink, PwStepIO
-        assert len(self.heads) == 1 and self.heads[0] == 5, 'single 5-logit head only'
         T, B, N = int(num_steps), env.num_envs, env.n
+        two = len(self.heads) == 2   # MultiDiscrete actor: simple_reference, act [T,B,N,2] = (movement, symbol), no ring sink
+        if two:
+            assert env.scenario_name == 'simple_reference' and self.heads == (5, env.dim_c), \
+                'two-head rollouts serve simple_reference (heads 5 | dim_c)'
+            assert memory is None and stats is None and out is not False, \
+                'simple_reference: no ring sink in the launch; append the chunk with ReplayBuffer.add_rollout'
+        else:
+            assert self.heads == (5,), 'single 5-logit head only' 
         if out is False:
             assert memory is not None or stats is not None
             out = {}
         else:
             out = env.alloc_outputs(T, coll=False) if out is None else out
             if 'act' not in out:
-                out['act'] = torch.empty(T, B, N, dtype=torch.int32, device=self.device)
+                out['act'] = torch.empty((T, B, N, 2) if two else (T, B, N), dtype=torch.int32, device=self.device)
         io = PwStepIO()
         for name in ('obs', 'final_obs', 'rew', 'rew_shared', 'done', 'terminal'):
             t = out.get(name)

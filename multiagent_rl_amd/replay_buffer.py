@@ -274,6 +274,8 @@ class ReplayBuffer(object):
                 setattr(io, name, t.data_ptr())
         act = out['act']
         assert act.dtype == torch.int32 and act.is_contiguous() and obs0.is_contiguous() and obs0.dtype == torch.float32
+        assert tuple(act.shape) == ((T, B, N, 2) if len(self.act_heads) == 2 else (T, B, N)), \
+            'chunk actions must be [T,B,N] ([T,B,N,2] for a two-head ring)' 
         scratch = None
         if episode_return is not None:
             if getattr(self, '_roll_scratch_B', None) != B:

@@ -261,9 +261,22 @@ class BatchedRollout(object):
         assert self._graph is None and hasattr(self.policy, 'rollout')
         stats = (self.episode_return, self.finished_return_sum, self.finished_episodes)
         done_steps = 0
+        two_head = len(getattr(self.policy, 'heads', (5,))) == 2
         while done_steps < num_steps:
             T = min(chunk, num_steps - done_steps)
-            if keep_outputs:
+            if two_head:
+                # MultiDiscrete (simple_reference): the launch has no ring sink; the chunk's outputs go into the two-head ring
+                # and the episode statistics with ONE more launch (pw_replay_add_rollout): 2 launches per chunk
+                obs0 = self.obs if done_steps == 0 else self.last_chunk['obs'][-1].clone()
+                if getattr(self, '_chunk_T', None) != T:
+                    self._chunk_T, self.last_chunk = T, None
+                self.last_chunk = self.policy.rollout(self.env, T, self.last_chunk)
+                if self.memory is not None:
+                    self.memory.add_rollout(obs0, self.last_chunk, *stats)
+                else:
+                    for t in range(T):
+                        self._bookkeeping(self.last_chunk['rew_shared'][t], self.last_chunk['terminal'][t])
+            elif keep_outputs:
                 if getattr(self, '_chunk_T', None) != T:
                     self._chunk_T, self.last_chunk = T, None
                 self.last_chunk = self.policy.rollout(self.env, T, self.last_chunk, memory=self.memory, stats=stats)

@@ -877,3 +877,79 @@ def test_exchanges_on_real_rccl_single_rank():
         assert torch.equal(o, first) and (a.sum(-1) == 1).all()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('B,T', [(4096, 27), (100, 55), (37, 30), (16, 3), (17, 26)])
+def test_one_launch_policy_rollout_simple_reference_equals_the_step_loop(B, T):
+    """The MultiDiscrete scenario of the reference's sweep (main.py:24,52-54; run.py:39-41) with the two-head actor in the loop
+    as ONE launch: pw_policy_rollout on simple_reference vs the loop of FusedActor() + env.step((movement, symbol)) --
+    identical sampled pairs, observations (incl. the partner's spoken symbol), rewards, terminals, pre-reset observations,
+    final world / communication state, across auto-resets and ragged batches; a second chunk continues both."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    torch.manual_seed(6)
+    mk = lambda: make_batched_env('simple_reference', B, auto_reset=True, max_episode_len=25, seed=17)  # noqa: E731
+    env_a, env_b = mk(), mk()
+    actor = ActorNetwork(env_a.obs_dim, [5, 10]).cuda().eval()
+    loop, one = FusedActor(actor, seed=9), FusedActor(actor, seed=9)
+    obs = env_a.reset()
+    env_b.reset()
+
+    def run_loop(steps):
+        nonlocal obs
+        want = dict(obs=[], act=[], rew=[], rew_shared=[], terminal=[], final_obs=[])
+        for t in range(steps):
+            act = loop(obs)
+            assert act.shape == (B, 2, 2)
+            obs, rew, done, info = env_a.step(act)
+            for k, v in (('obs', obs), ('act', act), ('rew', rew), ('rew_shared', info['rew_shared']),
+                         ('terminal', info['terminal']), ('final_obs', info['final_obs'])):
+                want[k].append(v.clone())
+        return {k: torch.stack(v) for k, v in want.items()}
+
+    for chunk in (T, 7):
+        want = run_loop(chunk)
+        got = one.rollout(env_b, chunk)
+        assert got['act'].shape == (chunk, B, 2, 2) and int(got['act'][..., 1].max()) > 4      # symbols use the 10-wide head
+        for k in ('act', 'obs', 'rew', 'rew_shared', 'terminal'):
+            assert torch.equal(got[k], want[k]), k
+        term = got['terminal']
+        if term.any():
+            assert torch.equal(got['final_obs'][term], want['final_obs'][term])
+        assert not got['done'].any()
+        sa, sb = env_a.get_state(), env_b.get_state()
+        for k in ('pos', 'vel', 'landmarks', 'ep_step', 'ep_count', 'comm', 'goal'):
+            assert torch.equal(sa[k], sb[k]), k
+    assert one.calls == loop.calls == T + 7
+
+
+def test_collect_one_launch_multidiscrete_fills_the_two_head_ring_like_the_step_loop():
+    """BatchedRollout.collect_one_launch on simple_reference (pw_policy_rollout + pw_replay_add_rollout into a ring built with
+    act_heads = (5, 10): 2 launches per chunk) vs BatchedRollout.collect (3 launches per step): identical ring contents
+    (wrapping), cursor, final observation and state; statistics equal up to float64 summation order."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    from multiagent_rl_amd.rollout import BatchedRollout
+    torch.manual_seed(0)
+    B = 150
+    res = []
+    actor = None
+    for one in (False, True):
+        env = make_batched_env('simple_reference', B, auto_reset=True, max_episode_len=25, seed=3)
+        if actor is None:
+            actor = ActorNetwork(env.obs_dim, [5, 10]).cuda().eval()
+        mem = ReplayBuffer(B * 40, 2, env.obs_dim, act_heads=(5, 10))              # 57 steps into 40 slots-of-B: wraps
+        ro = BatchedRollout(env, FusedActor(actor, seed=7), mem)
+        if one:
+            ro.collect_one_launch(57, chunk=20)                                     # chunks of 20, 20, 17
+        else:
+            ro.collect(57)
+        st = ro.stats()
+        assert st['env_steps'] == 57 * B and st['episodes'] == 2 * B and len(mem) == B * 40
+        assert mem._next_idx == (57 * B) % (B * 40)
+        res.append((mem.obs.clone(), mem.next_obs.clone(), mem.act.clone(), mem.rew.clone(), mem.done.clone(),
+                    ro.obs.clone(), env.get_state()['pos'].clone(), ro.episode_return.clone(), st['mean_episode_reward']))
+    for a, b in zip(res[0][:8], res[1][:8]):
+        assert torch.equal(a, b)
+    assert abs(res[0][8] - res[1][8]) < 1e-9 * abs(res[0][8])
