@@ -616,9 +616,10 @@ OTHER_CONFIGS = (
 )
 
 
-def measure_rollout(env, dev, T, K, W, ring_cap_bytes=64e9):
-    """The headline's method for any env: K pw_rollout launches of T steps, timed by ONE HIP-event pair on the launch
-    stream after W untimed ones, every output written, a ring of output buffers reused round-robin (up to 4 slots)."""
+def measure_rollout(env, dev, T, K, W, ring_cap_bytes=64e9, ramp_ms=60.0):
+    """The headline's method for any env: the same launch untimed for ramp_ms (clock ramp), a reset, then K pw_rollout
+    launches of T steps timed by ONE HIP-event pair on the launch stream after W untimed ones; every output written, a
+    ring of output buffers reused round-robin (up to 4 slots)."""
     import torch
     B, N, D = env.num_envs, env.n, env.obs_dim
     slot_bytes = T * B * N * (2 * D * 4 + 4 + 4 + 1) + T * B * 5
@@ -627,6 +628,12 @@ def measure_rollout(env, dev, T, K, W, ring_cap_bytes=64e9):
     outs = env.alloc_outputs(ring * T, coll=False)
     launches = [env.plan_rollout(acts[i * T:(i + 1) * T], {k: v[i * T:(i + 1) * T] for k, v in outs.items()})
                 for i in range(ring)]
+    env.reset()
+    t_r = time.perf_counter()
+    while (time.perf_counter() - t_r) * 1e3 < ramp_ms:
+        for i in range(4):
+            launches[i % ring]()
+        torch.cuda.synchronize()
     env.reset()
     for i in range(W):
         launches[i % ring]()
