@@ -188,6 +188,10 @@ void setup_fast_path(pw_handle *h)
     h->fast = true;
 }
 
+#ifndef PW_N3_TRIO_HI
+#define PW_N3_TRIO_HI 600   // workgroups (C5 N = 3 at B = 4096: 512 of 8 envs): measured B = 1024 ... 4096: -6.5 % step time
+#endif
+
 void dispatch_defaults(pw_dispatch *d)
 {
     std::memset(d, 0, sizeof(*d));
@@ -398,6 +402,16 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
             const bool trio_inst = key == 6 || key == 9 || key == 12 || key == 24 || key == 48;
             bool trio = um && blk && !wc && key >= 12 && trio_inst && grid.x >= 512 && grid.x <= 1280;
             if (dp.trio >= 0) trio = um && blk && !wc && trio_inst && dp.trio != 0;
+            // N = L = 3 with row-wise stores on grids that do not fill the chip (C5's N = 3 point: 256 workgroups): the single
+            // output wave (rewards 730 + rows 560 busy cycles) is longer than the physics wave (1210), and there are idle SIMDs
+            // for a third wave: its own three-wave instantiation (profiles/r3_n3_trio.txt).  pw_dispatch.trio overrides.
+            const bool trio3 = key == 3 && um && !blk && !wc && (dp.trio >= 0 ? dp.trio != 0 : grid.x <= PW_N3_TRIO_HI);
+            if (trio3) {
+                if (dp.p_prio < 0) A.p_prio = 3;
+                PW_LAUNCH(h, (pw_spread_duo_kernel<3, 3, true, false, false, true>), grid, dim3(3 * kWave), shm2, st, A, T);
+                PW_HIP_CHECK(hipGetLastError());
+                return PW_OK;
+            }
             if (trio && dp.p_prio < 0) A.p_prio = 3 | (3 << 4);  // three waves: physics and observation wave first (N = 12: -2.5 %)
             const dim3 block2((trio ? 3 : 2) * kWave);
             if (wc) {

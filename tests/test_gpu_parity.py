@@ -141,8 +141,8 @@ def kernel_path(request):
     'duo+block' / 'stream+block' force the block-wise observation stores large grids use (default here: only N >= 12,
     the test batches being small), '-dense' then gives 60- and 63-row blocks;
     'trio' / 'trio+block' the three-wave variants of the duo kernels -- what BASELINE configs[2] (simple_tag, B = 8192)
-    and the N = 12 point of configs[4] dispatch by default: simple_tag in both, simple_spread in its block-store form
-    ('trio+block', N >= 6; 'trio' alone is the two-wave form there).
+    and the N = 3 / N = 12 points of configs[4] dispatch by default: simple_tag in both, simple_spread N = 3 with row-wise stores
+    ('trio'), N >= 6 in its block-store form ('trio+block'; 'trio' alone is the two-wave form there).
     simple_tag has three: pw_tag_duo_kernel ('duo', 'trio'), pw_tag_stream_kernel ('stream') and the generic kernel
     ('fast'/'generic').
     Small batches are spread over ~512 workgroups (few envs per wave); '-dense' forces the packing large batches
@@ -611,7 +611,7 @@ def test_bench_path_full_size_every_output_bitwise(case, disp, kernel, kernel_co
 
 
 @pytest.mark.parametrize('case, kernel', [
-    (dict(scenario='simple_spread', num_agents=3, num_envs=4096), 'pw_spread_duo_kernel<3,3,true>'),
+    (dict(scenario='simple_spread', num_agents=3, num_envs=4096), 'pw_spread_duo_kernel<3,3,true,false,false,true>'),   # three waves, row-wise stores
     (dict(scenario='simple_spread', num_agents=12, num_envs=4096), 'pw_spread_duo_kernel<12,12,true,false,true,true>'),  # three waves
     (dict(scenario='simple_spread', num_agents=24, num_envs=4096), 'pw_spread_duo_kernel<24,24,true,false,true>'),
     (dict(scenario='simple_spread', num_agents=48, num_envs=4096), 'pw_spread_duo_kernel<48,48,true,false,true>'),
@@ -705,7 +705,7 @@ def test_quad_kernel_equals_duo_with_desynchronised_episode_clocks(B, ep_len):
 @pytest.mark.parametrize('case, want', [
     (dict(scenario='simple_spread', num_agents=6, num_envs=4096), 'pw_spread_quad_kernel<true,false,true>'),       # C2: the bench path
     (dict(scenario='simple_spread', num_agents=6, num_envs=16384), 'pw_spread_duo_kernel<6,6,true,false,true>'),
-    (dict(scenario='simple_spread', num_agents=3, num_envs=4096), 'pw_spread_duo_kernel<3,3,true>'),
+    (dict(scenario='simple_spread', num_agents=3, num_envs=4096), 'pw_spread_duo_kernel<3,3,true,false,false,true>'),
     (dict(scenario='simple_spread', num_agents=48, num_envs=4096), 'pw_spread_duo_kernel<48,48,true,false,true>'),
     (dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192), 'pw_tag_duo_kernel<6,4,2,true,false,true>'),   # three-wave form
 ], ids=['C2', 'B16384', 'N3', 'N48', 'C3'])
