@@ -476,9 +476,14 @@ __global__ void __launch_bounds__(kWave) pw_spread_stream_kernel(const StreamPar
         float r = 0.0f;
 #pragma unroll(LT > 0 ? LT : 1)
         for (int l = 0; l < (LT ? LT : L); ++l) r -= __shfl(own, base + l, kWave);
+        if (NT > 12 || NT == 0) {  // as in the duo kernel's reward half: a loop up to the wave's largest collision count
+            const int cnt = sizeof(MaskT) == 4 ? __builtin_popcount((uint32_t)coll) : __builtin_popcountll((uint64_t)coll);
+            for (int k2 = 0; __any(k2 < cnt); ++k2) r -= k2 < cnt ? 1.0f : 0.0f;
+        } else {
 #pragma unroll(NT > 0 ? NT : 1)
-        for (int j = 0; j < (NT ? NT : N); ++j)
-            if ((coll >> j) & 1) r -= 1.0f;
+            for (int j = 0; j < (NT ? NT : N); ++j)
+                if ((coll >> j) & 1) r -= 1.0f;
+        }
         float acc = 0.0f;
 #pragma unroll(NT > 0 ? NT : 1)
         for (int i = 0; i < (NT ? NT : N); ++i) acc += __shfl(r, base + i, kWave);
@@ -713,9 +718,19 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_spread_duo_kernel(c
                 float r = 0.0f;
 #pragma unroll(LT > 0 ? LT : 1)
                 for (int l = 0; l < (LT ? LT : L); ++l) r -= s_min[base + l];
+                // "rew -= 1" once per colliding agent (itself included): the subtrahends are all 1.0, so only their NUMBER
+                // matters.  Few agents collide at a time: for large N a loop up to the wave's largest count (a handful of
+                // iterations) replaces N bit tests -- N = 48: ~12 instead of 144 instructions per step, on grids that are
+                // VALU-issue bound (profiles/r3_n3_trio.txt); small N keeps the unrolled selects (a compare feeding a scalar
+                // branch per iteration costs more than six of them)
+                if (NT > 12 || NT == 0) {   // measured: N = 48 -13.6 %, N = 24 -3.3 % step time; N = 12 +2 % (stays unrolled)
+                    const int cnt = sizeof(MaskT) == 4 ? __builtin_popcount((uint32_t)coll) : __builtin_popcountll((uint64_t)coll);
+                    for (int k2 = 0; __any(k2 < cnt); ++k2) r -= k2 < cnt ? 1.0f : 0.0f;
+                } else {
 #pragma unroll(NT > 0 ? NT : 1)
-                for (int j = 0; j < (NT ? NT : N); ++j)
-                    if ((coll >> j) & 1) r -= 1.0f;
+                    for (int j = 0; j < (NT ? NT : N); ++j)
+                        if ((coll >> j) & 1) r -= 1.0f;
+                }
                 s_rew[me] = r;
                 wave_lds_sync();
                 float acc = 0.0f;
