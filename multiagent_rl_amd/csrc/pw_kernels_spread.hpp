@@ -369,6 +369,65 @@ constexpr int obs_block_stores()
     return (rows * ch + 63) / 64;
 }
 
+// "Planned" block-wise observation stores (duo kernel, even L, rows up to 64 floats... CH * rows <= 640 chunks): chunk n = lane + 64 i of the
+// wave's rows x CH grid has a fixed (row, column group) for the whole launch, so the two LDS addresses it is composed from
+// are computed ONCE per launch and kept packed in one register per chunk: A = 16 bytes -- the row's {vel, pos} (c = 0) or the
+// env's landmarks 2c - 2, 2c - 1 (c >= 1) --, B = 8 bytes -- a zero that lives in LDS (c = 0: x - 0 is x, for every x) or
+// the row's position.  A step is then, per chunk: two LDS reads, two packed subtractions (A.xy - B, A.zw - B: the
+// subtractions stream_write_obs does), one store of 1 KiB contiguous per wave -- ~7 instructions instead of the ~18 of the
+// incremental (row, column) walk of stream_write_obs_block.  Needs the rows staged as {vx, vy, px, py}.
+#ifndef PW_PLAN_MAX
+#define PW_PLAN_MAX 20   // registers for the plan: N = L = 6 / 12 / 24 / 48 need 4 / 7 / 10 / 19 (N = 48: 128 -> 168 VGPRs, three instead of four waves per SIMD, still -12 %)
+#endif
+template <int NT, int LT>
+constexpr int obs_plan_iters()
+{
+    if (NT <= 0 || LT <= 0 || LT % 2) return 0;
+    return ((64 / NT) * NT * ((4 + 2 * LT) / 4) + 63) / 64;
+}
+template <int NT, int LT, int NIT>
+__device__ __forceinline__ void obs_plan_build(uint32_t (&plan)[NIT], const int rows, const int lane, const unsigned char *smem,
+                                               const float4 *s_row, const float2 *s_lm, const float2 *s_zero)
+{
+    constexpr int CH = (4 + 2 * LT) / 4;
+    const int total = rows * CH;
+    const uint32_t zoff = (uint32_t)(reinterpret_cast<const unsigned char *>(s_zero) - smem);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int n = lane + 64 * i, nn = n < total ? n : 0;
+        const int r = nn / CH, c = nn - r * CH, e = r / NT;
+        const uint32_t self = (uint32_t)(reinterpret_cast<const unsigned char *>(s_row + r) - smem);   // {vx, vy, px, py}
+        const uint32_t offA = c == 0 ? self : (uint32_t)(reinterpret_cast<const unsigned char *>(s_lm + e * LT + 2 * c - 2) - smem);
+        const uint32_t offB = c == 0 ? zoff : self + 8;
+        plan[i] = offA | (offB << 16);
+    }
+}
+template <int NT, int LT, int NIT>
+__device__ __forceinline__ void obs_plan_store(float *__restrict__ blk, const int rows, const int lane, const uint32_t (&plan)[NIT],
+                                               const unsigned char *smem)
+{
+    constexpr int CH = (4 + 2 * LT) / 4, UN = NIT < 4 ? NIT : 4;
+    const int total = rows * CH;
+    float4 *const out = reinterpret_cast<float4 *>(blk) + lane;
+#pragma unroll
+    for (int i0 = 0; i0 < NIT; i0 += UN) {
+        float4 va[UN];
+        float2 vb[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (i0 + u < NIT) {
+                va[u] = *reinterpret_cast<const float4 *>(smem + (plan[i0 + u] & 0xFFFFu));
+                vb[u] = *reinterpret_cast<const float2 *>(smem + (plan[i0 + u] >> 16));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (i0 + u < NIT && lane + 64 * (i0 + u) < total)
+                nt_store(out + 64 * (i0 + u), make_float4(va[u].x - vb[u].x, va[u].y - vb[u].y, va[u].z - vb[u].x, va[u].w - vb[u].y));
+        }
+    }
+}
+
 template <int NT, typename MaskT>
 __device__ __forceinline__ void stream_partner_pass(const int N, const int a, const float2 *pp, float px, float py,
                                                     float olx, float oly, float coll_thr2, float near_thr2,
@@ -588,6 +647,9 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_spread_duo_kernel(c
     float4 *s_row = reinterpret_cast<float4 *>(smem_raw + ((3 * kWave * sizeof(float4) + (size_t)A.epw * L * sizeof(float2) +
                                                             2 * kWave * sizeof(float) + 15) & ~(size_t)15));
     float2 *s_utab = reinterpret_cast<float2 *>(s_row + kWave);      // [8] action force per index (wave P)
+    float2 *s_zero = s_utab + 8;                                     // {0, 0} (planned observation stores)
+    constexpr int kPlanIters = obs_plan_iters<NT, LT>();
+    constexpr bool kPlan = BLOCK && kPlanIters >= 1 && kPlanIters <= PW_PLAN_MAX;
 
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = (int)threadIdx.x & 63;
@@ -690,6 +752,13 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_spread_duo_kernel(c
         }
         constexpr int kStoresPerStep = LT > 0 ? 4 + (COLL ? 1 : 0) + (BLOCK ? obs_block_stores<NT, LT>() : (LT % 2 == 0 ? 1 + LT / 2 : 2 + LT)) : 0;
         constexpr int kVm = kStoresPerStep < 63 ? kStoresPerStep : 63;
+        uint32_t plan[kPlan ? kPlanIters : 1];
+        if constexpr (kPlan) {
+            if (do_obs) {
+                if (lane == 0) *s_zero = make_float2(0.0f, 0.0f);
+                obs_plan_build<NT, LT, kPlanIters>(plan, rows_here, lane, smem_raw, s_row, s_lm, s_zero);
+            }
+        }
         PW_STAMP_DECL;
         for (int t = 0; t < T; ++t) {
             const size_t tBN = (size_t)t * BN;
@@ -760,9 +829,11 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_spread_duo_kernel(c
             }
             cur = nxt;
             if (do_obs) {
-                if (BLOCK) s_row[me] = make_float4(px, py, vx, vy);
+                if (BLOCK) s_row[me] = kPlan ? make_float4(vx, vy, px, py) : make_float4(px, py, vx, vy);
                 wave_lds_sync();
-                if constexpr (BLOCK)
+                if constexpr (kPlan)
+                    obs_plan_store<NT, LT, kPlanIters>(A.obs + (tBN + (size_t)blockIdx.x * A.epw * N) * D, rows_here, lane, plan, smem_raw);
+                else if constexpr (BLOCK)
                     stream_write_obs_block<NT, LT>(A.obs + (tBN + (size_t)blockIdx.x * A.epw * N) * D, rows_here, lane, s_row, s_lm);
                 else
                     stream_write_obs<LT>(A.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);

@@ -395,7 +395,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         const bool duo = dp.duo < 0 ? grid.x <= 8192 : dp.duo != 0;
         if (duo) {
             const size_t shm2 = 3 * kWave * sizeof(float4) + (size_t)kp.epw * kp.L * sizeof(float2) +
-                                2 * kWave * sizeof(float) + 16 + kWave * sizeof(float4) + 8 * sizeof(float2);
+                                2 * kWave * sizeof(float) + 16 + kWave * sizeof(float4) + 8 * sizeof(float2) + 16;
             // three waves per env group (the output wave split in two) where the single output wave is the step's critical
             // path: block-store instantiations on mid-size grids (measured: profiles/r2_trio.txt).  pw_dispatch.trio overrides.
             // (only the compile-time instantiations below have the three-wave form: a runtime-N launch stays two waves wide)
