@@ -191,7 +191,7 @@ typedef struct pw_dispatch {
     int32_t trio;          /* -1 auto; 0 / 1: the three-wave variants of the duo kernels (spread: block-store forms, N >= 6) */
     int32_t p_prio;        /* -1 auto; >= 0: issue-priority bits of the duo kernels' waves (2 bits per wave; simple_tag: 0 / 1) */
     int32_t envs_per_wave; /* 0 auto; n >= 1: envs per wave, clamped to 64 / N */
-    int32_t policy_form;   /* 0 auto; 1 / 2: pw_policy_rollout_kernel / pw_policy_rollout2_kernel */
+    int32_t policy_form;   /* 0 auto; 1 / 2 / 3: pw_policy_rollout_kernel / pw_policy_rollout2_kernel / pw_policy_rollout3_kernel */
 } pw_dispatch;
 int pw_dispatch_default(pw_dispatch *d);                    /* every choice automatic */
 int pw_set_dispatch(pw_handle *h, const pw_dispatch *d);    /* between launches; the bound state is untouched */

@@ -385,12 +385,14 @@ __global__ void __launch_bounds__(512) pw_policy_rollout2_kernel(const PolicyRol
                     ar = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.w, xr_[m][4 * rq + 3], ar, 0, 0, 0);
                 }
             }
+            // the tiles go out WITHOUT the bias: the LSTM lanes add it when they pick a value up (their four biases are
+            // lane constants in registers; here it would be 32 just-in-time LDS reads per pair -- 2.7 k cycles of
+            // round trips at this kernel's register budget).  acc + bias either way: the same bits.
             float *df = S.s_g[0] + (rtf * 32 + col) * kGs + wave * 32, *dr = S.s_g[1] + (rtr * 32 + col) * kGs + wave * 32;
-            const float *bf = S.s_bih + wave * 32, *br = S.s_bih + 128 + wave * 32;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                df[mfma_row(q, half)] = af[q] + bf[mfma_row(q, half)];
-                dr[mfma_row(q, half)] = ar[q] + br[mfma_row(q, half)];
+                df[mfma_row(q, half)] = af[q];
+                dr[mfma_row(q, half)] = ar[q];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tiles have landed before they are announced
             if (lane == 0) {
@@ -413,9 +415,13 @@ __global__ void __launch_bounds__(512) pw_policy_rollout2_kernel(const PolicyRol
             } else if (nrt == 3) {
                 stage1(x0, obs_off[0]);
                 stage1(x2, obs_off[2]);
+                PW_R2_STAMP(0);
                 stage2_pair(x0, 0, x2, 2);
+                PW_R2_STAMP(1);
                 stage1(x1, obs_off[1]);
+                PW_R2_STAMP(2);
                 stage2_pair(x1, 1, x1, 1);
+                PW_R2_STAMP(3);
                 stage2_pair(x2, 2, x0, 0);
             } else if (nrt == 2) {
                 stage1(x0, obs_off[0]);
@@ -426,11 +432,11 @@ __global__ void __launch_bounds__(512) pw_policy_rollout2_kernel(const PolicyRol
                 stage1(x0, obs_off[0]);
                 stage2_pair(x0, 0, x0, 0);
             }
-            PW_R2_STAMP(0);
+            PW_R2_STAMP(4);
             wg_lds_barrier();  // B1: both recurrences done, Hs complete
-            PW_R2_STAMP(1);
+            PW_R2_STAMP(5);
             head();  // B2, B3 inside
-            PW_R2_STAMP(2);
+            PW_R2_STAMP(6);
 
             // ---- environment step (pw_spread_stream_kernel's arithmetic)
             if (env_wave) {
@@ -513,9 +519,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout2_kernel(const PolicyRol
                     lds_write_obs_row<LT>(S.s_obs + r * DS, L, lmv, px, py, vx, vy);
                 }
             }
-            PW_R2_STAMP(3);
             wg_lds_barrier();  // B4: the next observation rows (and the next noise) are in LDS
-            PW_R2_STAMP(4);
+            PW_R2_STAMP(7);
         }
         if (wave == 0) PW_R2_FLUSH(0);
 
@@ -582,6 +587,9 @@ __global__ void __launch_bounds__(512) pw_policy_rollout2_kernel(const PolicyRol
         const bool busy = s_first < envs_here;  // wave-uniform
         draw_noise(step0, tid - 256);
         wg_lds_barrier();
+        float bq[4];  // this unit's input-projection biases (gates i, f, g, o), added to the matrix waves' tiles
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = S.s_bih[dir * 128 + q * 32 + j];
         PW_R2_DECL;
 
         for (int t = 0; t < P.T; ++t) {
@@ -602,7 +610,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout2_kernel(const PolicyRol
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float *gp = G + (ts * E + se[i]) * kGs;
-                        gt[i][0] = gp[j]; gt[i][1] = gp[32 + j]; gt[i][2] = gp[64 + j]; gt[i][3] = gp[96 + j];
+                        gt[i][0] = gp[j] + bq[0]; gt[i][1] = gp[32 + j] + bq[1];
+                        gt[i][2] = gp[64 + j] + bq[2]; gt[i][3] = gp[96 + j] + bq[3];
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hs[i * 64 + j] = h[i];

@@ -1,0 +1,489 @@
+// pw_kernels_policy3.hpp -- part of libpworld.so (translation unit csrc/pworld_policy.hip includes it).
+// Policy-in-the-loop rollout, third form: the whole BiLSTM -- input projection AND recurrence -- on the matrix cores, one
+// timestep at a time, every weight resident in registers, no G tile in LDS.
+#pragma once
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// What the stamps of the second form say (profiles/r3_policy_phases.txt): the f32 MFMA and the vector ALU of a SIMD share
+// their multipliers, so "matrix waves" and "LSTM waves" take turns anyway, and while one role works the other's four waves
+// idle (18 k of a step's 47 k cycles); and the recurrence runs at the packed-FMA rate a single wave can issue
+// (5.5 cycles per v_pk_fma_f32, 23 MAC/clk/SIMD) where the matrix pipe does 32.
+//
+// Here a workgroup still owns 16 environments, but its eight waves are identical: wave w = (direction w / 4, hidden
+// quarter w % 4) owns 8 hidden units x 4 gates = 32 gate units as two 16-row MFMA tiles and runs, per LSTM timestep,
+//     acc  = W_ih(tile) * x1(ts)        16 x v_mfma_f32_16x16x4_f32 per tile  (k in the order of the other forms)
+//     acc += b_ih + b_hh
+//     acc  = W_hh(tile) * h(ts - 1) + acc  8 x v_mfma_f32_16x16x4_f32 per tile (k ascending)
+//     cell update in the lane, h -> LDS (exchange + head input), one workgroup barrier per timestep
+// with the 16 sequences of the workgroup as the MFMA's 16 columns.  Tile rows are ordered (unit, gate): accumulator
+// register i of lane (column n, row group rg) is gate i of unit 4 * tile + rg -- all four gates of a cell in one lane, no
+// cross-lane traffic.  A fragments: 32 (W_ih) + 16 (W_hh) VGPRs per lane for the whole launch; nothing but h (8 KB, double
+// buffered) and the dense1 output (4 KB per timestep) passes through LDS.  The input projection of timestep ts + 1 is
+// issued before the barrier of timestep ts, so the matrix pipe has work while the workgroup meets.
+//   dense1 + ReLU: as 32 x 32 blocks on v_mfma_f32_32x32x2_f32 (one block per wave, once per workgroup), scattered to LDS
+//   directly in the B-fragment order of the timestep loop.
+//   head, Gumbel noise, environment step: as in the second form.
+// Bits: v_mfma_f32_16x16x4_f32 is a chain of fused multiply-adds over k = 0..3 in order (tools/mfma16_probe.hip: 0 of
+// 512000 elements differ), as the 32x32x2 form is over its two k; the input projection feeds k in the order the other
+// forms' 32x32x2 chains use (pairs {k, k + 4}), the bias is added to the finished sum, the recurrence continues the same
+// accumulator with k ascending -- element for element the operation sequence of pw_bilstm_kernel.  (At the first timestep
+// h = 0 and the other forms run the chain with zeros, which leaves every nonzero accumulator unchanged; here it is skipped.)
+// LDS (N = 6, D = 16): 24 KB x1 fragments + 8 KB h exchange + 26 KB head input + 20 KB small = 78 KB.
+// ------------------------------------------------------------------------------------------
+struct Roll3Lds {
+    float4 *s_xf;    // [N timesteps][4 j][64 lane]: element e of (j, lane (n, kq)) = x1[row (ts, n)][kpos(16 j + 4 e + kq)]
+    float4 *s_hx;    // [2 buffers][2 dir][2 j][64 lane]: element e = h[seq n][16 j + 4 e + kq]
+    float *s_hid;    // [rows][68] head input (relu(h) of both directions), rows env-major
+    float *f_w1;     // [2 m][S1][64 lane]
+    float *s_b1, *s_w2, *s_b2;
+    float *s_noise;  // [rows * 5] Gumbel noise of the coming head
+    float *s_obs;    // [rows][DS], DS = D + 2
+    int32_t *s_act;  // [rows]
+    float2 *s_posb;  // [8 env waves][64] (16 environments of N agents: up to 8 waves of whole environments)
+    float2 *s_lmb;   // [E * L]
+    double *s_fs;    // [16]
+    int *s_fc;       // [16]
+    float *s_lg;     // perturbed logits [rows * 5] -- aliases s_xf, dead once the timestep loop is done
+};
+__host__ __device__ inline size_t roll3_lds_bytes(int E, int N, int L, int D, int S1)
+{
+    const size_t rows = (size_t)E * N;
+    size_t fl = (size_t)N * 4 * 64 * 4 + 2 * 2 * 2 * 64 * 4 + rows * kHs + (size_t)2 * S1 * 64 + 64 + 1024 + 16 + rows * 5 + 1 +
+                rows * (D + 2) + rows + 1;
+    return fl * 4 + 8 * kWave * sizeof(float2) + (size_t)E * L * sizeof(float2) + 16 * (sizeof(double) + sizeof(int)) + 64;
+}
+__device__ __forceinline__ Roll3Lds roll3_carve(unsigned char *raw, int E, int N, int L, int D, int S1)
+{
+    // offsets in floats from the (16-byte aligned) base; no pointer <-> integer casts (LDS address space kept)
+    const int rows = E * N;
+    float *base = reinterpret_cast<float *>(raw);
+    Roll3Lds S;
+    int o = 0;
+    S.s_xf = reinterpret_cast<float4 *>(base + o); o += N * 4 * 64 * 4;
+    S.s_hx = reinterpret_cast<float4 *>(base + o); o += 2 * 2 * 2 * 64 * 4;
+    S.s_hid = base + o; o += rows * kHs;
+    S.f_w1 = base + o; o += 2 * S1 * 64;
+    S.s_b1 = base + o; o += 64;
+    S.s_w2 = base + o; o += 1024;
+    S.s_b2 = base + o; o += 16;
+    S.s_noise = base + o; o += rows * 5;
+    o = (o + 1) & ~1;
+    S.s_obs = base + o; o += rows * (D + 2);
+    S.s_act = reinterpret_cast<int32_t *>(base + o); o += rows;
+    o = (o + 1) & ~1;
+    S.s_posb = reinterpret_cast<float2 *>(base + o); o += 8 * kWave * 2;
+    S.s_lmb = reinterpret_cast<float2 *>(base + o); o += E * L * 2;
+    S.s_fs = reinterpret_cast<double *>(base + o); o += 32;
+    S.s_fc = reinterpret_cast<int *>(base + o);
+    S.s_lg = reinterpret_cast<float *>(S.s_xf);
+    return S;
+}
+
+// hidden index of position p (0..63) in the summation order of the input projection: the 32x32x2 chains of the other forms
+// walk (m, rq, e) and sum the pair {m * 32 + 8 rq + e, + 4} per instruction
+__device__ __forceinline__ int x1_kpos(int p) { return ((p >> 5) << 5) + (((p >> 3) & 3) << 3) + ((p >> 1) & 3) + ((p & 1) << 2); }
+
+template <int S1C, int NT, bool SINK>
+__global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRolloutArgs P)
+{
+    constexpr int LT = NT;
+    constexpr int S1 = 4 * S1C;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const ActorFusedArgs &A = P.A;
+    const StreamParams &V = P.V;
+    const int N = NT ? NT : A.N, L = LT ? LT : V.L, D = A.D, DS = D + 2, E = A.E;
+    const Roll3Lds S = roll3_carve(smem_raw, E, N, L, D, S1);
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long env0 = (long)blockIdx.x * E;
+    const int envs_here = (int)((long)A.B - env0 < (long)E ? (long)A.B - env0 : (long)E);
+    const int rows_here = envs_here * N;
+    const int nblk = 2 * ((N + 1) >> 1);    // stage-1 blocks: (32-column tile = two timesteps of 16 sequences) x (hidden half)
+    const long row_base = env0 * N;
+    const size_t BN = (size_t)A.B * N;
+    const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
+    constexpr int OUT = 5;  // one 5-logit head (checked on the host)
+
+    // ---- constants -> LDS (once)
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(A.frag + 8 * 2 * 4 * 64 * 4);
+        for (int f = tid; f < (2 * S1 * 64) / 4; f += 512) reinterpret_cast<float4 *>(S.f_w1)[f] = src[f];
+        if (tid < 64) S.s_b1[tid] = A.b1[tid];
+        for (int f = tid; f < OUT * 64; f += 512) S.s_w2[f] = A.w2[f];
+        if (tid < OUT) S.s_b2[tid] = A.b2[tid];
+    }
+
+    // Gumbel noise of one head evaluation (as in the second form): called by the 256 threads of waves 4-7 (t0 = their
+    // index) while the environment step runs
+    auto draw_noise = [&](const uint64_t step, const int t0) {
+        for (int idx = t0; idx < rows_here * OUT; idx += 256) {
+            const int r = idx / OUT, o = idx - r * OUT;
+            const long grow = row_base + r;
+            const uint32_t blk = (uint32_t)o >> 2, tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
+            uint32_t u[4];
+            pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | tag, (uint32_t)step, (uint32_t)(step >> 32),
+                             (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
+            const int wq = o & 3;
+            const uint32_t uw = wq == 0 ? u[0] : wq == 1 ? u[1] : wq == 2 ? u[2] : u[3];
+            const float uo = ((float)(uw >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
+            S.s_noise[idx] = __logf(-__logf(uo));
+        }
+    };
+
+    // the head: thread = (row, logit), then one thread per row picks the arg-max (actor_forward_wg's arithmetic)
+    auto head = [&]() {
+        for (int idx = tid; idx < rows_here * OUT; idx += 512) {
+            const int r = idx / OUT, o = idx - r * OUT;
+            float acc = S.s_b2[o];
+            const float4 *hv = reinterpret_cast<const float4 *>(S.s_hid + r * kHs), *wv = reinterpret_cast<const float4 *>(S.s_w2 + o * 64);
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const float4 hq4 = hv[q], wq = wv[q];
+                acc = __builtin_fmaf(wq.x, hq4.x, acc);
+                acc = __builtin_fmaf(wq.y, hq4.y, acc);
+                acc = __builtin_fmaf(wq.z, hq4.z, acc);
+                acc = __builtin_fmaf(wq.w, hq4.w, acc);
+            }
+            S.s_lg[idx] = acc - S.s_noise[idx];
+        }
+        wg_lds_barrier();
+        for (int r = tid; r < rows_here; r += 512) {
+            const float *v = S.s_lg + r * OUT;
+            int best = 0;
+            float bv = v[0];
+#pragma unroll
+            for (int o = 1; o < OUT; ++o)
+                if (v[o] > bv) { bv = v[o]; best = o; }
+            S.s_act[r] = best;
+        }
+        wg_lds_barrier();
+    };
+
+    // ---- environment lanes (as the other forms): wave w < n_env_waves owns local envs [w * epw, ...)
+    const int epw_max = E < kWave / N ? E : kWave / N;
+    const int waves_full = (E + epw_max - 1) / epw_max;
+    const int epw = (E + waves_full - 1) / waves_full;
+    const int n_env_waves = (envs_here + epw - 1) / epw;  // <= 8 (N <= 32)
+    const bool env_wave = wave < n_env_waves;
+    int e_loc = lane / N, a = lane - e_loc * N;
+    int el = wave * epw + e_loc;
+    const bool live = env_wave && e_loc < epw && el < envs_here;
+    if (!live) { e_loc = 0; a = 0; el = env_wave ? wave * epw : 0; }
+    const int base = e_loc * N, r = el * N + a;
+    const long env = env0 + el;
+    const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
+    float2 *s_pos = S.s_posb + (env_wave ? wave : 0) * kWave;
+    const float2 *pp = s_pos + base;
+    float2 *lmv = S.s_lmb + el * L;
+    const int la = a < L ? a : 0;
+
+    float px = 0.f, py = 0.f, vx = 0.f, vy = 0.f, olx = 0.f, oly = 0.f, best = 0.f;
+    int ep_step = 0;
+    uint32_t ep_count = 0;
+    uint64_t coll = 0, near = 0;
+    float ep_ret = 0.f;
+    double fin_sum = 0.0;
+    int fin_cnt = 0;
+    if (env_wave) {
+        if (SINK && P.episode_return && live && a == 0) ep_ret = P.episode_return[env];
+        px = V.pos_x[g]; py = V.pos_y[g]; vx = V.vel_x[g]; vy = V.vel_y[g];
+        ep_step = V.ep_step[env];
+        ep_count = V.ep_count[env];
+        if (L > 0) {
+            olx = V.lm_x[(size_t)env * L + la];
+            oly = V.lm_y[(size_t)env * L + la];
+            if (live) lmv[la] = make_float2(olx, oly);
+        }
+        if (live) s_pos[base + a] = make_float2(px, py);
+        wave_lds_sync();
+        stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
+        if (live) lds_write_obs_row<LT>(S.s_obs + r * DS, L, lmv, px, py, vx, vy);
+    }
+    const float k = V.contact_margin, cf = V.contact_force, dt = V.dt, damp = V.damp, mass = V.mass;
+
+    // ---- this wave's resident weights.  MFMA 16x16x4 lane roles: as A operand lane = (tile row ar = lane % 16, k quarter
+    // kq = lane / 16); as B operand / accumulator lane = (column n = lane % 16, kq resp. row group rg = lane / 16).
+    // Tile row ar = 4 * (unit within tile) + gate: W row gate * 32 + hq * 8 + 4 * tile + ar / 4 of direction dir.
+    const int dir = wave >> 2, hq = wave & 3;
+    const int n16 = lane & 15, kq = lane >> 4;
+    float aih[2][16], ahh[2][8], bias[2][4];
+    {
+        const float *whh = dir ? A.whh_r : A.whh_f;
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            const int wrow = (n16 & 3) * 32 + hq * 8 + 4 * T + (n16 >> 2);  // within the direction: gate * 32 + unit
+            const int R = dir * 128 + wrow;                                 // row of W_ih [256][64]
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int kk = x1_kpos(4 * s + kq);
+                // W_ih[R][kk] out of the 32x32x2 fragment array (pw_actor_front_pack): [8 n][2 m][4 rq][64 lane] float4
+                const int kl = kk & 31;
+                const size_t idx = ((((size_t)(R >> 5) * 2 + (kk >> 5)) * 4 + (kl >> 3)) * 64 + (R & 31) + 32 * ((kl >> 2) & 1)) * 4 + (kl & 3);
+                aih[T][s] = A.frag[idx];
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) ahh[T][s] = whh[wrow * 32 + 4 * s + kq];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bias[T][i] = A.bih[dir * 128 + i * 32 + hq * 8 + 4 * T + kq];  // accumulator role: rg = kq
+        }
+    }
+    const int unit0 = hq * 8 + kq;  // this lane's cells: units unit0 and unit0 + 4 of sequence n16
+    const bool seq_ok = n16 < envs_here;
+    wg_lds_barrier();  // constants in LDS
+    if (wave >= 4) draw_noise(step0, tid - 256);
+    wg_lds_barrier();  // first observation rows and first noise in LDS
+    PW_R2_DECL;
+
+    // input projection of timestep ts for this wave's two tiles (+ bias)
+    auto inproj = [&](const int ts, f32x4 (&acc)[2]) {
+        const float4 *xf = S.s_xf + (ts * 4) * 64 + lane;
+        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            const float4 b = xf[jx * 64];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 0], b.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 0], b.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 1], b.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 1], b.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 2], b.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 2], b.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 3], b.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 3], b.w, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[T][i] += bias[T][i];
+    };
+
+    for (int t = 0; t < P.T; ++t) {
+        PW_R2_START;
+        // ---- dense1 + ReLU: 32 x 32 blocks of relu(W1 X^T + b1), column rho = 16 * timestep + sequence
+        for (int blk = wave; blk < nblk && !PW_DBG(1); blk += 8) {
+            const int rt = blk >> 1, m = blk & 1;
+            // the observation row behind column rt * 32 + col: agent ts of local env n (slots past N or past the envs of
+            // this workgroup read a valid row; nobody uses their results)
+            int ts = 2 * rt + (col >> 4), n = col & 15;
+            if (ts >= N) ts = N - 1;
+            if (n >= envs_here) n = 0;
+            const float *xr = S.s_obs + (n * N + ts) * DS;
+            float xb[S1];
+#pragma unroll
+            for (int sidx = 0; sidx < S1; ++sidx) {
+                const int kk = 2 * sidx + half;
+                xb[sidx] = kk < D ? xr[kk] : 0.0f;
+            }
+            f32x16 acc1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc1[q] = 0.0f;
+#pragma unroll
+            for (int sidx = 0; sidx < S1; ++sidx)
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(S.f_w1[(m * S1 + sidx) * 64 + lane], xb[sidx], acc1, 0, 0, 0);
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = fmaxf(acc1[q] + S.s_b1[m * 32 + mfma_row(q, half)], 0.0f);
+            // register q of lane half `half` is hidden unit m * 32 + (q & 3) + 8 (q >> 2) + 4 half = position 32 m + 2 q + half of
+            // the projection's summation order: k step s = 8 m + q / 2, k quarter 2 (q & 1) + half -> fragment j = s / 4 =
+            // 2 m + q / 8, element e = (q / 2) % 4, lane (2 (q & 1) + half) * 16 + sequence
+            if (2 * rt + (col >> 4) < N) {
+                float4 *dst = S.s_xf + ((2 * rt + (col >> 4)) * 4 + 2 * m) * 64 + half * 16 + (col & 15);
+#pragma unroll
+                for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+                    for (int ql = 0; ql < 2; ++ql)
+                        dst[qh * 64 + ql * 32] = make_float4(v[8 * qh + ql], v[8 * qh + 2 + ql], v[8 * qh + 4 + ql], v[8 * qh + 6 + ql]);
+            }
+        }
+        PW_R2_STAMP(0);
+        wg_lds_barrier();  // the x1 fragments are in LDS
+        PW_R2_STAMP(1);
+        // ---- the BiLSTM, one timestep per barrier
+        if (!PW_DBG(2)) {
+            f32x4 acc[2], accn[2];
+            float c0 = 0.f, c1 = 0.f;
+            inproj(dir ? N - 1 : 0, acc);
+            for (int s2 = 0; s2 < N; ++s2) {
+                const int ts = dir ? N - 1 - s2 : s2;
+                if (s2 > 0) {
+                    const float4 *hx = S.s_hx + ((((s2 - 1) & 1) * 2 + dir) * 2) * 64 + lane;
+                    const float4 h0 = hx[0], h1 = hx[64];
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[0][0], h0.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[1][0], h0.x, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[0][1], h0.y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[1][1], h0.y, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[0][2], h0.z, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[1][2], h0.z, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[0][3], h0.w, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[1][3], h0.w, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[0][4], h1.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[1][4], h1.x, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[0][5], h1.y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[1][5], h1.y, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[0][6], h1.z, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[1][6], h1.z, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[0][7], h1.w, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[1][7], h1.w, acc[1], 0, 0, 0);
+                }
+                // the two cells of this lane: accumulator registers = gates i, f, g, o
+                c0 = fast_sigmoid(acc[0][1]) * c0 + fast_sigmoid(acc[0][0]) * fast_tanh(acc[0][2]);
+                c1 = fast_sigmoid(acc[1][1]) * c1 + fast_sigmoid(acc[1][0]) * fast_tanh(acc[1][2]);
+                const float h0v = fast_sigmoid(acc[0][3]) * fast_tanh(c0);
+                const float h1v = fast_sigmoid(acc[1][3]) * fast_tanh(c1);
+                // h exchange: unit u = hq * 8 + 4 T + kq is k quarter kq of k step 2 hq + T: fragment j = hq / 2, elements
+                // (2 hq) % 4 + T of this very lane slot
+                reinterpret_cast<float2 *>(S.s_hx + (((s2 & 1) * 2 + dir) * 2 + (hq >> 1)) * 64 + lane)[hq & 1] = make_float2(h0v, h1v);
+                if (seq_ok) {
+                    float *hd = S.s_hid + (n16 * N + ts) * kHs + dir * 32 + unit0;
+                    hd[0] = A.relu_out ? fmaxf(h0v, 0.0f) : h0v;
+                    hd[4] = A.relu_out ? fmaxf(h1v, 0.0f) : h1v;
+                }
+                if (s2 + 1 < N) inproj(dir ? N - 2 - s2 : s2 + 1, accn);  // before the barrier: work for the matrix pipe while the workgroup meets
+                wg_lds_barrier();  // h(ts) of every unit is in LDS (the last one: Hs complete)
+                if (s2 + 1 < N) { acc[0] = accn[0]; acc[1] = accn[1]; }
+            }
+        } else {
+            wg_lds_barrier();
+        }
+        PW_R2_STAMP(2);
+        head();  // two barriers inside
+        PW_R2_STAMP(3);
+
+        // ---- environment step (pw_spread_stream_kernel's arithmetic)
+        if (env_wave) {
+            const size_t tBN = (size_t)t * BN;
+            const int ai = S.s_act[r];
+            size_t slot = 0;
+            if (SINK && P.has_ring) {  // the observation the policy acted on (still in LDS) -> ring.obs
+                slot = (size_t)((P.ring_start + (int64_t)t * A.B + env) % P.ring.capacity);
+                if (live) {
+                    const float2 *src = reinterpret_cast<const float2 *>(S.s_obs + r * DS);
+                    float2 *dst = reinterpret_cast<float2 *>(P.ring.obs + (slot * N + a) * D);
+                    for (int c = 0; c < D / 2; ++c) dst[c] = src[c];
+                    P.ring.act[slot * N + a] = (uint8_t)ai;
+                }
+            }
+            float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
+            float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
+            ux *= V.sens; uy *= V.sens;
+            if (V.fscale != 1.0f) { ux = V.fscale * ux; uy = V.fscale * uy; }
+            float fx = ux + 0.0f, fy = uy + 0.0f;
+            near_force_loop<uint64_t, float2>(live ? near : 0, pp, px, py, V.dist_min, k, cf, fx, fy);
+            vx = vx * damp; vy = vy * damp;
+            vx = vx + (fx / mass) * dt;
+            vy = vy + (fy / mass) * dt;
+            px = px + vx * dt;
+            py = py + vy * dt;
+            wave_lds_sync();
+            if (live) s_pos[base + a] = make_float2(px, py);
+            wave_lds_sync();
+            stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
+            const float own = sqrtf(best);
+            float rw = 0.0f;
+#pragma unroll(LT > 0 ? LT : 1)
+            for (int l = 0; l < L; ++l) rw -= __shfl(own, base + l, kWave);
+#pragma unroll(NT > 0 ? NT : 1)
+            for (int j = 0; j < N; ++j)
+                if ((coll >> j) & 1) rw -= 1.0f;
+            float acc = 0.0f;
+#pragma unroll(NT > 0 ? NT : 1)
+            for (int i = 0; i < N; ++i) acc += __shfl(rw, base + i, kWave);
+            ep_step += 1;
+            const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
+            if (live) {
+                if (P.act_out) P.act_out[tBN + g] = ai;
+                if (V.rew) V.rew[tBN + g] = rw;
+                if (V.done) V.done[tBN + g] = 0;
+                if (a == 0) {
+                    if (V.rew_shared) V.rew_shared[(size_t)t * A.B + env] = acc;
+                    if (V.terminal) V.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+                }
+                if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
+                    stream_write_obs<LT>(P.ring.next_obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
+                    if (a == 0) { P.ring.rew[slot] = acc; P.ring.done[slot] = 0.0f; }
+                }
+                if (SINK && a == 0 && P.episode_return) {  // run.py:55-65, per env
+                    const float rsum = ep_ret + acc;
+                    if (term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
+                    else ep_ret = rsum;
+                }
+            }
+            if (term && V.auto_reset) {  // same for every lane of an env
+                if (live && V.final_obs) stream_write_obs<LT>(V.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+                wave_lds_sync();
+                ep_count += 1;
+                ep_step = 0;
+                const uint64_t env_id = V.env_id_base + (uint64_t)env;
+                pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
+                vx = 0.f; vy = 0.f;
+                if (L > 0) {
+                    pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)(N + la), -1.0f, 1.0f, &olx, &oly);
+                    if (live) lmv[la] = make_float2(olx, oly);
+                }
+                if (live) s_pos[base + a] = make_float2(px, py);
+            }
+            wave_lds_sync();
+            if (V.auto_reset && __any(term))
+                stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
+            if (live) {
+                if (V.obs) stream_write_obs<LT>(V.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+                lds_write_obs_row<LT>(S.s_obs + r * DS, L, lmv, px, py, vx, vy);
+            }
+        }
+        if (wave >= 4 && t + 1 < P.T) draw_noise(step0 + (uint64_t)(t + 1), tid - 256);  // beside the environment step
+        PW_R2_STAMP(4);
+        wg_lds_barrier();  // the next observation rows (and the next noise) are in LDS
+        PW_R2_STAMP(5);
+    }
+    if (wave == 0) PW_R2_FLUSH(0);
+    if (wave == 4) PW_R2_FLUSH(8);
+
+    if (live) {
+        V.pos_x[g] = px; V.pos_y[g] = py;
+        V.vel_x[g] = vx; V.vel_y[g] = vy;
+        if (L > 0 && a < L) {
+            V.lm_x[(size_t)env * L + la] = olx;
+            V.lm_y[(size_t)env * L + la] = oly;
+        }
+        if (a == 0) {
+            V.ep_step[env] = ep_step;
+            V.ep_count[env] = ep_count;
+            if (SINK && P.episode_return) P.episode_return[env] = ep_ret;
+        }
+    }
+    if (SINK && P.episode_return) {
+        wg_lds_barrier();
+        if (live && a == 0) { S.s_fs[el] = fin_sum; S.s_fc[el] = fin_cnt; }
+        wg_lds_barrier();
+        if (tid == 0) {
+            double ws = 0.0;
+            long long wc = 0;
+            for (int i = 0; i < envs_here; ++i) { ws += S.s_fs[i]; wc += S.s_fc[i]; }
+            double *part_sum = reinterpret_cast<double *>(P.scratch);
+            long long *part_cnt = reinterpret_cast<long long *>(P.scratch + gridDim.x);
+            unsigned long long *ticket = P.scratch + 2 * gridDim.x;
+            part_sum[blockIdx.x] = ws;
+            part_cnt[blockIdx.x] = wc;
+            __threadfence();
+            if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1) {
+                __threadfence();
+                double ssum = 0.0;
+                long long scnt = 0;
+                for (unsigned i = 0; i < gridDim.x; ++i) {
+                    ssum += __builtin_nontemporal_load(part_sum + i);
+                    scnt += __builtin_nontemporal_load(part_cnt + i);
+                }
+                *P.finished_sum += ssum;
+                *P.finished_count += scnt;
+                *ticket = 0;
+            }
+        }
+    }
+}
+
+}  // namespace

@@ -23,6 +23,7 @@
 #include "pw_handle.hpp"
 #include "pw_kernels_policy.hpp"
 #include "pw_kernels_policy2.hpp"
+#include "pw_kernels_policy3.hpp"
 #include "pw_kernels_policy_tag.hpp"
 #include "pw_kernels_policy_ref.hpp"
 
@@ -226,19 +227,26 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     }
     const int S1C = (kp.D + 7) / 8, S1 = 4 * S1C;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // Two forms.  pw_policy_rollout_kernel: workgroup-wide phases, 16 envs per workgroup, LDS bounds the observation
-    // length (D <= 36).  pw_policy_rollout2_kernel (pw_kernels_policy2.hpp): role-specialised waves -- matrix cores and
-    // vector ALUs busy together, weights resident in registers -- with as many environments per workgroup as fit
-    // 160 KB of LDS, so it also serves long observation rows (D <= 64: N <= 30).  Measured at B = 4096
-    // (profiles/r2_policy_rollout.txt): N = 3: 15.4 vs 17.0 us/step; N = 6: 22.3 vs 23.4; N = 12: 69.1 vs 67.5; N = 16: 169 vs
-    // 120 -- so the second form runs where it wins (N <= 6) or where the first does not fit.  pw_dispatch.policy_form overrides.
+    // Three forms.  pw_policy_rollout_kernel: workgroup-wide phases, weights refilled through LDS, 16 envs per workgroup,
+    // LDS bounds the observation length (D <= 36).  pw_policy_rollout2_kernel (pw_kernels_policy2.hpp): role-specialised
+    // waves, weights resident in registers, as many environments per workgroup as fit 160 KB of LDS (D <= 64: N <= 30).
+    // pw_policy_rollout3_kernel (pw_kernels_policy3.hpp): the whole BiLSTM on v_mfma_f32_16x16x4_f32, one timestep per
+    // barrier, 16 environments per workgroup at any N; its dense1 output takes 4 KB of LDS per agent, so the environments per
+    // workgroup shrink past N = 12.  Measured at B = 4096, us per step, forms 1 / 2 / 3 (profiles/r3_policy_forms.txt):
+    // N = 3: 16.0 / 13.9 / 9.7; N = 6: 24.2 / 21.6 / 15.6; N = 12: 65.8 / 65.1 / 32.7; N = 16: 114.7 / 165.8 / 84.6;
+    // N = 24: - / 405 / 483 -- the third form runs wherever it keeps >= 8 environments per workgroup, then the old rule
+    // (the second where it wins, N <= 6, or where the first does not fit).  pw_dispatch.policy_form overrides.
     const size_t shm = actor_lds_bytes(S1) + (size_t)kFusedRows * kp.D * sizeof(float) + kFusedRows * sizeof(int32_t) +
                        2 * kWave * sizeof(float2) + (size_t)a.E * kp.L * sizeof(float2) + 16 * (sizeof(double) + sizeof(int));
     const bool v1_fits = shm <= 160 * 1024;
-    bool use_v2 = !v1_fits || kp.N <= 6;
-    if (h->disp.policy_form == 2) use_v2 = true;
-    if (h->disp.policy_form == 1 && v1_fits) use_v2 = false;
-    int E2 = 0;
+    const int form = h->disp.policy_form;
+    int E3 = 0;
+    for (int e = kp.B < 16 ? kp.B : 16; e >= 1; --e)  // 16 MFMA columns = 16 environments whatever N is (no 96-row limit here)
+        if (roll3_lds_bytes(e, kp.N, kp.L, kp.D, S1) <= 160 * 1024) { E3 = e; break; }
+    bool use_v3 = form == 3 ? E3 > 0 : form == 0 ? E3 >= (kp.B < 8 ? kp.B : 8) : (form == 1 && !v1_fits && E3 >= 8);
+    bool use_v2 = !use_v3 && (!v1_fits || kp.N <= 6 || form >= 2);
+    if (form == 1 && v1_fits) { use_v2 = false; use_v3 = false; }
+    int E2 = use_v3 ? E3 : 0;
     if (use_v2) {
         for (int e = a.E; e >= 1; --e)
             if (roll2_lds_bytes(e, kp.N, kp.L, kp.D, S1) <= 160 * 1024) { E2 = e; break; }
@@ -246,7 +254,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     }
     if (E2 > 0) {
         a.E = E2;
-        const size_t shm2 = roll2_lds_bytes(E2, kp.N, kp.L, kp.D, S1);
+        const size_t shm2 = use_v3 ? roll3_lds_bytes(E2, kp.N, kp.L, kp.D, S1) : roll2_lds_bytes(E2, kp.N, kp.L, kp.D, S1);
         const unsigned grid2 = (unsigned)((kp.B + E2 - 1) / E2);
 #define PW_R23(C, NT, SK)                                                                                                \
     do {                                                                                                                 \
@@ -255,7 +263,13 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
             PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout2_kernel<C, NT, SK>),       \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
         }                                                                                                                \
-        hipLaunchKernelGGL((pw_policy_rollout2_kernel<C, NT, SK>), dim3(grid2), dim3(512), shm2, st, P);                 \
+        static unsigned long long attr_set3 = 0;                                                                          \
+        if (lds_optin_needed(&attr_set3)) {                                                                               \
+            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout3_kernel<C, NT, SK>),       \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+        }                                                                                                                \
+        if (use_v3) hipLaunchKernelGGL((pw_policy_rollout3_kernel<C, NT, SK>), dim3(grid2), dim3(512), shm2, st, P);     \
+        else hipLaunchKernelGGL((pw_policy_rollout2_kernel<C, NT, SK>), dim3(grid2), dim3(512), shm2, st, P);            \
     } while (0)
 #define PW_R22(C, NT) do { if (sink) PW_R23(C, NT, true); else PW_R23(C, NT, false); } while (0)
 #define PW_R2(C) case C: PW_R22(C, 0); break;

@@ -393,15 +393,16 @@ def test_one_launch_actor_equals_three_launch_chain(monkeypatch):
     assert torch.equal(one(obs), three(obs))
 
 
-@pytest.mark.parametrize('form', ['default', 'v1', 'v2'])
+@pytest.mark.parametrize('form', ['default', 'v1', 'v2', 'v3'])
 @pytest.mark.parametrize('B,N,T', [(16, 6, 3), (4096, 6, 30), (512, 6, 300), (100, 3, 60), (37, 7, 27), (5, 10, 4), (70, 2, 26),
                                    (9, 12, 26), (33, 16, 26), (7, 24, 5), (4, 30, 3)])
 def test_one_launch_policy_rollout_equals_the_step_loop(B, N, T, form):
     """pw_policy_rollout (T x (actor + sampling + env step) in ONE launch, everything resident on the CU) vs the
     loop of FusedActor() + env.step(): sampled actions, observations, rewards, terminals, pre-reset observations
     and the final world state must be IDENTICAL, across auto-resets, ragged batches and N that does not divide 96.
-    Both kernel forms (phase-by-phase 'v1'; role-specialised waves 'v2', which also serves observation rows too
-    long for v1's LDS budget: N = 24, 30) and the default choice between them."""
+    All kernel forms (phase-by-phase 'v1'; role-specialised waves 'v2', which also serves observation rows too
+    long for v1's LDS budget: N = 24, 30; 'v3': the whole BiLSTM on v_mfma_f32_16x16x4_f32, one timestep per
+    barrier -- N = 30 exceeds its LDS and falls back to v2) and the default choice between them."""
     from multiagent_rl_amd import make_batched_env
     from multiagent_rl_amd.policy import ActorNetwork, FusedActor
     if form == 'v1' and N > 16:
@@ -409,7 +410,7 @@ def test_one_launch_policy_rollout_equals_the_step_loop(B, N, T, form):
     torch.manual_seed(4)
     mk = lambda: make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=25, seed=21)  # noqa: E731
     env_a, env_b = mk(), mk()
-    env_b.set_dispatch(policy_form=dict(default=0, v1=1, v2=2)[form])   # pw_dispatch: the handle carries the selection
+    env_b.set_dispatch(policy_form=dict(default=0, v1=1, v2=2, v3=3)[form])   # pw_dispatch: the handle carries the selection
     actor = ActorNetwork(env_a.obs_dim, 5).cuda().eval()
     loop, one = FusedActor(actor, seed=9), FusedActor(actor, seed=9)
     obs = env_a.reset()

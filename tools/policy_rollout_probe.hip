@@ -48,11 +48,20 @@ int main(int argc, char **argv)
         printf("  total %.0f cycles/step\n", sum / T);
         const char *an[8] = {"fill dir 0 + barrier", "stage 1", "fill dir 1 + barrier", "stage 2 MFMA", "barrier", "recurrence", "barrier", "head"};
         for (int i = 0; i < 8; ++i) printf("    last actor pass: %-24s %8llu cycles\n", an[i], s[i]);
+    } else if (!getenv("PWORLD_POLICY_V2")) {
+        const char *mn[8] = {"dense1 blocks (one per wave)", "  barrier", "  BiLSTM timestep loop (N barriers)", "  head (two barriers inside)", "  env step / noise", "  barrier", "  -", "  -"};
+        for (int wv = 0; wv < 2; ++wv) {
+            double sm = 0; for (int i = 0; i < 8; ++i) sm += s[8 * wv + i];
+            printf(" wave %d\n", 4 * wv);
+            for (int i = 0; i < 8; ++i) printf("  %-44s %9.0f cycles/step %5.1f%%\n", mn[i], s[8 * wv + i] / (double)T, 100.0 * s[8 * wv + i] / sm);
+            printf("  total %.0f cycles/step\n", sm / T);
+        }
     } else {
-        const char *mn[5] = {"matrix wave 0: stage 1 + stage 2 jobs", "  wait B1 (recurrences done)", "  head (B2, B3 inside)", "  env step", "  wait B4"};
+        const char *mn[8] = {"matrix wave 0: stage 1 of tiles 0, 2", "  stage 2 pair (fw 0, rev 2)", "  stage 1 of tile 1", "  stage 2 pair (fw 1, rev 1)", "  stage 2 pair (fw 2, rev 0)", "  wait B1 (recurrences done)", "  head (B2, B3 inside)", "  env step + wait B4"};
         const char *ln[5] = {"LSTM wave 4: waiting for row tiles", "  recurrence", "  wait B1", "  head (B2, B3 inside)", "  wait B4 (env step of waves 0-1)"};
-        double sm = 0, sl = 0; for (int i = 0; i < 5; ++i) { sm += s[i]; sl += s[8 + i]; }
-        for (int i = 0; i < 5; ++i) printf("  %-44s %9.0f cycles/step %5.1f%%\n", mn[i], s[i] / (double)T, 100.0 * s[i] / sm);
+        double sm = 0, sl = 0; for (int i = 0; i < 8; ++i) sm += s[i];
+        for (int i = 0; i < 5; ++i) sl += s[8 + i];
+        for (int i = 0; i < 8; ++i) printf("  %-44s %9.0f cycles/step %5.1f%%\n", mn[i], s[i] / (double)T, 100.0 * s[i] / sm);
         printf("  total %.0f cycles/step\n", sm / T);
         for (int i = 0; i < 5; ++i) printf("  %-44s %9.0f cycles/step %5.1f%%\n", ln[i], s[8 + i] / (double)T, 100.0 * s[8 + i] / sl);
         printf("  total %.0f cycles/step\n", sl / T);
