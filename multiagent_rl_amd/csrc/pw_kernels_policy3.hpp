@@ -37,9 +37,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct Roll3Lds {
     float4 *s_xf;    // [N timesteps][4 j][64 lane]: element e of (j, lane (n, kq)) = x1[row (ts, n)][kpos(16 j + 4 e + kq)]
     float4 *s_hx;    // [2 buffers][2 dir][2 j][64 lane]: element e = h[seq n][16 j + 4 e + kq]
-    float *s_hid;    // [rows][68] head input (relu(h) of both directions), rows env-major
+    float4 *s_hf;    // head input in B-fragment order: [rows / 16 tiles][4 j][64 lane], element e of (j, lane (n, kq)) =
+                     // relu(h)[row 16 tile + n][16 j + 4 e + kq] (k < 32 forward, >= 32 reverse), rows env-major
     float *f_w1;     // [2 m][S1][64 lane]
-    float *s_b1, *s_w2, *s_b2;
+    float *s_b1, *s_b2;
     float *s_noise;  // [rows * 5] Gumbel noise of the coming head
     float *s_obs;    // [rows][DS], DS = D + 2
     int32_t *s_act;  // [rows]
@@ -52,7 +53,7 @@ struct Roll3Lds {
 __host__ __device__ inline size_t roll3_lds_bytes(int E, int N, int L, int D, int S1)
 {
     const size_t rows = (size_t)E * N;
-    size_t fl = (size_t)N * 4 * 64 * 4 + 2 * 2 * 2 * 64 * 4 + rows * kHs + (size_t)2 * S1 * 64 + 64 + 1024 + 16 + rows * 5 + 1 +
+    size_t fl = (size_t)N * 4 * 64 * 4 + 2 * 2 * 2 * 64 * 4 + ((rows + 15) / 16) * 1024 + (size_t)2 * S1 * 64 + 64 + 16 + rows * 5 + 1 +
                 rows * (D + 2) + rows + 1;
     return fl * 4 + 8 * kWave * sizeof(float2) + (size_t)E * L * sizeof(float2) + 16 * (sizeof(double) + sizeof(int)) + 64;
 }
@@ -65,10 +66,9 @@ __device__ __forceinline__ Roll3Lds roll3_carve(unsigned char *raw, int E, int N
     int o = 0;
     S.s_xf = reinterpret_cast<float4 *>(base + o); o += N * 4 * 64 * 4;
     S.s_hx = reinterpret_cast<float4 *>(base + o); o += 2 * 2 * 2 * 64 * 4;
-    S.s_hid = base + o; o += rows * kHs;
+    S.s_hf = reinterpret_cast<float4 *>(base + o); o += ((rows + 15) / 16) * 1024;
     S.f_w1 = base + o; o += 2 * S1 * 64;
     S.s_b1 = base + o; o += 64;
-    S.s_w2 = base + o; o += 1024;
     S.s_b2 = base + o; o += 16;
     S.s_noise = base + o; o += rows * 5;
     o = (o + 1) & ~1;
@@ -114,14 +114,12 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
         const float4 *src = reinterpret_cast<const float4 *>(A.frag + 8 * 2 * 4 * 64 * 4);
         for (int f = tid; f < (2 * S1 * 64) / 4; f += 512) reinterpret_cast<float4 *>(S.f_w1)[f] = src[f];
         if (tid < 64) S.s_b1[tid] = A.b1[tid];
-        for (int f = tid; f < OUT * 64; f += 512) S.s_w2[f] = A.w2[f];
         if (tid < OUT) S.s_b2[tid] = A.b2[tid];
     }
 
-    // Gumbel noise of one head evaluation (as in the second form): called by the 256 threads of waves 4-7 (t0 = their
-    // index) while the environment step runs
-    auto draw_noise = [&](const uint64_t step, const int t0) {
-        for (int idx = t0; idx < rows_here * OUT; idx += 256) {
+    // Gumbel noise of one head evaluation (as in the second form): called by `nthr` threads (t0 = their index)
+    auto draw_noise = [&](const uint64_t step, const int t0, const int nthr) {
+        for (int idx = t0; idx < rows_here * OUT; idx += nthr) {
             const int r = idx / OUT, o = idx - r * OUT;
             const long grow = row_base + r;
             const uint32_t blk = (uint32_t)o >> 2, tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
@@ -135,49 +133,23 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
         }
     };
 
-    // the head: thread = (row, logit), then one thread per row picks the arg-max (actor_forward_wg's arithmetic)
-    auto head = [&]() {
-        for (int idx = tid; idx < rows_here * OUT; idx += 512) {
-            const int r = idx / OUT, o = idx - r * OUT;
-            float acc = S.s_b2[o];
-            const float4 *hv = reinterpret_cast<const float4 *>(S.s_hid + r * kHs), *wv = reinterpret_cast<const float4 *>(S.s_w2 + o * 64);
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) {
-                const float4 hq4 = hv[q], wq = wv[q];
-                acc = __builtin_fmaf(wq.x, hq4.x, acc);
-                acc = __builtin_fmaf(wq.y, hq4.y, acc);
-                acc = __builtin_fmaf(wq.z, hq4.z, acc);
-                acc = __builtin_fmaf(wq.w, hq4.w, acc);
-            }
-            S.s_lg[idx] = acc - S.s_noise[idx];
-        }
-        wg_lds_barrier();
-        for (int r = tid; r < rows_here; r += 512) {
-            const float *v = S.s_lg + r * OUT;
-            int best = 0;
-            float bv = v[0];
-#pragma unroll
-            for (int o = 1; o < OUT; ++o)
-                if (v[o] > bv) { bv = v[o]; best = o; }
-            S.s_act[r] = best;
-        }
-        wg_lds_barrier();
-    };
-
     // ---- environment lanes (as the other forms): wave w < n_env_waves owns local envs [w * epw, ...)
     const int epw_max = E < kWave / N ? E : kWave / N;
     const int waves_full = (E + epw_max - 1) / epw_max;
     const int epw = (E + waves_full - 1) / waves_full;
     const int n_env_waves = (envs_here + epw - 1) / epw;  // <= 8 (N <= 32)
-    const bool env_wave = wave < n_env_waves;
+    // the LAST waves: after a step they finish its rewards and stores while the first waves (dense1 blocks are dealt from
+    // wave 0 up) already work on the next one
+    const int ew = wave - (8 - n_env_waves);
+    const bool env_wave = ew >= 0;
     int e_loc = lane / N, a = lane - e_loc * N;
-    int el = wave * epw + e_loc;
+    int el = ew * epw + e_loc;
     const bool live = env_wave && e_loc < epw && el < envs_here;
-    if (!live) { e_loc = 0; a = 0; el = env_wave ? wave * epw : 0; }
+    if (!live) { e_loc = 0; a = 0; el = env_wave ? ew * epw : 0; }
     const int base = e_loc * N, r = el * N + a;
     const long env = env0 + el;
     const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
-    float2 *s_pos = S.s_posb + (env_wave ? wave : 0) * kWave;
+    float2 *s_pos = S.s_posb + (env_wave ? ew : 0) * kWave;
     const float2 *pp = s_pos + base;
     float2 *lmv = S.s_lmb + el * L;
     const int la = a < L ? a : 0;
@@ -232,12 +204,51 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
             for (int i = 0; i < 4; ++i) bias[T][i] = A.bih[dir * 128 + i * 32 + hq * 8 + 4 * T + kq];  // accumulator role: rg = kq
         }
     }
+    float aw2[16];  // head weights as A fragments: tile row = logit (5 of 16 rows used)
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) aw2[sx] = n16 < OUT ? A.w2[n16 * 64 + 4 * sx + kq] : 0.0f;
     const int unit0 = hq * 8 + kq;  // this lane's cells: units unit0 and unit0 + 4 of sequence n16
     const bool seq_ok = n16 < envs_here;
+    // the Gumbel noise of a step is drawn at its start by the waves without environment duty (all of them if those are few)
+    const int noise_thr = n_env_waves <= 4 ? (8 - n_env_waves) * 64 : 512;
     wg_lds_barrier();  // constants in LDS
-    if (wave >= 4) draw_noise(step0, tid - 256);
+    if (tid < noise_thr) draw_noise(step0, tid, noise_thr);
     wg_lds_barrier();  // first observation rows and first noise in LDS
     PW_R2_DECL;
+
+    // the head on the matrix cores: logits^T [16 (5 used) x 16 rows] = W2 [16 x 64] * relu(h)^T per 16-row tile, C-in = b2, k
+    // ascending -- the chain of actor_forward_wg's head (b2, then one fused multiply-add per hidden unit) -- then minus the
+    // Gumbel noise and the arg-max (first maximum wins) in the lanes: row group 0 holds logits 0..3 of its row, row group 1
+    // logit 4.  Wave w serves tiles w, w + 8, ..; one barrier afterwards.
+    auto head = [&]() {
+        const int ntile = (rows_here + 15) >> 4;
+        for (int tile = wave; tile < ntile; tile += 8) {
+            f32x4 lg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lg[i] = 4 * kq + i < OUT ? S.s_b2[4 * kq + i] : 0.0f;
+            const float4 *hf = S.s_hf + (tile * 4) * 64 + lane;
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) {
+                const float4 b = hf[jx * 64];
+                lg = __builtin_amdgcn_mfma_f32_16x16x4f32(aw2[4 * jx + 0], b.x, lg, 0, 0, 0);
+                lg = __builtin_amdgcn_mfma_f32_16x16x4f32(aw2[4 * jx + 1], b.y, lg, 0, 0, 0);
+                lg = __builtin_amdgcn_mfma_f32_16x16x4f32(aw2[4 * jx + 2], b.z, lg, 0, 0, 0);
+                lg = __builtin_amdgcn_mfma_f32_16x16x4f32(aw2[4 * jx + 3], b.w, lg, 0, 0, 0);
+            }
+            const int rr = tile * 16 + n16;
+            const float *nz = S.s_noise + (rr < rows_here ? rr : 0) * OUT;
+            const float p0 = lg[0] - nz[kq == 1 ? 4 : 0], p1 = lg[1] - nz[1], p2 = lg[2] - nz[2], p3 = lg[3] - nz[3];
+            const float p4 = __shfl(p0, n16 + 16, kWave);  // logit 4 lives in register 0 of row group 1
+            int best = 0;
+            float bv = p0;
+            if (p1 > bv) { bv = p1; best = 1; }
+            if (p2 > bv) { bv = p2; best = 2; }
+            if (p3 > bv) { bv = p3; best = 3; }
+            if (p4 > bv) { bv = p4; best = 4; }
+            if (kq == 0 && rr < rows_here) S.s_act[rr] = best;
+        }
+        wg_lds_barrier();
+    };
 
     // input projection of timestep ts for this wave's two tiles (+ bias)
     auto inproj = [&](const int ts, f32x4 (&acc)[2]) {
@@ -260,6 +271,69 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
         for (int T = 0; T < 2; ++T)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[T][i] += bias[T][i];
+    };
+
+    // second part of the environment step t (positions and velocities already advanced): partner pass, rewards, outputs,
+    // ring append, episode bookkeeping, auto-reset; `publish`: also write the next observation row to LDS
+    int ai = 0;
+    size_t slot = 0;
+    auto env_tail = [&](const int t, const bool publish) {
+        const size_t tBN = (size_t)t * BN;
+        wave_lds_sync();
+        if (live) s_pos[base + a] = make_float2(px, py);
+        wave_lds_sync();
+        stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
+        const float own = sqrtf(best);
+        float rw = 0.0f;
+#pragma unroll(LT > 0 ? LT : 1)
+        for (int l = 0; l < L; ++l) rw -= __shfl(own, base + l, kWave);
+#pragma unroll(NT > 0 ? NT : 1)
+        for (int j = 0; j < N; ++j)
+            if ((coll >> j) & 1) rw -= 1.0f;
+        float acc = 0.0f;
+#pragma unroll(NT > 0 ? NT : 1)
+        for (int i = 0; i < N; ++i) acc += __shfl(rw, base + i, kWave);
+        ep_step += 1;
+        const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
+        if (live) {
+            if (P.act_out) P.act_out[tBN + g] = ai;
+            if (V.rew) V.rew[tBN + g] = rw;
+            if (V.done) V.done[tBN + g] = 0;
+            if (a == 0) {
+                if (V.rew_shared) V.rew_shared[(size_t)t * A.B + env] = acc;
+                if (V.terminal) V.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+            }
+            if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
+                stream_write_obs<LT>(P.ring.next_obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
+                if (a == 0) { P.ring.rew[slot] = acc; P.ring.done[slot] = 0.0f; }
+            }
+            if (SINK && a == 0 && P.episode_return) {  // run.py:55-65, per env
+                const float rsum = ep_ret + acc;
+                if (term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
+                else ep_ret = rsum;
+            }
+        }
+        if (term && V.auto_reset) {  // same for every lane of an env
+            if (live && V.final_obs) stream_write_obs<LT>(V.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+            wave_lds_sync();
+            ep_count += 1;
+            ep_step = 0;
+            const uint64_t env_id = V.env_id_base + (uint64_t)env;
+            pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
+            vx = 0.f; vy = 0.f;
+            if (L > 0) {
+                pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)(N + la), -1.0f, 1.0f, &olx, &oly);
+                if (live) lmv[la] = make_float2(olx, oly);
+            }
+            if (live) s_pos[base + a] = make_float2(px, py);
+        }
+        wave_lds_sync();
+        if (V.auto_reset && __any(term))
+            stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
+        if (live) {
+            if (V.obs) stream_write_obs<LT>(V.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
+            if (publish) lds_write_obs_row<LT>(S.s_obs + r * DS, L, lmv, px, py, vx, vy);
+        }
     };
 
     for (int t = 0; t < P.T; ++t) {
@@ -300,6 +374,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
                         dst[qh * 64 + ql * 32] = make_float4(v[8 * qh + ql], v[8 * qh + 2 + ql], v[8 * qh + 4 + ql], v[8 * qh + 6 + ql]);
             }
         }
+        if (t > 0 && tid < noise_thr) draw_noise(step0 + (uint64_t)t, tid, noise_thr);  // for this step's head
         PW_R2_STAMP(0);
         wg_lds_barrier();  // the x1 fragments are in LDS
         PW_R2_STAMP(1);
@@ -338,10 +413,10 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
                 // h exchange: unit u = hq * 8 + 4 T + kq is k quarter kq of k step 2 hq + T: fragment j = hq / 2, elements
                 // (2 hq) % 4 + T of this very lane slot
                 reinterpret_cast<float2 *>(S.s_hx + (((s2 & 1) * 2 + dir) * 2 + (hq >> 1)) * 64 + lane)[hq & 1] = make_float2(h0v, h1v);
-                if (seq_ok) {
-                    float *hd = S.s_hid + (n16 * N + ts) * kHs + dir * 32 + unit0;
-                    hd[0] = A.relu_out ? fmaxf(h0v, 0.0f) : h0v;
-                    hd[4] = A.relu_out ? fmaxf(h1v, 0.0f) : h1v;
+                if (seq_ok) {  // head input: row n16 * N + ts, k = dir * 32 + unit -> fragment 2 dir + hq / 2, same element pair
+                    const int rr = n16 * N + ts;
+                    reinterpret_cast<float2 *>(S.s_hf + ((rr >> 4) * 4 + 2 * dir + (hq >> 1)) * 64 + kq * 16 + (rr & 15))[hq & 1] =
+                        make_float2(A.relu_out ? fmaxf(h0v, 0.0f) : h0v, A.relu_out ? fmaxf(h1v, 0.0f) : h1v);
                 }
                 if (s2 + 1 < N) inproj(dir ? N - 2 - s2 : s2 + 1, accn);  // before the barrier: work for the matrix pipe while the workgroup meets
                 wg_lds_barrier();  // h(ts) of every unit is in LDS (the last one: Hs complete)
@@ -351,14 +426,16 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
             wg_lds_barrier();
         }
         PW_R2_STAMP(2);
-        head();  // two barriers inside
+        head();  // one barrier inside
         PW_R2_STAMP(3);
 
-        // ---- environment step (pw_spread_stream_kernel's arithmetic)
+        // ---- environment step (pw_spread_stream_kernel's arithmetic), in two parts: advance the agents and publish the next
+        // observation rows (everybody waits for those), then -- behind the barrier, while the other waves start the next
+        // actor pass -- the partner pass, rewards, stores and bookkeeping (env_tail).  A wave with an episode ending this
+        // step runs the tail first: the rows to publish are the post-reset ones.
+        bool tail_pending = false;
         if (env_wave) {
-            const size_t tBN = (size_t)t * BN;
-            const int ai = S.s_act[r];
-            size_t slot = 0;
+            ai = S.s_act[r];
             if (SINK && P.has_ring) {  // the observation the policy acted on (still in LDS) -> ring.obs
                 slot = (size_t)((P.ring_start + (int64_t)t * A.B + env) % P.ring.capacity);
                 if (live) {
@@ -379,69 +456,21 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
             vy = vy + (fy / mass) * dt;
             px = px + vx * dt;
             py = py + vy * dt;
-            wave_lds_sync();
-            if (live) s_pos[base + a] = make_float2(px, py);
-            wave_lds_sync();
-            stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
-            const float own = sqrtf(best);
-            float rw = 0.0f;
-#pragma unroll(LT > 0 ? LT : 1)
-            for (int l = 0; l < L; ++l) rw -= __shfl(own, base + l, kWave);
-#pragma unroll(NT > 0 ? NT : 1)
-            for (int j = 0; j < N; ++j)
-                if ((coll >> j) & 1) rw -= 1.0f;
-            float acc = 0.0f;
-#pragma unroll(NT > 0 ? NT : 1)
-            for (int i = 0; i < N; ++i) acc += __shfl(rw, base + i, kWave);
-            ep_step += 1;
-            const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
-            if (live) {
-                if (P.act_out) P.act_out[tBN + g] = ai;
-                if (V.rew) V.rew[tBN + g] = rw;
-                if (V.done) V.done[tBN + g] = 0;
-                if (a == 0) {
-                    if (V.rew_shared) V.rew_shared[(size_t)t * A.B + env] = acc;
-                    if (V.terminal) V.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
-                }
-                if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
-                    stream_write_obs<LT>(P.ring.next_obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
-                    if (a == 0) { P.ring.rew[slot] = acc; P.ring.done[slot] = 0.0f; }
-                }
-                if (SINK && a == 0 && P.episode_return) {  // run.py:55-65, per env
-                    const float rsum = ep_ret + acc;
-                    if (term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
-                    else ep_ret = rsum;
-                }
-            }
-            if (term && V.auto_reset) {  // same for every lane of an env
-                if (live && V.final_obs) stream_write_obs<LT>(V.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
-                wave_lds_sync();
-                ep_count += 1;
-                ep_step = 0;
-                const uint64_t env_id = V.env_id_base + (uint64_t)env;
-                pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
-                vx = 0.f; vy = 0.f;
-                if (L > 0) {
-                    pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)(N + la), -1.0f, 1.0f, &olx, &oly);
-                    if (live) lmv[la] = make_float2(olx, oly);
-                }
-                if (live) s_pos[base + a] = make_float2(px, py);
-            }
-            wave_lds_sync();
-            if (V.auto_reset && __any(term))
-                stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
-            if (live) {
-                if (V.obs) stream_write_obs<LT>(V.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
-                lds_write_obs_row<LT>(S.s_obs + r * DS, L, lmv, px, py, vx, vy);
+            const bool ends = V.auto_reset && V.max_episode_len > 0 && ep_step + 1 >= V.max_episode_len;
+            if (__any(ends)) env_tail(t, true);
+            else {
+                if (live) lds_write_obs_row<LT>(S.s_obs + r * DS, L, lmv, px, py, vx, vy);
+                tail_pending = true;
             }
         }
-        if (wave >= 4 && t + 1 < P.T) draw_noise(step0 + (uint64_t)(t + 1), tid - 256);  // beside the environment step
         PW_R2_STAMP(4);
-        wg_lds_barrier();  // the next observation rows (and the next noise) are in LDS
+        wg_lds_barrier();  // the next observation rows are in LDS
         PW_R2_STAMP(5);
+        if (tail_pending) env_tail(t, false);
+        PW_R2_STAMP(6);
     }
     if (wave == 0) PW_R2_FLUSH(0);
-    if (wave == 4) PW_R2_FLUSH(8);
+    if (wave == 7) PW_R2_FLUSH(8);
 
     if (live) {
         V.pos_x[g] = px; V.pos_y[g] = py;
