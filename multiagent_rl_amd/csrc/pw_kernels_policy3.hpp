@@ -117,19 +117,26 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
         if (tid < OUT) S.s_b2[tid] = A.b2[tid];
     }
 
-    // Gumbel noise of one head evaluation (as in the second form): called by `nthr` threads (t0 = their index)
+    // Gumbel noise of one head evaluation: value (row, logit o) = log(-log(u)), u = word (o & 3) of Philox block (o >> 2) keyed
+    // (seed; step, global row) exactly as actor_forward_wg / pw_actor_head_kernel.  One thread per (row, block) -- the four
+    // words of a block serve four logits -- called by `nthr` threads (t0 = their index)
     auto draw_noise = [&](const uint64_t step, const int t0, const int nthr) {
-        for (int idx = t0; idx < rows_here * OUT; idx += nthr) {
-            const int r = idx / OUT, o = idx - r * OUT;
-            const long grow = row_base + r;
-            const uint32_t blk = (uint32_t)o >> 2, tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
+        constexpr int NB = (OUT + 3) / 4;
+        for (int idx = t0; idx < rows_here * NB; idx += nthr) {
+            const int rr = idx / NB;
+            const uint32_t blk = (uint32_t)(idx - rr * NB), tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
+            const long grow = row_base + rr;
             uint32_t u[4];
             pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | tag, (uint32_t)step, (uint32_t)(step >> 32),
                              (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
-            const int wq = o & 3;
-            const uint32_t uw = wq == 0 ? u[0] : wq == 1 ? u[1] : wq == 2 ? u[2] : u[3];
-            const float uo = ((float)(uw >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
-            S.s_noise[idx] = __logf(-__logf(uo));
+#pragma unroll
+            for (int wq = 0; wq < 4; ++wq) {
+                const int o = 4 * (int)blk + wq;
+                if (o < OUT) {
+                    const float uo = ((float)(u[wq] >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
+                    S.s_noise[rr * OUT + o] = __logf(-__logf(uo));
+                }
+            }
         }
     };
 
@@ -209,8 +216,9 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
     for (int sx = 0; sx < 16; ++sx) aw2[sx] = n16 < OUT ? A.w2[n16 * 64 + 4 * sx + kq] : 0.0f;
     const int unit0 = hq * 8 + kq;  // this lane's cells: units unit0 and unit0 + 4 of sequence n16
     const bool seq_ok = n16 < envs_here;
-    // the Gumbel noise of a step is drawn at its start by the waves without environment duty (all of them if those are few)
-    const int noise_thr = n_env_waves <= 4 ? (8 - n_env_waves) * 64 : 512;
+    // the Gumbel noise of the next step is drawn by the waves without environment duty while the environment waves advance
+    // the agents (by everybody, first, when every wave has environment duty: N > 24)
+    const int noise_thr = n_env_waves < 8 ? (8 - n_env_waves) * 64 : 512;
     wg_lds_barrier();  // constants in LDS
     if (tid < noise_thr) draw_noise(step0, tid, noise_thr);
     wg_lds_barrier();  // first observation rows and first noise in LDS
@@ -273,12 +281,18 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
             for (int i = 0; i < 4; ++i) acc[T][i] += bias[T][i];
     };
 
-    // second part of the environment step t (positions and velocities already advanced): partner pass, rewards, outputs,
-    // ring append, episode bookkeeping, auto-reset; `publish`: also write the next observation row to LDS
+    // The rest of environment step t once positions and velocities are advanced, in two pieces so that each fits a window in
+    // which the environment waves have nothing else to do:
+    //   tail_compute  partner pass on the new positions (the next step's forces need its near mask), rewards, episode
+    //                 bookkeeping -- beside the next step's dense1 blocks (the first waves)
+    //   tail_stores   every global store of the step -- beside the next step's head tiles (the first waves again)
+    // A wave with an episode ending in this step runs both, the reset and the post-reset partner pass before it publishes
+    // the next observation rows (env_step_with_reset).
     int ai = 0;
     size_t slot = 0;
-    auto env_tail = [&](const int t, const bool publish) {
-        const size_t tBN = (size_t)t * BN;
+    float t_rw = 0.f, t_acc = 0.f;
+    bool t_term = false;
+    auto tail_compute = [&]() {
         wave_lds_sync();
         if (live) s_pos[base + a] = make_float2(px, py);
         wave_lds_sync();
@@ -294,25 +308,37 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
 #pragma unroll(NT > 0 ? NT : 1)
         for (int i = 0; i < N; ++i) acc += __shfl(rw, base + i, kWave);
         ep_step += 1;
-        const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
+        t_term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
+        t_rw = rw;
+        t_acc = acc;
+        if (SINK && live && a == 0 && P.episode_return) {  // run.py:55-65, per env
+            const float rsum = ep_ret + acc;
+            if (t_term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
+            else ep_ret = rsum;
+        }
+    };
+    auto tail_stores = [&](const int t, const bool with_obs) {  // with_obs: V.obs too (no reset in between: the same row)
+        const size_t tBN = (size_t)t * BN;
         if (live) {
             if (P.act_out) P.act_out[tBN + g] = ai;
-            if (V.rew) V.rew[tBN + g] = rw;
+            if (V.rew) V.rew[tBN + g] = t_rw;
             if (V.done) V.done[tBN + g] = 0;
             if (a == 0) {
-                if (V.rew_shared) V.rew_shared[(size_t)t * A.B + env] = acc;
-                if (V.terminal) V.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
+                if (V.rew_shared) V.rew_shared[(size_t)t * A.B + env] = t_acc;
+                if (V.terminal) V.terminal[(size_t)t * A.B + env] = t_term ? 1 : 0;
             }
             if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
                 stream_write_obs<LT>(P.ring.next_obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
-                if (a == 0) { P.ring.rew[slot] = acc; P.ring.done[slot] = 0.0f; }
+                if (a == 0) { P.ring.rew[slot] = t_acc; P.ring.done[slot] = 0.0f; }
             }
-            if (SINK && a == 0 && P.episode_return) {  // run.py:55-65, per env
-                const float rsum = ep_ret + acc;
-                if (term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
-                else ep_ret = rsum;
-            }
+            if (with_obs && V.obs) stream_write_obs<LT>(V.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
         }
+    };
+    auto env_step_with_reset = [&](const int t) {
+        const size_t tBN = (size_t)t * BN;
+        tail_compute();
+        tail_stores(t, false);
+        const bool term = t_term;
         if (term && V.auto_reset) {  // same for every lane of an env
             if (live && V.final_obs) stream_write_obs<LT>(V.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
             wave_lds_sync();
@@ -332,12 +358,14 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
             stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
         if (live) {
             if (V.obs) stream_write_obs<LT>(V.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
-            if (publish) lds_write_obs_row<LT>(S.s_obs + r * DS, L, lmv, px, py, vx, vy);
+            lds_write_obs_row<LT>(S.s_obs + r * DS, L, lmv, px, py, vx, vy);
         }
     };
+    int tail_stage = 0;  // 0 nothing pending; 1: tail_compute of step t - 1 pending; 2: its tail_stores pending
 
     for (int t = 0; t < P.T; ++t) {
         PW_R2_START;
+        if (tail_stage == 1) { tail_compute(); tail_stage = 2; }  // step t - 1, beside the dense1 blocks of the first waves
         // ---- dense1 + ReLU: 32 x 32 blocks of relu(W1 X^T + b1), column rho = 16 * timestep + sequence
         for (int blk = wave; blk < nblk && !PW_DBG(1); blk += 8) {
             const int rt = blk >> 1, m = blk & 1;
@@ -374,7 +402,6 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
                         dst[qh * 64 + ql * 32] = make_float4(v[8 * qh + ql], v[8 * qh + 2 + ql], v[8 * qh + 4 + ql], v[8 * qh + 6 + ql]);
             }
         }
-        if (t > 0 && tid < noise_thr) draw_noise(step0 + (uint64_t)t, tid, noise_thr);  // for this step's head
         PW_R2_STAMP(0);
         wg_lds_barrier();  // the x1 fragments are in LDS
         PW_R2_STAMP(1);
@@ -426,6 +453,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
             wg_lds_barrier();
         }
         PW_R2_STAMP(2);
+        if (tail_stage == 2) { tail_stores(t - 1, true); tail_stage = 0; }  // beside the head tiles of the first waves
         head();  // one barrier inside
         PW_R2_STAMP(3);
 
@@ -433,7 +461,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
         // observation rows (everybody waits for those), then -- behind the barrier, while the other waves start the next
         // actor pass -- the partner pass, rewards, stores and bookkeeping (env_tail).  A wave with an episode ending this
         // step runs the tail first: the rows to publish are the post-reset ones.
-        bool tail_pending = false;
+        if (t + 1 < P.T && tid < noise_thr) draw_noise(step0 + (uint64_t)(t + 1), tid, noise_thr);  // this one is consumed
         if (env_wave) {
             ai = S.s_act[r];
             if (SINK && P.has_ring) {  // the observation the policy acted on (still in LDS) -> ring.obs
@@ -457,18 +485,19 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
             px = px + vx * dt;
             py = py + vy * dt;
             const bool ends = V.auto_reset && V.max_episode_len > 0 && ep_step + 1 >= V.max_episode_len;
-            if (__any(ends)) env_tail(t, true);
+            if (__any(ends)) env_step_with_reset(t);
             else {
                 if (live) lds_write_obs_row<LT>(S.s_obs + r * DS, L, lmv, px, py, vx, vy);
-                tail_pending = true;
+                tail_stage = 1;
             }
         }
         PW_R2_STAMP(4);
         wg_lds_barrier();  // the next observation rows are in LDS
         PW_R2_STAMP(5);
-        if (tail_pending) env_tail(t, false);
         PW_R2_STAMP(6);
     }
+    if (tail_stage == 1) tail_compute();
+    if (tail_stage != 0) tail_stores(P.T - 1, true);
     if (wave == 0) PW_R2_FLUSH(0);
     if (wave == 7) PW_R2_FLUSH(8);
 

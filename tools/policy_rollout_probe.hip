@@ -49,7 +49,7 @@ int main(int argc, char **argv)
         const char *an[8] = {"fill dir 0 + barrier", "stage 1", "fill dir 1 + barrier", "stage 2 MFMA", "barrier", "recurrence", "barrier", "head"};
         for (int i = 0; i < 8; ++i) printf("    last actor pass: %-24s %8llu cycles\n", an[i], s[i]);
     } else if (!getenv("PWORLD_POLICY_V2")) {
-        const char *mn[8] = {"dense1 block + Gumbel noise", "  barrier", "  BiLSTM timestep loop (N barriers)", "  head (one barrier inside)", "  env step, part 1 (env waves)", "  barrier", "  env step, tail (env waves)", "  -"};
+        const char *mn[8] = {"dense1 block", "  barrier", "  BiLSTM timestep loop (N barriers)", "  head (one barrier inside)", "  env step, part 1 (env waves) / noise", "  barrier", "  env step, tail (env waves)", "  -"};
         for (int wv = 0; wv < 2; ++wv) {
             double sm = 0; for (int i = 0; i < 8; ++i) sm += s[8 * wv + i];
             printf(" wave %d\n", 7 * wv);
