@@ -218,9 +218,11 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
     const bool seq_ok = n16 < envs_here;
     // the Gumbel noise of the next step is drawn by the waves without environment duty while the environment waves advance
     // the agents (by everybody, first, when every wave has environment duty: N > 24)
-    const int noise_thr = n_env_waves < 8 ? (8 - n_env_waves) * 64 : 512;
+    // With two environment waves (6 and 7: SIMDs 2 and 3) the noise goes to waves 0, 1, 4, 5 -- the other two SIMDs.
+    const int noise_thr = n_env_waves == 2 ? 256 : n_env_waves < 8 ? (8 - n_env_waves) * 64 : 512;
+    const int noise_t0 = n_env_waves == 2 ? ((wave & 2) ? 512 : (wave >> 2) * 128 + (wave & 1) * 64 + lane) : tid;
     wg_lds_barrier();  // constants in LDS
-    if (tid < noise_thr) draw_noise(step0, tid, noise_thr);
+    if (noise_t0 < noise_thr) draw_noise(step0, noise_t0, noise_thr);
     wg_lds_barrier();  // first observation rows and first noise in LDS
     PW_R2_DECL;
 
@@ -461,7 +463,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
         // observation rows (everybody waits for those), then -- behind the barrier, while the other waves start the next
         // actor pass -- the partner pass, rewards, stores and bookkeeping (env_tail).  A wave with an episode ending this
         // step runs the tail first: the rows to publish are the post-reset ones.
-        if (t + 1 < P.T && tid < noise_thr) draw_noise(step0 + (uint64_t)(t + 1), tid, noise_thr);  // this one is consumed
+        if (t + 1 < P.T && noise_t0 < noise_thr) draw_noise(step0 + (uint64_t)(t + 1), noise_t0, noise_thr);  // this step's is consumed
         if (env_wave) {
             ai = S.s_act[r];
             if (SINK && P.has_ring) {  // the observation the policy acted on (still in LDS) -> ring.obs

@@ -232,9 +232,9 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     // waves, weights resident in registers, as many environments per workgroup as fit 160 KB of LDS (D <= 64: N <= 30).
     // pw_policy_rollout3_kernel (pw_kernels_policy3.hpp): the whole BiLSTM on v_mfma_f32_16x16x4_f32, one timestep per
     // barrier, 16 environments per workgroup at any N; its dense1 output takes 4 KB of LDS per agent, so the environments per
-    // workgroup shrink past N = 12.  Measured at B = 4096, us per step, forms 1 / 2 / 3 (profiles/r3_policy_forms.txt):
-    // N = 3: 16.0 / 13.9 / 9.7; N = 6: 24.2 / 21.6 / 15.6; N = 12: 65.8 / 65.1 / 32.7; N = 16: 114.7 / 165.8 / 84.6;
-    // N = 24: - / 405 / 483 -- the third form runs wherever it keeps >= 8 environments per workgroup, then the old rule
+    // workgroup shrink past N = 12.  Measured at B = 4096, us per step, forms 1 / 2 / 3 (profiles/r3_policy_phases.txt):
+    // N = 3: 15.9 / 13.7 / 8.5; N = 6: 23.2 / 21.0 / 13.9; N = 12: 65.3 / 64.8 / 32.5; N = 16: 113.7 / 165.0 / 86.4;
+    // N = 24: - / 404 / 485 -- the third form runs wherever it keeps >= 8 environments per workgroup, then the old rule
     // (the second where it wins, N <= 6, or where the first does not fit).  pw_dispatch.policy_form overrides.
     const size_t shm = actor_lds_bytes(S1) + (size_t)kFusedRows * kp.D * sizeof(float) + kFusedRows * sizeof(int32_t) +
                        2 * kWave * sizeof(float2) + (size_t)a.E * kp.L * sizeof(float2) + 16 * (sizeof(double) + sizeof(int));
