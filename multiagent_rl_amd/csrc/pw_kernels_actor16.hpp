@@ -1,0 +1,303 @@
+// pw_kernels_actor16.hpp -- part of libpworld.so (translation unit csrc/pworld_policy.hip includes it).
+// One forward pass of the actor (dense1 + ReLU, BiLSTM over the agent axis, head(s) + Gumbel arg-max) for the <= 16
+// environments of a workgroup with the whole BiLSTM on v_mfma_f32_16x16x4_f32 -- the core of the third rollout form
+// (pw_kernels_policy3.hpp explains the design) as a function, for the kernels that run an actor pass between other work:
+// pw_actor_fused16_kernel (one pass per launch), the simple_reference and simple_tag one-launch rollouts.
+#pragma once
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS of the pass (floats from a 16-byte aligned base): dense1 output and head input in B-fragment order, the h exchange,
+// the dense1 constants
+struct Actor16Lds {
+    float4 *s_xf;  // [N timesteps][4 j][64 lane]: element e of (j, lane (n, kq)) = x1[row (ts, n)][x1_kpos(16 j + 4 e + kq)]
+    float4 *s_hx;  // [2 buffers][2 dir][2 j][64 lane]: element e = h[seq n][16 j + 4 e + kq]
+    float4 *s_hf;  // [rows / 16 tiles][4 j][64 lane]: element e = relu(h)[row 16 tile + n][16 j + 4 e + kq], rows env-major
+    float *f_w1;   // [2 m][S1][64 lane]
+    float *s_b1;   // [64]
+    float *end;
+};
+__host__ __device__ inline size_t actor16_lds_floats(int N, int rows, int S1)
+{
+    return (size_t)N * 1024 + 2048 + (size_t)((rows + 15) / 16) * 1024 + (size_t)2 * S1 * 64 + 64;
+}
+__device__ __forceinline__ Actor16Lds actor16_carve(float *base, int N, int rows, int S1)
+{
+    Actor16Lds S;
+    int o = 0;
+    S.s_xf = reinterpret_cast<float4 *>(base + o); o += N * 1024;
+    S.s_hx = reinterpret_cast<float4 *>(base + o); o += 2048;
+    S.s_hf = reinterpret_cast<float4 *>(base + o); o += ((rows + 15) / 16) * 1024;
+    S.f_w1 = base + o; o += 2 * S1 * 64;
+    S.s_b1 = base + o; o += 64;
+    S.end = base + o;
+    return S;
+}
+
+// A wave's resident weights (wave = (direction wave / 4, hidden quarter wave % 4) of a 512-thread workgroup).  MFMA 16x16x4
+// lane roles: as A operand lane = (tile row ar = lane % 16, k quarter kq = lane / 16); as B operand / accumulator lane =
+// (column n = lane % 16, kq resp. row group rg = lane / 16).  LSTM tile row ar = 4 * (unit within tile) + gate: W row
+// gate * 32 + hq * 8 + 4 * tile + ar / 4 of the direction; head tile row = logit.
+struct Actor16W {
+    float aih[2][16], ahh[2][8], bias[2][4];
+    float aw2[16], b2c[4];
+};
+
+// weights -> registers, dense1 constants -> LDS; a workgroup barrier must follow before the first pass
+template <int S1C>
+__device__ __forceinline__ void actor16_load(const ActorFusedArgs &A, const Actor16Lds &S, Actor16W &W)
+{
+    constexpr int S1 = 4 * S1C;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = wave >> 2, hq = wave & 3, n16 = lane & 15, kq = lane >> 4;
+    const int OUT = A.n_out0 + A.n_out1;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(A.frag + 8 * 2 * 4 * 64 * 4);
+        for (int f = tid; f < (2 * S1 * 64) / 4; f += 512) reinterpret_cast<float4 *>(S.f_w1)[f] = src[f];
+        if (tid < 64) S.s_b1[tid] = A.b1[tid];
+    }
+    const float *whh = dir ? A.whh_r : A.whh_f;
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        const int wrow = (n16 & 3) * 32 + hq * 8 + 4 * T + (n16 >> 2);  // within the direction: gate * 32 + unit
+        // W_ih rows dir * 128 + wrow, k in the projection's summation order: the third section of pw_actor_front_pack's image
+        const float4 *f16 = reinterpret_cast<const float4 *>(A.frag + actor_frag16_offset(S1)) + ((wave * 2 + T) * 4) * 64 + lane;
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            const float4 q = f16[jx * 64];
+            W.aih[T][4 * jx + 0] = q.x; W.aih[T][4 * jx + 1] = q.y; W.aih[T][4 * jx + 2] = q.z; W.aih[T][4 * jx + 3] = q.w;
+        }
+#pragma unroll
+        for (int sx = 0; sx < 8; ++sx) W.ahh[T][sx] = whh[wrow * 32 + 4 * sx + kq];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) W.bias[T][i] = A.bih[dir * 128 + i * 32 + hq * 8 + 4 * T + kq];  // accumulator role: rg = kq
+    }
+#pragma unroll
+    for (int sx = 0; sx < 16; ++sx) W.aw2[sx] = n16 < OUT ? A.w2[n16 * 64 + 4 * sx + kq] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) W.b2c[i] = 4 * kq + i < OUT ? A.b2[4 * kq + i] : 0.0f;
+}
+
+// One pass for the rows of this workgroup (all 512 threads call it; E <= 16 environments, rows env-major r = e * N + agent).
+//   xrows, xstride  observation rows [rows_here][xstride >= A.D] -- global memory or LDS (readable on entry)
+//   step            Philox step of the Gumbel noise: value (row, logit o) = log(-log(u)), u = word (o & 3) of Philox block
+//                   (o >> 2) keyed (seed; step, global row), as pw_actor_head_kernel -- block rg is exactly what the lanes of
+//                   row group rg need for their four logits
+//   act_g / act_l   sinks of the sampled indices [rows_here * nheads], global / LDS (either may be NULL); A.H, A.logits too
+// Arithmetic: element for element the operation sequence of actor_forward_wg (see pw_kernels_policy3.hpp, "Bits").
+// On return every thread has passed a barrier after the last LDS access of the pass.
+template <int S1C>
+__device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const Actor16Lds &S, const Actor16W &W,
+                                                const float *xrows, const int xstride, const int rows_here,
+                                                const int envs_here, const long row_base, const uint64_t step,
+                                                int32_t *act_g, int32_t *act_l)
+{
+    constexpr int S1 = 4 * S1C;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = wave >> 2, hq = wave & 3, n16 = lane & 15, kq = lane >> 4;
+    const int N = A.N, D = A.D;
+    const int nblk = 2 * ((N + 1) >> 1);  // dense1 blocks: (32-column tile = two timesteps of 16 sequences) x (hidden half)
+    const bool seq_ok = n16 < envs_here;
+
+    // ---- dense1 + ReLU: 32 x 32 blocks of relu(W1 X^T + b1), column rho = 16 * timestep + sequence
+    for (int blk = wave; blk < nblk; blk += 8) {
+        const int rt = blk >> 1, m = blk & 1;
+        int ts = 2 * rt + (col >> 4), n = col & 15;
+        if (ts >= N) ts = N - 1;
+        if (n >= envs_here) n = 0;  // slots past the environments of this workgroup read a valid row; nobody uses their results
+        const float *xr = xrows + (size_t)(n * N + ts) * xstride;
+        float xb[S1];
+#pragma unroll
+        for (int sidx = 0; sidx < S1; ++sidx) {
+            const int kk = 2 * sidx + half;
+            xb[sidx] = kk < D ? xr[kk] : 0.0f;
+        }
+        f32x16 acc1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc1[q] = 0.0f;
+#pragma unroll
+        for (int sidx = 0; sidx < S1; ++sidx)
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(S.f_w1[(m * S1 + sidx) * 64 + lane], xb[sidx], acc1, 0, 0, 0);
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = fmaxf(acc1[q] + S.s_b1[m * 32 + mfma_row(q, half)], 0.0f);
+        // register q of lane half `half` is hidden unit m * 32 + (q & 3) + 8 (q >> 2) + 4 half = position 32 m + 2 q + half of the
+        // projection's summation order: fragment j = 2 m + q / 8, element (q / 2) % 4, lane (2 (q & 1) + half) * 16 + sequence
+        if (2 * rt + (col >> 4) < N) {
+            float4 *dst = S.s_xf + ((2 * rt + (col >> 4)) * 4 + 2 * m) * 64 + half * 16 + (col & 15);
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+                for (int ql = 0; ql < 2; ++ql)
+                    dst[qh * 64 + ql * 32] = make_float4(v[8 * qh + ql], v[8 * qh + 2 + ql], v[8 * qh + 4 + ql], v[8 * qh + 6 + ql]);
+        }
+    }
+    wg_lds_barrier();  // the x1 fragments are in LDS
+
+    // ---- the BiLSTM, one timestep per barrier
+    auto inproj = [&](const int ts, f32x4 (&acc)[2]) {
+        const float4 *xf = S.s_xf + (ts * 4) * 64 + lane;
+        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            const float4 b = xf[jx * 64];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[0][4 * jx + 0], b.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[1][4 * jx + 0], b.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[0][4 * jx + 1], b.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[1][4 * jx + 1], b.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[0][4 * jx + 2], b.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[1][4 * jx + 2], b.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[0][4 * jx + 3], b.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[1][4 * jx + 3], b.w, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[T][i] += W.bias[T][i];
+    };
+    {
+        f32x4 acc[2], accn[2];
+        float c0 = 0.f, c1 = 0.f;
+        inproj(dir ? N - 1 : 0, acc);
+        for (int s2 = 0; s2 < N; ++s2) {
+            const int ts = dir ? N - 1 - s2 : s2;
+            if (s2 > 0) {
+                const float4 *hx = S.s_hx + ((((s2 - 1) & 1) * 2 + dir) * 2) * 64 + lane;
+                const float4 h0 = hx[0], h1 = hx[64];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[0][0], h0.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[1][0], h0.x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[0][1], h0.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[1][1], h0.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[0][2], h0.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[1][2], h0.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[0][3], h0.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[1][3], h0.w, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[0][4], h1.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[1][4], h1.x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[0][5], h1.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[1][5], h1.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[0][6], h1.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[1][6], h1.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[0][7], h1.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.ahh[1][7], h1.w, acc[1], 0, 0, 0);
+            }
+            // the two cells of this lane: accumulator registers = gates i, f, g, o
+            c0 = fast_sigmoid(acc[0][1]) * c0 + fast_sigmoid(acc[0][0]) * fast_tanh(acc[0][2]);
+            c1 = fast_sigmoid(acc[1][1]) * c1 + fast_sigmoid(acc[1][0]) * fast_tanh(acc[1][2]);
+            const float h0v = fast_sigmoid(acc[0][3]) * fast_tanh(c0);
+            const float h1v = fast_sigmoid(acc[1][3]) * fast_tanh(c1);
+            // h exchange: unit u = hq * 8 + 4 T + kq is k quarter kq of k step 2 hq + T: fragment j = hq / 2, elements
+            // (2 hq) % 4 + T of this very lane slot
+            reinterpret_cast<float2 *>(S.s_hx + (((s2 & 1) * 2 + dir) * 2 + (hq >> 1)) * 64 + lane)[hq & 1] = make_float2(h0v, h1v);
+            if (seq_ok) {  // head input: row n16 * N + ts, k = dir * 32 + unit -> fragment 2 dir + hq / 2, same element pair
+                const int rr = n16 * N + ts;
+                reinterpret_cast<float2 *>(S.s_hf + ((rr >> 4) * 4 + 2 * dir + (hq >> 1)) * 64 + kq * 16 + (rr & 15))[hq & 1] =
+                    make_float2(A.relu_out ? fmaxf(h0v, 0.0f) : h0v, A.relu_out ? fmaxf(h1v, 0.0f) : h1v);
+            }
+            if (s2 + 1 < N) inproj(dir ? N - 2 - s2 : s2 + 1, accn);  // before the barrier: work for the matrix pipe while the workgroup meets
+            wg_lds_barrier();  // h(ts) of every unit is in LDS (the last one: the head input is complete)
+            if (s2 + 1 < N) { acc[0] = accn[0]; acc[1] = accn[1]; }
+        }
+    }
+
+    // ---- optional: the hidden state H [rows][64] back in row order
+    if (A.H) {
+        for (int idx = tid; idx < rows_here * 64; idx += 512) {
+            const int rr = idx >> 6, kk = idx & 63;
+            const float4 q = S.s_hf[((rr >> 4) * 4 + (kk >> 4)) * 64 + (kk & 3) * 16 + (rr & 15)];
+            const int e = (kk >> 2) & 3;
+            A.H[(size_t)row_base * 64 + idx] = e == 0 ? q.x : e == 1 ? q.y : e == 2 ? q.z : q.w;
+        }
+    }
+    // ---- the head(s) on the matrix cores: logits^T [16 x 16 rows] = W2 [16 x 64] * relu(h)^T per 16-row tile, C-in = b2, k
+    // ascending (the chain of actor_forward_wg's head); the heads' logits are concatenated ([n_out0 | n_out1], run.py:39-41
+    // order): row group rg of a column holds logits 4 rg .. 4 rg + 3.  Then minus the Gumbel noise and one arg-max per head
+    // (first maximum wins): a local scan and two exchanges across the four row groups.
+    const int OUT = A.n_out0 + A.n_out1, nheads = A.n_out1 > 0 ? 2 : 1;
+    const bool sample = act_g != nullptr || act_l != nullptr;
+    const int ntile = (rows_here + 15) >> 4;
+    for (int tile = wave; tile < ntile; tile += 8) {
+        f32x4 lg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lg[i] = W.b2c[i];
+        const float4 *hf = S.s_hf + (tile * 4) * 64 + lane;
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            const float4 b = hf[jx * 64];
+            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aw2[4 * jx + 0], b.x, lg, 0, 0, 0);
+            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aw2[4 * jx + 1], b.y, lg, 0, 0, 0);
+            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aw2[4 * jx + 2], b.z, lg, 0, 0, 0);
+            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aw2[4 * jx + 3], b.w, lg, 0, 0, 0);
+        }
+        const int rr = tile * 16 + n16;
+        const bool row_ok = rr < rows_here;
+        const long grow = row_base + (row_ok ? rr : 0);
+        if (A.logits && row_ok) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * kq + i < OUT) A.logits[(size_t)grow * OUT + 4 * kq + i] = lg[i];
+        }
+        if (sample) {
+            float p[4] = {lg[0], lg[1], lg[2], lg[3]};
+            if (4 * kq < OUT) {  // wave-divergent only by row group
+                const uint32_t blk = (uint32_t)kq, tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
+                uint32_t u[4];
+                pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | tag, (uint32_t)step, (uint32_t)(step >> 32),
+                                 (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float uo = ((float)(u[i] >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
+                    p[i] = lg[i] - __logf(-__logf(uo));
+                }
+            }
+#pragma unroll 1
+            for (int hd = 0; hd < nheads; ++hd) {
+                const int lo = hd ? A.n_out0 : 0, cnt = hd ? A.n_out1 : A.n_out0;
+                float bv = -INFINITY;
+                int best = 0x7fffffff;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = 4 * kq + i - lo;
+                    if (o >= 0 && o < cnt && (best == 0x7fffffff || p[i] > bv)) { bv = p[i]; best = o; }
+                }
+#pragma unroll
+                for (int sh = 16; sh <= 32; sh <<= 1) {  // the lower logit index wins a tie: the first maximum, as a scan would find
+                    const float ov = __shfl_xor(bv, sh, kWave);
+                    const int ob = __shfl_xor(best, sh, kWave);
+                    if (ob != 0x7fffffff && (best == 0x7fffffff || ov > bv || (ov == bv && ob < best))) { bv = ov; best = ob; }
+                }
+                if (kq == 0 && row_ok) {
+                    if (act_g) act_g[rr * nheads + hd] = best;
+                    if (act_l) act_l[rr * nheads + hd] = best;
+                }
+            }
+        }
+    }
+    wg_lds_barrier();
+}
+
+// The whole actor in ONE launch (pw_actor_fused) on the 16x16x4 core: 16 environments per workgroup at any N <= 16 that fits LDS
+template <int S1C>
+__global__ void __launch_bounds__(512) pw_actor_fused16_kernel(const ActorFusedArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int N = A.N, E = A.E;
+    const Actor16Lds S = actor16_carve(reinterpret_cast<float *>(smem_raw), N, E * N, 4 * S1C);
+    const long env0 = (long)blockIdx.x * E;
+    const int envs_here = (int)((long)A.B - env0 < (long)E ? (long)A.B - env0 : (long)E);
+    const long row_base = env0 * N;
+    const int nheads = A.n_out1 > 0 ? 2 : 1;
+    const uint64_t step = (A.act && A.step_dev) ? (uint64_t)*A.step_dev : A.step;
+    Actor16W W;
+    actor16_load<S1C>(A, S, W);
+    wg_lds_barrier();
+    actor16_forward<S1C>(A, S, W, A.X + (size_t)row_base * A.D, A.D, envs_here * N, envs_here, row_base, step,
+                         A.act ? A.act + row_base * nheads : nullptr, nullptr);
+}
+
+}  // namespace

@@ -169,7 +169,14 @@ __device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 
 // Wih[n*32 + (ln & 31)][m*32 + 8*rq + 4*(ln >> 5) + e]; stage 1: [2 m][S1][64 lane], lane ln of step s =
 // W1[m*32 + (ln & 31)][2s + (ln >> 5)] (0 past in_dim), S1 = the k-step count rounded up to a multiple of 4 (the
 // kernel is instantiated per S1 / 4 so that stage 1 is straight-line code; a zero k-step adds +0 to the
-// accumulators, which never hold -0).  pw_actor_front_pack writes both once per weight update.
+// accumulators, which never hold -0).  Third section (pw_kernels_actor16.hpp): the same W_ih as A fragments of
+// v_mfma_f32_16x16x4_f32, [8 wave][2 tile][4 j][64 lane] float4: element e of lane ln of wave (dir, hq) = Wih[dir * 128 +
+// (ln & 3) * 32 + hq * 8 + 4 tile + ((ln & 15) >> 2)][x1_kpos(4 * (4 j + e) + ln / 16)] -- tile rows ordered (unit, gate), k in the
+// order the 32x32x2 chains sum.  pw_actor_front_pack writes all three once per weight update.
+// hidden index of position p (0..63) in the summation order of the input projection: the 32x32x2 chains walk (m, rq, e) and sum
+// the pair {m * 32 + 8 rq + e, + 4} per instruction
+__host__ __device__ __forceinline__ int x1_kpos(int p) { return ((p >> 5) << 5) + (((p >> 3) & 3) << 3) + ((p >> 1) & 3) + ((p & 1) << 2); }
+__host__ __device__ inline size_t actor_frag16_offset(int S1) { return (size_t)8 * 2 * 4 * 64 * 4 + (size_t)2 * S1 * 64; }
 __global__ void pw_actor_front_pack_kernel(const float *__restrict__ w1, const float *__restrict__ wih, const int D,
                                            float *__restrict__ frag)
 {
@@ -184,6 +191,17 @@ __global__ void pw_actor_front_pack_kernel(const float *__restrict__ w1, const f
         const int ln = f & 63, sidx = (f >> 6) % S1, m = (f >> 6) / S1;
         const int k = 2 * sidx + (ln >> 5);
         frag[8 * 2 * 4 * 64 * 4 + f] = k < D ? w1[(size_t)(m * 32 + (ln & 31)) * D + k] : 0.0f;
+    }
+    if (f < 8 * 2 * 4 * 64) {
+        const int ln = f & 63, jx = (f >> 6) & 3, T = (f >> 8) & 1, wv = f >> 9;
+        const int n16 = ln & 15, kq = ln >> 4;
+        const size_t R = (size_t)(wv >> 2) * 128 + (n16 & 3) * 32 + (wv & 3) * 8 + 4 * T + (n16 >> 2);
+        float4 v;
+        v.x = wih[R * 64 + x1_kpos(4 * (4 * jx + 0) + kq)];
+        v.y = wih[R * 64 + x1_kpos(4 * (4 * jx + 1) + kq)];
+        v.z = wih[R * 64 + x1_kpos(4 * (4 * jx + 2) + kq)];
+        v.w = wih[R * 64 + x1_kpos(4 * (4 * jx + 3) + kq)];
+        reinterpret_cast<float4 *>(frag + actor_frag16_offset(S1))[f] = v;
     }
 }
 

@@ -5,8 +5,6 @@
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 // ------------------------------------------------------------------------------------------
 // What the stamps of the second form say (profiles/r3_policy_phases.txt): the f32 MFMA and the vector ALU of a SIMD share
 // their multipliers, so "matrix waves" and "LSTM waves" take turns anyway, and while one role works the other's four waves
@@ -82,10 +80,6 @@ __device__ __forceinline__ Roll3Lds roll3_carve(unsigned char *raw, int E, int N
     S.s_lg = reinterpret_cast<float *>(S.s_xf);
     return S;
 }
-
-// hidden index of position p (0..63) in the summation order of the input projection: the 32x32x2 chains of the other forms
-// walk (m, rq, e) and sum the pair {m * 32 + 8 rq + e, + 4} per instruction
-__device__ __forceinline__ int x1_kpos(int p) { return ((p >> 5) << 5) + (((p >> 3) & 3) << 3) + ((p >> 1) & 3) + ((p & 1) << 2); }
 
 template <int S1C, int NT, bool SINK>
 __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRolloutArgs P)
@@ -196,14 +190,12 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
             const int wrow = (n16 & 3) * 32 + hq * 8 + 4 * T + (n16 >> 2);  // within the direction: gate * 32 + unit
-            const int R = dir * 128 + wrow;                                 // row of W_ih [256][64]
+            // W_ih rows dir * 128 + wrow, k in the projection's summation order: the third section of pw_actor_front_pack's image
+            const float4 *f16 = reinterpret_cast<const float4 *>(A.frag + actor_frag16_offset(S1)) + ((wave * 2 + T) * 4) * 64 + lane;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int kk = x1_kpos(4 * s + kq);
-                // W_ih[R][kk] out of the 32x32x2 fragment array (pw_actor_front_pack): [8 n][2 m][4 rq][64 lane] float4
-                const int kl = kk & 31;
-                const size_t idx = ((((size_t)(R >> 5) * 2 + (kk >> 5)) * 4 + (kl >> 3)) * 64 + (R & 31) + 32 * ((kl >> 2) & 1)) * 4 + (kl & 3);
-                aih[T][s] = A.frag[idx];
+            for (int jx = 0; jx < 4; ++jx) {
+                const float4 q = f16[jx * 64];
+                aih[T][4 * jx + 0] = q.x; aih[T][4 * jx + 1] = q.y; aih[T][4 * jx + 2] = q.z; aih[T][4 * jx + 3] = q.w;
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s) ahh[T][s] = whh[wrow * 32 + 4 * s + kq];
@@ -214,7 +206,6 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
     float aw2[16];  // head weights as A fragments: tile row = logit (5 of 16 rows used)
 #pragma unroll
     for (int sx = 0; sx < 16; ++sx) aw2[sx] = n16 < OUT ? A.w2[n16 * 64 + 4 * sx + kq] : 0.0f;
-    const int unit0 = hq * 8 + kq;  // this lane's cells: units unit0 and unit0 + 4 of sequence n16
     const bool seq_ok = n16 < envs_here;
     // the Gumbel noise of the next step is drawn by the waves without environment duty while the environment waves advance
     // the agents (by everybody, first, when every wave has environment duty: N > 24)

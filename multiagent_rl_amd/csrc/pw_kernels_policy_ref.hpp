@@ -9,8 +9,8 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // T x (two-head actor forward + one Gumbel-argmax per head + environment step + auto-reset) per workgroup of 16
 // environments (32 observation rows: N = 2), observations / sampled (movement, symbol) pairs / world state resident on the
-// CU between steps -- the simple_reference counterpart of pw_policy_rollout_kernel.  The actor pass is actor_forward_wg
-// (the arithmetic and Philox keying of pw_actor_fused with n_out0 = 5, n_out1 = 10); the environment step is
+// CU between steps -- the simple_reference counterpart of pw_policy_rollout_kernel.  The actor pass is actor16_forward
+// (pw_kernels_actor16.hpp: the arithmetic and Philox keying of pw_actor_fused with n_out0 = 5, n_out1 = 10); the environment step is
 // pw_reference_rollout_kernel's arithmetic on the workgroup's first wave (lane = (env, agent), the partner is lane ^ 1,
 // every exchange a shuffle), so the results equal the loop "act = pw_actor_fused(obs); pw_step(act)" bit for bit.
 // Outputs as pw_rollout's; act_out [T,B,N,2] int32 = (movement index, symbol index).
@@ -31,8 +31,10 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const ActorFusedArgs &A = P.A;
     const RefParams &V = P.V;
-    const ActorLds S = actor_carve(smem_raw, 4 * S1C);
+    const Actor16Lds S = actor16_carve(reinterpret_cast<float *>(smem_raw), N, A.E * N, 4 * S1C);
     const int D = A.D;
+    Actor16W W;  // the actor's weights: registers for the whole launch (pw_kernels_actor16.hpp)
+    actor16_load<S1C>(A, S, W);
     float *s_obs = reinterpret_cast<float *>(S.end);                       // [96][D] observation rows
     int32_t *s_act = reinterpret_cast<int32_t *>(s_obs + kFusedRows * D);  // [96][2] (movement, symbol)
 
@@ -70,8 +72,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
 
     for (int t = 0; t < P.T; ++t) {
         // ---- policy: observation rows (LDS) -> one sampled index per head and row (LDS)
-        actor_forward_wg<S1C>(A, S, s_obs, rows_here, envs_here, row_base, t == 0, t == 0, step0 + (uint64_t)t, nullptr, s_act);
-        wg_lds_barrier();
+        actor16_forward<S1C>(A, S, W, s_obs, D, rows_here, envs_here, row_base, step0 + (uint64_t)t, nullptr, s_act);  // a barrier at its end
         // ---- environment step (pw_reference_rollout_kernel's arithmetic, index actions)
         if (env_wave) {
             const size_t row = (size_t)t * BN + g;
@@ -126,9 +127,6 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
                 if (P.obs) ref_write_obs<DC, false>(V, s, co, a, P.obs + row * D);
                 ref_write_obs<DC, false>(V, s, co, a, s_obs + r * D);
             }
-        } else if (t + 1 < P.T) {
-            // the other waves fetch the next pass's forward-direction weights meanwhile (their LDS tiles are idle)
-            actor_fill_dir(A, S, 0, tid - kWave, 7 * kWave);
         }
         wg_lds_barrier();
     }

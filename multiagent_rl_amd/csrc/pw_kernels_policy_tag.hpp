@@ -19,9 +19,9 @@ struct PolicyRolloutTagArgs {
     unsigned long long *scratch;
 };
 
-__host__ __device__ inline size_t policy_tag_lds_bytes(int S1, int D, int E, int L)
+__host__ __device__ inline size_t policy_tag_lds_bytes(int S1, int D, int E, int L, int N)
 {
-    return actor_lds_bytes(S1) + (size_t)kFusedRows * D * sizeof(float) + kFusedRows * sizeof(int32_t) +
+    return actor16_lds_floats(N, E * N, S1) * sizeof(float) + (size_t)kFusedRows * D * sizeof(float) + kFusedRows * sizeof(int32_t) +
            4 * kWave * sizeof(float2) + (size_t)E * L * sizeof(float2) + 3 * 2 * kWave * sizeof(float) +
            16 * (sizeof(double) + sizeof(int));
 }
@@ -34,8 +34,10 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const ActorFusedArgs &A = P.A;
     const TagParams &V = P.V;
-    const ActorLds S = actor_carve(smem_raw, 4 * S1C);
     const int N = A.N, L = V.L, D = A.D, NA = V.A;
+    const Actor16Lds S = actor16_carve(reinterpret_cast<float *>(smem_raw), N, A.E * N, 4 * S1C);
+    Actor16W W;  // the actor's weights: registers for the whole launch (pw_kernels_actor16.hpp)
+    actor16_load<S1C>(A, S, W);
     float *s_obs = reinterpret_cast<float *>(S.end);                       // [96][D] observation rows
     int32_t *s_act = reinterpret_cast<int32_t *>(s_obs + kFusedRows * D);  // [96]
     float2 *s_posb = reinterpret_cast<float2 *>(s_act + kFusedRows);       // [2 env waves][64]
@@ -122,9 +124,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
     wg_lds_barrier();
 
     for (int t = 0; t < P.T; ++t) {
-        actor_forward_wg<S1C>(A, S, s_obs, rows_here, envs_here, row_base, t == 0, t == 0, step0 + (uint64_t)t, nullptr,
-                              s_act);
-        wg_lds_barrier();
+        actor16_forward<S1C>(A, S, W, s_obs, D, rows_here, envs_here, row_base, step0 + (uint64_t)t, nullptr, s_act);  // a barrier at its end
         if (env_wave) {
             const size_t tBN = (size_t)t * BN;
             const int ai = s_act[r];
@@ -231,9 +231,6 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
                 if (V.obs) tag_write_obs<0, -1, 0>(V.obs + (tBN + g) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
                 tag_write_obs<0, -1, 0>(s_obs + r * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
             }
-        } else if (t + 1 < P.T) {
-            const int nw = 8 - n_env_waves;
-            actor_fill_dir(A, S, 0, tid - n_env_waves * kWave, nw * kWave);
         }
         wg_lds_barrier();
     }

@@ -22,6 +22,7 @@
 #include "pw_kernels_reference.hpp"
 #include "pw_handle.hpp"
 #include "pw_kernels_policy.hpp"
+#include "pw_kernels_actor16.hpp"
 #include "pw_kernels_policy2.hpp"
 #include "pw_kernels_policy3.hpp"
 #include "pw_kernels_policy_tag.hpp"
@@ -73,9 +74,31 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
     a.E = 96 / N < 16 ? 96 / N : 16;
     a.seed = seed; a.step = step; a.step_dev = step_dev; a.H = H; a.logits = logits; a.act = act;
     const int S1C = (in_dim + 7) / 8, S1 = 4 * S1C;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // N <= 16: the BiLSTM on v_mfma_f32_16x16x4_f32 (pw_kernels_actor16.hpp), 16 environments per workgroup whatever N is; same
+    // bits as the kernel below, which keeps the long sequences (its 96-row workgroups hold N <= 96)
+    const size_t shm16 = actor16_lds_floats(N, 16 * N, S1) * sizeof(float);
+    if (N <= 16 && shm16 <= 160 * 1024) {
+        a.E = 16;
+        const unsigned grid16 = (unsigned)((B + 15) / 16);
+        static unsigned long long attr_set16[9] = {};  // per kernel: bit = device
+#define PW_FUSED16(C)                                                                                                    \
+    case C:                                                                                                              \
+        if (lds_optin_needed(&attr_set16[C])) {                                                                          \
+            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_actor_fused16_kernel<C>),                 \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+        }                                                                                                                \
+        hipLaunchKernelGGL(pw_actor_fused16_kernel<C>, dim3(grid16), dim3(512), shm16, st, a);                           \
+        break;
+        switch (S1C) {
+            PW_FUSED16(1) PW_FUSED16(2) PW_FUSED16(3) PW_FUSED16(4) PW_FUSED16(5) PW_FUSED16(6) PW_FUSED16(7) PW_FUSED16(8)
+        }
+#undef PW_FUSED16
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
     const size_t shm = actor_lds_bytes(S1);
     const unsigned grid = (unsigned)((B + a.E - 1) / a.E);
-    hipStream_t st = static_cast<hipStream_t>(stream);
     static unsigned long long attr_set[9] = {};  // per kernel: bit = device
 #define PW_FUSED(C)                                                                                                      \
     case C:                                                                                                              \
@@ -126,7 +149,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         R.done = io->done; R.terminal = io->terminal;
         const int rS1C = (kp.D + 7) / 8;
         if (rS1C != 3) return fail(PW_EINVAL, "simple_reference one-launch rollout: the observation is 21 numbers (3 landmarks)");
-        const size_t rshm = actor_lds_bytes(4 * rS1C) + (size_t)kFusedRows * kp.D * sizeof(float) + 2 * kFusedRows * sizeof(int32_t);
+        const size_t rshm = actor16_lds_floats(2, 32, 4 * rS1C) * sizeof(float) + (size_t)kFusedRows * kp.D * sizeof(float) + 2 * kFusedRows * sizeof(int32_t);
         static unsigned long long attr_set = 0; /* bit = device */
         if (lds_optin_needed(&attr_set))
             PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_ref_kernel<3>),
@@ -179,7 +202,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
             Q.finished_count = sink->finished_count; Q.scratch = static_cast<unsigned long long *>(sink->scratch);
         }
         const int tS1C = (kp.D + 7) / 8;
-        const size_t tshm = policy_tag_lds_bytes(4 * tS1C, kp.D, qa.E, kp.L);
+        const size_t tshm = policy_tag_lds_bytes(4 * tS1C, kp.D, qa.E, kp.L, kp.N);
         if (tshm > 160 * 1024 || tS1C < 2 || tS1C > 6)
             return fail(PW_EINVAL, "simple_tag one-launch rollout: observation length must be in [9, 48] and fit the LDS");
         const unsigned tgrid = (unsigned)((kp.B + qa.E - 1) / qa.E);
@@ -371,7 +394,7 @@ int pw_debug_math(int32_t fn, const float *x, float aux, float *y, int64_t n, vo
     return PW_OK;
 }
 
-size_t pw_actor_front_pack_floats(int32_t in_dim) { return (size_t)8 * 2 * 4 * 64 * 4 + (size_t)2 * (((in_dim + 7) / 8) * 4) * 64; }
+size_t pw_actor_front_pack_floats(int32_t in_dim) { return actor_frag16_offset(((in_dim + 7) / 8) * 4) + (size_t)8 * 2 * 4 * 64 * 4; }
 
 int pw_actor_front_pack(const float *w1, const float *w_ih, int32_t in_dim, float *frag, void *stream)
 {
