@@ -725,6 +725,22 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
         sync()
         tg = time.perf_counter() - tg
         line['three_launches_per_step_hipgraph'] = dict(value=B * 500 / tg, us_per_step=tg / 500 * 1e6)
+        # labelled extra, never the figure above: the OPT-IN, NOT exact actor mode (LSTM input projection on bfloat16 matrix
+        # instructions, three products per k step -- pw_set_actor_precision in include/pworld.h) on a fresh env + ring
+        benv = BatchedParticleEnv('simple_spread', B, num_agents=N, max_episode_len=25, auto_reset=True,
+                                  seed=12345678, env_id_base=rank * B)
+        benv.set_actor_precision('bf16x3')
+        rb = BatchedRollout(benv, actor, ReplayBuffer(1e6, N, benv.obs_dim))
+        rb.collect_one_launch(Tp, chunk=Tp)
+        sync()
+        tb = time.perf_counter()
+        rb.collect_one_launch(n_chunks * Tp, chunk=Tp)
+        sync()
+        tb = time.perf_counter() - tb
+        line['bf16x3_input_projection'] = dict(value=B * n_chunks * Tp / tb, us_per_step=tb / (n_chunks * Tp) * 1e6, exact=False,
+                                               note='opt-in (PW_ACTOR_BF16X3=1 / pw_set_actor_precision), within 2e-5 of the '
+                                                    'float32 logits, does not reproduce the exact form\'s sampled actions; '
+                                                    'never the default, never the headline')
         return line
 
     if stub_env is None:

@@ -53,7 +53,8 @@
 extern "C" {
 #endif
 
-#define PW_VERSION 103 /* 0.1.3: + pw_dispatch (kernel selection frozen in the handle; no environment reads at launch)
+#define PW_VERSION 104 /* 0.1.4: + pw_set_actor_precision / pw_actor_set_bf16x3 (opt-in bf16x3 input projection); pw_actor_front_pack's
+                          image grew a third section.  0.1.3: + pw_dispatch (kernel selection frozen in the handle; no environment reads at launch)
                           (0.1.2: + pw_rollout_kernel; 0.1.1: pw_replay_store grew act_heads / per_agent / head_width; wire-block entry points) */
 #define PW_MAX_AGENTS 64
 #define PW_MAX_LANDMARKS 64
@@ -196,6 +197,19 @@ typedef struct pw_dispatch {
 int pw_dispatch_default(pw_dispatch *d);                    /* every choice automatic */
 int pw_set_dispatch(pw_handle *h, const pw_dispatch *d);    /* between launches; the bound state is untouched */
 int pw_get_dispatch(const pw_handle *h, pw_dispatch *out);
+
+/* Arithmetic of the actor inside the one-launch policy rollouts of this handle (pw_policy_rollout).  PW_ACTOR_F32 (default): exact
+ * float32, bit-identical to every other form and to the pw_actor_fused + pw_step loop.  PW_ACTOR_BF16X3: OPT-IN and NOT exact -- the
+ * LSTM input projection runs on bfloat16 matrix instructions with both operands split in high and low halves, three products per k
+ * step, float32 accumulation; dense1, the recurrence and the head stay float32.  Within the 2e-5 bound of the PyTorch float32
+ * comparison on the reference's weights (tests/test_gpu_engine.py), but sampled actions can differ from the exact form's.
+ * PW_ACTOR_BF16X3=1 in the environment of the creating process selects it at pw_create; never a default, never a headline figure.
+ * pw_actor_set_bf16x3: the same switch for the handle-less pw_actor_fused (process-wide, off until set; N <= 16 only). */
+#define PW_ACTOR_F32 0
+#define PW_ACTOR_BF16X3 1
+int pw_set_actor_precision(pw_handle *h, int32_t mode);
+int pw_get_actor_precision(const pw_handle *h);
+int pw_actor_set_bf16x3(int32_t on);   /* returns the previous value */
 
 /* Name of the device kernel the last pw_step / pw_rollout on this handle launched (a static string; "" before the
  * first launch).  The dispatcher picks a kernel per (scenario, N, L, B, outputs requested): measurement tools name the

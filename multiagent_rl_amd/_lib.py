@@ -82,6 +82,9 @@ SIGNATURES = {
     'pw_dispatch_default': (C.c_int, [C.POINTER(PwDispatch)]),
     'pw_set_dispatch': (C.c_int, [C.c_void_p, C.POINTER(PwDispatch)]),
     'pw_get_dispatch': (C.c_int, [C.c_void_p, C.POINTER(PwDispatch)]),
+    'pw_set_actor_precision': (C.c_int, [C.c_void_p, C.c_int32]),
+    'pw_get_actor_precision': (C.c_int, [C.c_void_p]),
+    'pw_actor_set_bf16x3': (C.c_int, [C.c_int32]),
     'pw_get_state_layout': (C.c_int, [C.c_void_p, C.POINTER(PwStateLayout)]),
     'pw_state_bytes': (C.c_size_t, [C.c_void_p]),
     'pw_bind_state': (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -14,6 +14,7 @@ struct pw_handle {
     int32_t *goal;
     const char *last_kernel;  // name of the kernel the last pw_step / pw_rollout launched (pw_rollout_kernel)
     pw_dispatch disp;         // kernel selection: fixed by pw_create / pw_set_dispatch, never read from the environment at launch
+    int actor_bf16x3;         // pw_set_actor_precision: 1 = the opt-in, NOT exact bf16x3 input projection of the one-launch rollouts
 };
 
 namespace {

@@ -8,6 +8,127 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// Opt-in, NOT exact (ActorFusedArgs.bf16x3; pw_set_actor_precision / PW_ACTOR_BF16X3=1; never the default, never a headline):
+// the input projection W_ih * x1 -- two thirds of the pass's matrix time -- on v_mfma_f32_16x16x16_bf16 with both operands split
+// into bfloat16 high and low parts and three products per k step (lo*hi + hi*lo + hi*hi, f32 accumulate; the lo*lo term and the
+// parts' rounding are ~2^-16 relative).  dense1, the recurrence and the head stay exact f32.  tests/test_gpu_engine.py holds the
+// mode to the 2e-5 bound of the PyTorch comparison on the reference's own weights; it does NOT reproduce the exact form's bits.
+// Fragment layout of the 16x16x16 form: a lane supplies four consecutive k (16 s + 4 kq .. + 3) of its row / column per k step.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bf16_rn(float x)
+{
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;  // round to nearest even (finite inputs)
+}
+__device__ __forceinline__ void bf16_split4(const float a, const float b, const float c, const float d, u32x2 &hi, u32x2 &lo)
+{
+    const uint32_t ha = bf16_rn(a), hb = bf16_rn(b), hc = bf16_rn(c), hd = bf16_rn(d);
+    const uint32_t la = bf16_rn(a - __uint_as_float(ha << 16)), lb = bf16_rn(b - __uint_as_float(hb << 16));
+    const uint32_t lc = bf16_rn(c - __uint_as_float(hc << 16)), ld = bf16_rn(d - __uint_as_float(hd << 16));
+    hi = u32x2{ha | (hb << 16), hc | (hd << 16)};
+    lo = u32x2{la | (lb << 16), lc | (ld << 16)};
+}
+
+// A fragments of this wave's two W_ih tiles: exact form out of the third section of pw_actor_front_pack's image (k in the
+// projection's summation order); bf16x3 form: natural k, four consecutive k per k step = one float4 of the first section
+template <int S1, bool BF3>
+__device__ __forceinline__ void actor16_load_ih(const float *frag, const int wave, const int lane,
+                                                float (&aih)[2][16], u32x2 (&ah)[2][4], u32x2 (&al)[2][4])
+{
+    const int dir = wave >> 2, hq = wave & 3, n16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        if (!BF3) {
+            const float4 *f16 = reinterpret_cast<const float4 *>(frag + actor_frag16_offset(S1)) + ((wave * 2 + T) * 4) * 64 + lane;
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) {
+                const float4 q = f16[jx * 64];
+                aih[T][4 * jx + 0] = q.x; aih[T][4 * jx + 1] = q.y; aih[T][4 * jx + 2] = q.z; aih[T][4 * jx + 3] = q.w;
+            }
+        } else {
+            const int R = dir * 128 + (n16 & 3) * 32 + hq * 8 + 4 * T + (n16 >> 2);  // row of W_ih [256][64]
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+                const int k0 = 16 * sx + 4 * kq, kl = k0 & 31;
+                // W_ih[R][k0 .. k0 + 3] in the 32x32x2 fragment array: [8 n][2 m][4 rq][64 lane] float4
+                const float4 q = reinterpret_cast<const float4 *>(frag)[(((R >> 5) * 2 + (k0 >> 5)) * 4 + (kl >> 3)) * 64 + (R & 31) + 32 * ((kl >> 2) & 1)];
+                bf16_split4(q.x, q.y, q.z, q.w, ah[T][sx], al[T][sx]);
+            }
+        }
+    }
+}
+
+// dense1 block (32-column tile rt, hidden half m) -> LDS in the B-fragment order of the timestep loop.  Register q of lane half
+// `half` is hidden unit h = m * 32 + (q & 3) + 8 (q >> 2) + 4 half.  Exact form: position 32 m + 2 q + half of the projection's
+// summation order -> fragment j = 2 m + q / 8, element (q / 2) % 4, lane (2 (q & 1) + half) * 16 + sequence.  bf16x3 form: natural k,
+// registers 4 a .. 4 a + 3 are k step 2 m + a / 2, k quarter 2 (a & 1) + half: one 16-byte {hi, lo} group per a.
+template <bool BF3>
+__device__ __forceinline__ void actor16_store_x1(float4 *s_xf, const int ts_w, const int m, const int half, const int n,
+                                                 const float (&v)[16])
+{
+    if (!BF3) {
+        float4 *dst = s_xf + (ts_w * 4 + 2 * m) * 64 + half * 16 + n;
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+            for (int ql = 0; ql < 2; ++ql)
+                dst[qh * 64 + ql * 32] = make_float4(v[8 * qh + ql], v[8 * qh + 2 + ql], v[8 * qh + 4 + ql], v[8 * qh + 6 + ql]);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            u32x2 hi, lo;
+            bf16_split4(v[4 * a], v[4 * a + 1], v[4 * a + 2], v[4 * a + 3], hi, lo);
+            reinterpret_cast<uint4 *>(s_xf)[(ts_w * 4 + 2 * m + (a >> 1)) * 64 + (2 * (a & 1) + half) * 16 + n] = make_uint4(hi.x, hi.y, lo.x, lo.y);
+        }
+    }
+}
+
+// input projection of timestep ts for this wave's two tiles (+ bias)
+template <bool BF3>
+__device__ __forceinline__ void actor16_inproj(const float4 *s_xf, const int ts, const int lane,
+                                               const float (&aih)[2][16], const u32x2 (&ah)[2][4], const u32x2 (&al)[2][4],
+                                               const float (&bias)[2][4], f32x4 (&acc)[2])
+{
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!BF3) {
+        const float4 *xf = s_xf + (ts * 4) * 64 + lane;
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            const float4 b = xf[jx * 64];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 0], b.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 0], b.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 1], b.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 1], b.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 2], b.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 2], b.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 3], b.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 3], b.w, acc[1], 0, 0, 0);
+        }
+    } else {
+        const uint4 *xb = reinterpret_cast<const uint4 *>(s_xf) + (ts * 4) * 64 + lane;
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            const uint4 q = xb[sx * 64];
+            const bf16x4 bh = __builtin_bit_cast(bf16x4, u32x2{q.x, q.y}), bl = __builtin_bit_cast(bf16x4, u32x2{q.z, q.w});
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                const bf16x4 wh = __builtin_bit_cast(bf16x4, ah[T][sx]), wl = __builtin_bit_cast(bf16x4, al[T][sx]);
+                acc[T] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl, bh, acc[T], 0, 0, 0);
+                acc[T] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, bl, acc[T], 0, 0, 0);
+                acc[T] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, bh, acc[T], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[T][i] += bias[T][i];
+}
 
 // LDS of the pass (floats from a 16-byte aligned base): dense1 output and head input in B-fragment order, the h exchange,
 // the dense1 constants
@@ -43,10 +164,11 @@ __device__ __forceinline__ Actor16Lds actor16_carve(float *base, int N, int rows
 struct Actor16W {
     float aih[2][16], ahh[2][8], bias[2][4];
     float aw2[16], b2c[4];
+    u32x2 ah[2][4], al[2][4];  // bf16x3 form of aih (one of the two is live)
 };
 
 // weights -> registers, dense1 constants -> LDS; a workgroup barrier must follow before the first pass
-template <int S1C>
+template <int S1C, bool BF3 = false>
 __device__ __forceinline__ void actor16_load(const ActorFusedArgs &A, const Actor16Lds &S, Actor16W &W)
 {
     constexpr int S1 = 4 * S1C;
@@ -60,16 +182,10 @@ __device__ __forceinline__ void actor16_load(const ActorFusedArgs &A, const Acto
         if (tid < 64) S.s_b1[tid] = A.b1[tid];
     }
     const float *whh = dir ? A.whh_r : A.whh_f;
+    actor16_load_ih<S1, BF3>(A.frag, wave, lane, W.aih, W.ah, W.al);
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
         const int wrow = (n16 & 3) * 32 + hq * 8 + 4 * T + (n16 >> 2);  // within the direction: gate * 32 + unit
-        // W_ih rows dir * 128 + wrow, k in the projection's summation order: the third section of pw_actor_front_pack's image
-        const float4 *f16 = reinterpret_cast<const float4 *>(A.frag + actor_frag16_offset(S1)) + ((wave * 2 + T) * 4) * 64 + lane;
-#pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
-            const float4 q = f16[jx * 64];
-            W.aih[T][4 * jx + 0] = q.x; W.aih[T][4 * jx + 1] = q.y; W.aih[T][4 * jx + 2] = q.z; W.aih[T][4 * jx + 3] = q.w;
-        }
 #pragma unroll
         for (int sx = 0; sx < 8; ++sx) W.ahh[T][sx] = whh[wrow * 32 + 4 * sx + kq];
 #pragma unroll
@@ -88,8 +204,8 @@ __device__ __forceinline__ void actor16_load(const ActorFusedArgs &A, const Acto
 //                   row group rg need for their four logits
 //   act_g / act_l   sinks of the sampled indices [rows_here * nheads], global / LDS (either may be NULL); A.H, A.logits too
 // Arithmetic: element for element the operation sequence of actor_forward_wg (see pw_kernels_policy3.hpp, "Bits").
-// On return every thread has passed a barrier after the last LDS access of the pass.
-template <int S1C>
+// On return every thread has passed a barrier after the last LDS access of the pass.  BF3: the opt-in bf16x3 input projection.
+template <int S1C, bool BF3 = false>
 __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const Actor16Lds &S, const Actor16W &W,
                                                 const float *xrows, const int xstride, const int rows_here,
                                                 const int envs_here, const long row_base, const uint64_t step,
@@ -125,41 +241,12 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
         float v[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = fmaxf(acc1[q] + S.s_b1[m * 32 + mfma_row(q, half)], 0.0f);
-        // register q of lane half `half` is hidden unit m * 32 + (q & 3) + 8 (q >> 2) + 4 half = position 32 m + 2 q + half of the
-        // projection's summation order: fragment j = 2 m + q / 8, element (q / 2) % 4, lane (2 (q & 1) + half) * 16 + sequence
-        if (2 * rt + (col >> 4) < N) {
-            float4 *dst = S.s_xf + ((2 * rt + (col >> 4)) * 4 + 2 * m) * 64 + half * 16 + (col & 15);
-#pragma unroll
-            for (int qh = 0; qh < 2; ++qh)
-#pragma unroll
-                for (int ql = 0; ql < 2; ++ql)
-                    dst[qh * 64 + ql * 32] = make_float4(v[8 * qh + ql], v[8 * qh + 2 + ql], v[8 * qh + 4 + ql], v[8 * qh + 6 + ql]);
-        }
+        if (2 * rt + (col >> 4) < N) actor16_store_x1<BF3>(S.s_xf, 2 * rt + (col >> 4), m, half, col & 15, v);
     }
     wg_lds_barrier();  // the x1 fragments are in LDS
 
     // ---- the BiLSTM, one timestep per barrier
-    auto inproj = [&](const int ts, f32x4 (&acc)[2]) {
-        const float4 *xf = S.s_xf + (ts * 4) * 64 + lane;
-        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
-            const float4 b = xf[jx * 64];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[0][4 * jx + 0], b.x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[1][4 * jx + 0], b.x, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[0][4 * jx + 1], b.y, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[1][4 * jx + 1], b.y, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[0][4 * jx + 2], b.z, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[1][4 * jx + 2], b.z, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[0][4 * jx + 3], b.w, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aih[1][4 * jx + 3], b.w, acc[1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int T = 0; T < 2; ++T)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[T][i] += W.bias[T][i];
-    };
+    auto inproj = [&](const int ts, f32x4 (&acc)[2]) { actor16_inproj<BF3>(S.s_xf, ts, lane, W.aih, W.ah, W.al, W.bias, acc); };
     {
         f32x4 acc[2], accn[2];
         float c0 = 0.f, c1 = 0.f;
@@ -282,7 +369,7 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
 }
 
 // The whole actor in ONE launch (pw_actor_fused) on the 16x16x4 core: 16 environments per workgroup at any N <= 16 that fits LDS
-template <int S1C>
+template <int S1C, bool BF3 = false>
 __global__ void __launch_bounds__(512) pw_actor_fused16_kernel(const ActorFusedArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -294,9 +381,9 @@ __global__ void __launch_bounds__(512) pw_actor_fused16_kernel(const ActorFusedA
     const int nheads = A.n_out1 > 0 ? 2 : 1;
     const uint64_t step = (A.act && A.step_dev) ? (uint64_t)*A.step_dev : A.step;
     Actor16W W;
-    actor16_load<S1C>(A, S, W);
+    actor16_load<S1C, BF3>(A, S, W);
     wg_lds_barrier();
-    actor16_forward<S1C>(A, S, W, A.X + (size_t)row_base * A.D, A.D, envs_here * N, envs_here, row_base, step,
+    actor16_forward<S1C, BF3>(A, S, W, A.X + (size_t)row_base * A.D, A.D, envs_here * N, envs_here, row_base, step,
                          A.act ? A.act + row_base * nheads : nullptr, nullptr);
 }
 

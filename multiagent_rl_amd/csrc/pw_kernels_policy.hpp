@@ -368,6 +368,7 @@ struct ActorFusedArgs {
     const float *X, *frag, *b1, *bih, *whh_f, *whh_r, *w2, *b2;
     int B, N, D, E, relu_out;
     int n_out0, n_out1;  // logits of head 0 / head 1 (0 = single head); n_out0 + n_out1 <= 16
+    int bf16x3;          // opt-in, not exact: input projection on bf16 MFMAs, three products per k step (16x16x4-core kernels only)
     uint64_t seed, step;
     const int64_t *step_dev;
     float *H, *logits;

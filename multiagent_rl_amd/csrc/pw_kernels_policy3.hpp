@@ -81,7 +81,7 @@ __device__ __forceinline__ Roll3Lds roll3_carve(unsigned char *raw, int E, int N
     return S;
 }
 
-template <int S1C, int NT, bool SINK>
+template <int S1C, int NT, bool SINK, bool BF3 = false>  // BF3: the opt-in, not exact bf16x3 input projection (pw_kernels_actor16.hpp)
 __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRolloutArgs P)
 {
     constexpr int LT = NT;
@@ -185,18 +185,13 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
     const int dir = wave >> 2, hq = wave & 3;
     const int n16 = lane & 15, kq = lane >> 4;
     float aih[2][16], ahh[2][8], bias[2][4];
+    u32x2 ah[2][4], al[2][4];  // bf16x3 form of aih (opt-in, not exact: pw_kernels_actor16.hpp)
+    actor16_load_ih<S1, BF3>(A.frag, wave, lane, aih, ah, al);
     {
         const float *whh = dir ? A.whh_r : A.whh_f;
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
             const int wrow = (n16 & 3) * 32 + hq * 8 + 4 * T + (n16 >> 2);  // within the direction: gate * 32 + unit
-            // W_ih rows dir * 128 + wrow, k in the projection's summation order: the third section of pw_actor_front_pack's image
-            const float4 *f16 = reinterpret_cast<const float4 *>(A.frag + actor_frag16_offset(S1)) + ((wave * 2 + T) * 4) * 64 + lane;
-#pragma unroll
-            for (int jx = 0; jx < 4; ++jx) {
-                const float4 q = f16[jx * 64];
-                aih[T][4 * jx + 0] = q.x; aih[T][4 * jx + 1] = q.y; aih[T][4 * jx + 2] = q.z; aih[T][4 * jx + 3] = q.w;
-            }
 #pragma unroll
             for (int s = 0; s < 8; ++s) ahh[T][s] = whh[wrow * 32 + 4 * s + kq];
 #pragma unroll
@@ -252,27 +247,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
     };
 
     // input projection of timestep ts for this wave's two tiles (+ bias)
-    auto inproj = [&](const int ts, f32x4 (&acc)[2]) {
-        const float4 *xf = S.s_xf + (ts * 4) * 64 + lane;
-        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
-            const float4 b = xf[jx * 64];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 0], b.x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 0], b.x, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 1], b.y, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 1], b.y, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 2], b.z, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 2], b.z, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 3], b.w, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 3], b.w, acc[1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int T = 0; T < 2; ++T)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[T][i] += bias[T][i];
-    };
+    auto inproj = [&](const int ts, f32x4 (&acc)[2]) { actor16_inproj<BF3>(S.s_xf, ts, lane, aih, ah, al, bias, acc); };
 
     // The rest of environment step t once positions and velocities are advanced, in two pieces so that each fits a window in
     // which the environment waves have nothing else to do:
@@ -383,17 +358,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
             float v[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) v[q] = fmaxf(acc1[q] + S.s_b1[m * 32 + mfma_row(q, half)], 0.0f);
-            // register q of lane half `half` is hidden unit m * 32 + (q & 3) + 8 (q >> 2) + 4 half = position 32 m + 2 q + half of
-            // the projection's summation order: k step s = 8 m + q / 2, k quarter 2 (q & 1) + half -> fragment j = s / 4 =
-            // 2 m + q / 8, element e = (q / 2) % 4, lane (2 (q & 1) + half) * 16 + sequence
-            if (2 * rt + (col >> 4) < N) {
-                float4 *dst = S.s_xf + ((2 * rt + (col >> 4)) * 4 + 2 * m) * 64 + half * 16 + (col & 15);
-#pragma unroll
-                for (int qh = 0; qh < 2; ++qh)
-#pragma unroll
-                    for (int ql = 0; ql < 2; ++ql)
-                        dst[qh * 64 + ql * 32] = make_float4(v[8 * qh + ql], v[8 * qh + 2 + ql], v[8 * qh + 4 + ql], v[8 * qh + 6 + ql]);
-            }
+            if (2 * rt + (col >> 4) < N) actor16_store_x1<BF3>(S.s_xf, 2 * rt + (col >> 4), m, half, col & 15, v);
         }
         PW_R2_STAMP(0);
         wg_lds_barrier();  // the x1 fragments are in LDS

@@ -200,9 +200,11 @@ void dispatch_defaults(pw_dispatch *d)
 }
 
 // The PWORLD_* variables of the creating process, read ONCE per handle (pw_create): A/B runs of unmodified host programs.
-void dispatch_from_environment(pw_dispatch *d)
+void dispatch_from_environment(pw_dispatch *d, int *actor_bf16x3)
 {
     dispatch_defaults(d);
+    *actor_bf16x3 = 0;  // not a selection (it changes results): kept beside the dispatch, set by pw_set_actor_precision
+    if (const char *e = std::getenv("PW_ACTOR_BF16X3")) *actor_bf16x3 = std::atoi(e) != 0;
     if (std::getenv("PWORLD_FORCE_GENERIC")) d->force_generic = 1;
     if (std::getenv("PWORLD_NO_STREAM")) d->no_stream = 1;
     if (std::getenv("PWORLD_FORCE_DUO")) d->duo = 1;
@@ -642,7 +644,7 @@ int pw_create(const pw_config *cfg, pw_handle **out)
                                  : 1.0f;
         kp.agent_max_speed[i] = cfg->agent_max_speed[i];
     }
-    dispatch_from_environment(&h->disp);
+    dispatch_from_environment(&h->disp, &h->actor_bf16x3);
     apply_dispatch(h);
     const size_t BN = (size_t)kp.B * kp.N, BL = (size_t)kp.B * kp.L;
     pw_state_layout &lo = h->layout;
@@ -698,6 +700,16 @@ int pw_set_dispatch(pw_handle *h, const pw_dispatch *d)
     apply_dispatch(h);
     return PW_OK;
 }
+
+int pw_set_actor_precision(pw_handle *h, int32_t mode)
+{
+    if (!h) return fail(PW_EINVAL, "null handle");
+    if (mode != PW_ACTOR_F32 && mode != PW_ACTOR_BF16X3) return fail(PW_EINVAL, "mode: PW_ACTOR_F32 or PW_ACTOR_BF16X3");
+    h->actor_bf16x3 = mode == PW_ACTOR_BF16X3;
+    return PW_OK;
+}
+
+int pw_get_actor_precision(const pw_handle *h) { return h && h->actor_bf16x3 ? PW_ACTOR_BF16X3 : PW_ACTOR_F32; }
 
 int pw_get_dispatch(const pw_handle *h, pw_dispatch *out)
 {

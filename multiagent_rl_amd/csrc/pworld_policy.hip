@@ -56,6 +56,22 @@ int pw_actor_head(const float *H, const float *w2, const float *b2, int64_t rows
     return PW_OK;
 }
 
+namespace {
+int &actor_bf16x3_flag()
+{
+    static int flag = 0;  // process-wide, off unless pw_actor_set_bf16x3 turns it on (no environment reads outside pw_create)
+    return flag;
+}
+}  // namespace
+
+int pw_actor_set_bf16x3(int32_t on)
+{
+    int &f = actor_bf16x3_flag();
+    const int prev = f;
+    f = on != 0;
+    return prev;
+}
+
 int pw_actor_fused(const float *X, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
                    const float *w_hh_bw, const float *w2, const float *b2, int32_t n_out0, int32_t n_out1, int64_t B,
                    int32_t N, int32_t in_dim, int32_t relu_out, uint64_t seed, uint64_t step, const int64_t *step_dev,
@@ -73,6 +89,7 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
     a.B = (int)B; a.N = N; a.D = in_dim; a.relu_out = relu_out; a.n_out0 = n_out0; a.n_out1 = n_out1;
     a.E = 96 / N < 16 ? 96 / N : 16;
     a.seed = seed; a.step = step; a.step_dev = step_dev; a.H = H; a.logits = logits; a.act = act;
+    a.bf16x3 = actor_bf16x3_flag();  // honoured by the 16x16x4-core kernel (N <= 16) only
     const int S1C = (in_dim + 7) / 8, S1 = 4 * S1C;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // N <= 16: the BiLSTM on v_mfma_f32_16x16x4_f32 (pw_kernels_actor16.hpp), 16 environments per workgroup whatever N is; same
@@ -81,19 +98,21 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
     if (N <= 16 && shm16 <= 160 * 1024) {
         a.E = 16;
         const unsigned grid16 = (unsigned)((B + 15) / 16);
-        static unsigned long long attr_set16[9] = {};  // per kernel: bit = device
-#define PW_FUSED16(C)                                                                                                    \
-    case C:                                                                                                              \
-        if (lds_optin_needed(&attr_set16[C])) {                                                                          \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_actor_fused16_kernel<C>),                 \
+#define PW_FUSED16B(C, BF)                                                                                               \
+    do {                                                                                                                 \
+        static unsigned long long attr_set16 = 0; /* bit = device */                                                     \
+        if (lds_optin_needed(&attr_set16)) {                                                                             \
+            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_actor_fused16_kernel<C, BF>),             \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
         }                                                                                                                \
-        hipLaunchKernelGGL(pw_actor_fused16_kernel<C>, dim3(grid16), dim3(512), shm16, st, a);                           \
-        break;
+        hipLaunchKernelGGL((pw_actor_fused16_kernel<C, BF>), dim3(grid16), dim3(512), shm16, st, a);                     \
+    } while (0)
+#define PW_FUSED16(C) case C: if (a.bf16x3) PW_FUSED16B(C, true); else PW_FUSED16B(C, false); break;
         switch (S1C) {
             PW_FUSED16(1) PW_FUSED16(2) PW_FUSED16(3) PW_FUSED16(4) PW_FUSED16(5) PW_FUSED16(6) PW_FUSED16(7) PW_FUSED16(8)
         }
 #undef PW_FUSED16
+#undef PW_FUSED16B
         PW_HIP_CHECK(hipGetLastError());
         return PW_OK;
     }
@@ -142,7 +161,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         ra.frag = frag; ra.b1 = b1; ra.bih = b_ih; ra.whh_f = w_hh_fw; ra.whh_r = w_hh_bw; ra.w2 = w2; ra.b2 = b2;
         ra.B = kp.B; ra.N = 2; ra.D = kp.D; ra.relu_out = relu_out; ra.n_out0 = 5; ra.n_out1 = PW_DIM_C;
         ra.E = 16;
-        ra.seed = seed; ra.step = step; ra.step_dev = step_dev;
+        ra.seed = seed; ra.step = step; ra.step_dev = step_dev; ra.bf16x3 = h->actor_bf16x3;
         R.V = ref_params(h);
         R.T = num_steps; R.act_out = act_out;
         R.obs = io->obs; R.final_obs = io->final_obs; R.rew = io->rew; R.rew_shared = io->rew_shared;
@@ -188,7 +207,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         qa.frag = frag; qa.b1 = b1; qa.bih = b_ih; qa.whh_f = w_hh_fw; qa.whh_r = w_hh_bw; qa.w2 = w2; qa.b2 = b2;
         qa.B = kp.B; qa.N = kp.N; qa.D = kp.D; qa.relu_out = relu_out; qa.n_out0 = 5; qa.n_out1 = 0;
         qa.E = 96 / kp.N < 16 ? 96 / kp.N : 16;
-        qa.seed = seed; qa.step = step; qa.step_dev = step_dev;
+        qa.seed = seed; qa.step = step; qa.step_dev = step_dev; qa.bf16x3 = h->actor_bf16x3;
         Q.V = h->tp;
         TagParams &tv = Q.V;
         tv.pos_x = kp.pos_x; tv.pos_y = kp.pos_y; tv.vel_x = kp.vel_x; tv.vel_y = kp.vel_y;
@@ -229,7 +248,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     a.frag = frag; a.b1 = b1; a.bih = b_ih; a.whh_f = w_hh_fw; a.whh_r = w_hh_bw; a.w2 = w2; a.b2 = b2;
     a.B = kp.B; a.N = kp.N; a.D = kp.D; a.relu_out = relu_out; a.n_out0 = 5; a.n_out1 = 0;
     a.E = 96 / kp.N < 16 ? 96 / kp.N : 16;
-    a.seed = seed; a.step = step; a.step_dev = step_dev;
+    a.seed = seed; a.step = step; a.step_dev = step_dev; a.bf16x3 = h->actor_bf16x3;
     StreamParams &A = P.V;
     A.B = kp.B; A.N = kp.N; A.L = kp.L; A.epw = kp.epw;
     A.max_episode_len = kp.max_episode_len; A.auto_reset = kp.auto_reset;
@@ -279,20 +298,27 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         a.E = E2;
         const size_t shm2 = use_v3 ? roll3_lds_bytes(E2, kp.N, kp.L, kp.D, S1) : roll2_lds_bytes(E2, kp.N, kp.L, kp.D, S1);
         const unsigned grid2 = (unsigned)((kp.B + E2 - 1) / E2);
+#define PW_R24(C, NT, SK, BF)                                                                                            \
+    do {                                                                                                                 \
+        static unsigned long long attr_set3 = 0; /* bit = device */                                                      \
+        if (lds_optin_needed(&attr_set3)) {                                                                               \
+            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout3_kernel<C, NT, SK, BF>),   \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+        }                                                                                                                \
+        hipLaunchKernelGGL((pw_policy_rollout3_kernel<C, NT, SK, BF>), dim3(grid2), dim3(512), shm2, st, P);             \
+    } while (0)
 #define PW_R23(C, NT, SK)                                                                                                \
     do {                                                                                                                 \
-        static unsigned long long attr_set = 0; /* bit = device */                                            \
+        if (use_v3) {                                                                                                    \
+            if (a.bf16x3) PW_R24(C, NT, SK, true); else PW_R24(C, NT, SK, false);                                        \
+            break;                                                                                                       \
+        }                                                                                                                \
+        static unsigned long long attr_set = 0; /* bit = device */                                                       \
         if (lds_optin_needed(&attr_set)) {                                                                                \
             PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout2_kernel<C, NT, SK>),       \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
         }                                                                                                                \
-        static unsigned long long attr_set3 = 0;                                                                          \
-        if (lds_optin_needed(&attr_set3)) {                                                                               \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout3_kernel<C, NT, SK>),       \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
-        if (use_v3) hipLaunchKernelGGL((pw_policy_rollout3_kernel<C, NT, SK>), dim3(grid2), dim3(512), shm2, st, P);     \
-        else hipLaunchKernelGGL((pw_policy_rollout2_kernel<C, NT, SK>), dim3(grid2), dim3(512), shm2, st, P);            \
+        hipLaunchKernelGGL((pw_policy_rollout2_kernel<C, NT, SK>), dim3(grid2), dim3(512), shm2, st, P);                 \
     } while (0)
 #define PW_R22(C, NT) do { if (sink) PW_R23(C, NT, true); else PW_R23(C, NT, false); } while (0)
 #define PW_R2(C) case C: PW_R22(C, 0); break;
@@ -300,6 +326,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         else switch (S1C) {
             PW_R2(1) PW_R2(2) PW_R2(3) PW_R2(4) PW_R2(5) PW_R2(6) PW_R2(7) PW_R2(8)
         }
+#undef PW_R24
 #undef PW_R23
 #undef PW_R22
 #undef PW_R2

@@ -183,6 +183,15 @@ class BatchedParticleEnv(object):
             setattr(d, k, int(v))
         check(self.lib.pw_set_dispatch(self._h, C.byref(d)))
 
+    def set_actor_precision(self, mode):
+        """Arithmetic of the actor inside ``FusedActor.rollout`` on this env: ``'f32'`` (default, exact, bit-identical to the
+        step loop) or ``'bf16x3'`` -- opt-in and NOT exact: the LSTM input projection on bfloat16 matrix instructions, three
+        products per k step (pw_set_actor_precision in include/pworld.h)."""
+        check(self.lib.pw_set_actor_precision(self._h, {'f32': 0, 'bf16x3': 1}[mode]))
+
+    def get_actor_precision(self):
+        return ('f32', 'bf16x3')[self.lib.pw_get_actor_precision(self._h)]
+
     # -- helpers
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

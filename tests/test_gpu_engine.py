@@ -267,6 +267,72 @@ def test_fused_actor_matches_pytorch_float32_reference():
         np.testing.assert_allclose(fused.logits(obs.cuda()).cpu().numpy(), want.numpy(), rtol=0, atol=2e-5)
 
 
+def test_bf16x3_input_projection_mode_within_the_float32_tolerance():
+    """The OPT-IN, not exact actor mode (pw_actor_set_bf16x3 / pw_set_actor_precision: LSTM input projection on bfloat16 matrix
+    instructions, operands split in high and low halves, three products per k step) against the reference's own logits
+    (tests/golden/actor_forward.npz) and plain PyTorch fp32 at the 2e-5 bound the exact form is held to; it must differ from
+    the exact form somewhere (else the switch did nothing); and the exact form is back, bit for bit, once it is off."""
+    from multiagent_rl_amd import _lib
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    lib = _lib.load()
+    g = np.load(os.path.join(GOLD_DIR, 'actor_forward.npz'))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd/')}
+    ref = ActorNetwork(16, 5)
+    ref.load_state_dict(sd)
+    fused = FusedActor(ActorNetwork(16, 5).cuda().eval())
+    fused.actor.load_state_dict(sd)
+    fused.refresh()
+    gobs = torch.from_numpy(g['obs']).cuda()
+    exact = fused.logits(gobs).clone()
+    assert lib.pw_actor_set_bf16x3(1) == 0
+    try:
+        got = fused.logits(gobs)
+        np.testing.assert_allclose(got.cpu().numpy(), g['logits'], rtol=0, atol=2e-5)
+        assert not torch.equal(got, exact)
+        torch.manual_seed(1)
+        worst = 0.0
+        for B, N in [(1, 3), (257, 6), (1000, 12), (33, 1), (4096, 6)]:
+            obs = torch.randn(B, N, 16) * 2
+            with torch.no_grad():
+                want = ref(obs)
+            got = fused.logits(obs.cuda()).cpu()
+            np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=2e-5)
+            worst = max(worst, float((got - want).abs().max()))
+        assert worst > 0.0
+    finally:
+        assert lib.pw_actor_set_bf16x3(0) == 1
+    assert torch.equal(fused.logits(gobs), exact)
+
+
+def test_bf16x3_mode_in_the_one_launch_rollout():
+    """pw_set_actor_precision on a handle: the one-launch policy rollout runs in the bf16x3 mode (outputs finite, episode
+    statistics those of the exact form to sampling noise) and returns to the exact bits when the mode is switched back."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    torch.manual_seed(4)
+    mk = lambda: make_batched_env('simple_spread', 2048, n=6, auto_reset=True, max_episode_len=25, seed=21)  # noqa: E731
+    actor = ActorNetwork(16, 5).cuda().eval()
+    outs = {}
+    for mode in ('f32', 'bf16x3', 'f32-again'):
+        env = mk()
+        env.reset()
+        assert env.get_actor_precision() == 'f32'
+        if mode == 'bf16x3':
+            env.set_actor_precision('bf16x3')
+            assert env.get_actor_precision() == 'bf16x3'
+        out = FusedActor(actor, seed=9).rollout(env, 100)
+        outs[mode] = {k: v.clone() for k, v in out.items() if torch.is_tensor(v)}
+    for k in outs['f32']:
+        if k != 'final_obs':            # written at terminal steps only
+            assert torch.equal(outs['f32'][k], outs['f32-again'][k]), k
+    a, b = outs['f32'], outs['bf16x3']
+    assert torch.isfinite(b['obs']).all() and torch.isfinite(b['rew_shared']).all()
+    same = (a['act'] == b['act']).float().mean().item()
+    assert 0.5 < same <= 1.0            # the first steps agree; trajectories then part wherever one arg-max flips
+    assert (a['act'][0] == b['act'][0]).float().mean().item() > 0.999
+    assert abs(a['rew_shared'].mean().item() - b['rew_shared'].mean().item()) < 0.05 * abs(a['rew_shared'].mean().item())
+
+
 def test_fused_gumbel_sampling_distribution():
     """act = argmax(logits + Gumbel): frequencies follow softmax(logits); streams differ per call and row."""
     from multiagent_rl_amd.policy import ActorNetwork, FusedActor
