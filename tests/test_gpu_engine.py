@@ -460,7 +460,7 @@ def test_one_launch_actor_equals_three_launch_chain(monkeypatch):
 
 
 @pytest.mark.parametrize('form', ['default', 'v1', 'v2', 'v3'])
-@pytest.mark.parametrize('B,N,T', [(16, 6, 3), (4096, 6, 30), (512, 6, 300), (100, 3, 60), (37, 7, 27), (5, 10, 4), (70, 2, 26),
+@pytest.mark.parametrize('B,N,T', [(16, 6, 3), (4096, 6, 30), (512, 6, 300), (8192, 6, 130), (100, 3, 60), (37, 7, 27), (5, 10, 4), (70, 2, 26),
                                    (9, 12, 26), (33, 16, 26), (7, 24, 5), (4, 30, 3)])
 def test_one_launch_policy_rollout_equals_the_step_loop(B, N, T, form):
     """pw_policy_rollout (T x (actor + sampling + env step) in ONE launch, everything resident on the CU) vs the
