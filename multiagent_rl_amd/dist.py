@@ -234,9 +234,9 @@ class FullTransitionGather(object):
     """north_star's collective: EVERY transition of every rank's rollout chunk lands in the learner rank's replay
     ring (the reference keeps one buffer that sees every env-step: experiments/run.py:20-21,52).
 
-    Sized for the policy-in-the-loop rollout (``pw_policy_rollout``: ~2e8 env-steps/s per GPU), where a full gather
-    fits xGMI: 395 B per env-step (+ (1 + F)/T observation batches per chunk) is 70-90 GB/s per peer against
-    ~153 GB/s per link; the synthetic-action headline (4e9 env-steps/s per GPU = 1.6 TB/s per peer) keeps
+    Sized for the policy-in-the-loop rollout (``pw_policy_rollout``: 2.8e8 env-steps/s per GPU since round 3, 1.9e8
+    before), where a full gather fits xGMI: 395 B per env-step (+ (1 + F)/T observation batches per chunk) is
+    ~110 GB/s per peer (75 before) against ~153 GB/s per link -- the root's seven inbound links are the bound now; the synthetic-action headline (4e9 env-steps/s per GPU = 1.6 TB/s per peer) keeps
     ``SampledTransitionGather``.
 
     Per chunk and rank ONE wire block (``pw_chunk_wire``): the rollout kernel writes ``obs`` / ``rew_shared``
