@@ -737,6 +737,22 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
         rb.collect_one_launch(n_chunks * Tp, chunk=Tp)
         sync()
         tb = time.perf_counter() - tb
+        # the other scenarios of the reference's sweep with their actors in the loop (same one-launch form, ring append included)
+        others = []
+        tenv = BatchedParticleEnv('simple_tag', 8192, num_adversaries=4, num_good=2, max_episode_len=25, auto_reset=True, seed=1)
+        tro = BatchedRollout(tenv, FusedActor(ActorNetwork(tenv.obs_dim, 5).to(dev).eval(), seed=2), ReplayBuffer(1e6, tenv.n, tenv.obs_dim))
+        renv = BatchedParticleEnv('simple_reference', B, max_episode_len=25, auto_reset=True, seed=3)
+        rro = BatchedRollout(renv, FusedActor(ActorNetwork(renv.obs_dim, [5, 10]).to(dev).eval(), seed=7),
+                             ReplayBuffer(int(8e6), 2, renv.obs_dim, act_heads=(5, 10)))
+        for name, o_env, o_ro in (('simple_tag 4+2, B=8192', tenv, tro), ('simple_reference (two-head actor [5|10]), B=%d' % B, renv, rro)):
+            o_ro.collect_one_launch(Tp, chunk=Tp)
+            sync()
+            to = time.perf_counter()
+            o_ro.collect_one_launch(5 * Tp, chunk=Tp)
+            sync()
+            to = time.perf_counter() - to
+            others.append(dict(config=name, value=o_env.num_envs * 5 * Tp / to, unit='env-steps/s', us_per_step=to / (5 * Tp) * 1e6))
+        line['other_scenarios'] = others
         line['bf16x3_input_projection'] = dict(value=B * n_chunks * Tp / tb, us_per_step=tb / (n_chunks * Tp) * 1e6, exact=False,
                                                note='opt-in (PW_ACTOR_BF16X3=1 / pw_set_actor_precision), within 2e-5 of the '
                                                     'float32 logits, does not reproduce the exact form\'s sampled actions; '
