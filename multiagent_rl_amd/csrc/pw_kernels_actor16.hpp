@@ -205,11 +205,16 @@ __device__ __forceinline__ void actor16_load(const ActorFusedArgs &A, const Acto
 //   act_g / act_l   sinks of the sampled indices [rows_here * nheads], global / LDS (either may be NULL); A.H, A.logits too
 // Arithmetic: element for element the operation sequence of actor_forward_wg (see pw_kernels_policy3.hpp, "Bits").
 // On return every thread has passed a barrier after the last LDS access of the pass.  BF3: the opt-in bf16x3 input projection.
-template <int S1C, bool BF3 = false>
+// pre() / mid(): called by every wave before its dense1 blocks / before its head tiles -- the two windows in which waves without
+// a block or a tile idle; a rollout kernel parks the tail of its previous environment step there (no LDS of the pass touched).
+struct Actor16NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int S1C, bool BF3 = false, class Pre = Actor16NoHook, class Mid = Actor16NoHook>
 __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const Actor16Lds &S, const Actor16W &W,
                                                 const float *xrows, const int xstride, const int rows_here,
                                                 const int envs_here, const long row_base, const uint64_t step,
-                                                int32_t *act_g, int32_t *act_l)
+                                                int32_t *act_g, int32_t *act_l, Pre pre = Pre(), Mid mid = Mid())
 {
     constexpr int S1 = 4 * S1C;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
@@ -219,6 +224,7 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
     const int nblk = 2 * ((N + 1) >> 1);  // dense1 blocks: (32-column tile = two timesteps of 16 sequences) x (hidden half)
     const bool seq_ok = n16 < envs_here;
 
+    pre();
     // ---- dense1 + ReLU: 32 x 32 blocks of relu(W1 X^T + b1), column rho = 16 * timestep + sequence
     for (int blk = wave; blk < nblk; blk += 8) {
         const int rt = blk >> 1, m = blk & 1;
@@ -292,6 +298,7 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
         }
     }
 
+    mid();
     // ---- optional: the hidden state H [rows][64] back in row order
     if (A.H) {
         for (int idx = tid; idx < rows_here * 64; idx += 512) {

@@ -46,8 +46,9 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
     const long row_base = env0 * N;
     const size_t BN = (size_t)A.B * N;
 
-    // ---- environment lanes: wave 0, lane = el * 2 + a (E <= 16 envs: 32 lanes)
-    const bool env_wave = wave == 0;
+    // ---- environment lanes: the LAST wave, lane = el * 2 + a (E <= 16 envs: 32 lanes) -- the tail of a step (reward, stores) then runs
+    // beside the next actor pass's dense1 blocks and head tiles, which sit on waves 0 and 1 (actor16_forward's pre / mid windows)
+    const bool env_wave = wave == 7;
     int el = lane >> 1;
     const int a = lane & 1;
     const bool live = env_wave && el < envs_here;
@@ -70,13 +71,49 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
     const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
     wg_lds_barrier();
 
+    // the rest of a step once the agents are advanced and the next observation rows published: rewards + episode step count
+    // (tail_compute), every global store (tail_stores); a wave with an episode ending in this step does everything at once
+    int ai = 0, ci = 0, tail_t = 0, tail_stage = 0;
+    float t_rw = 0.f, t_acc = 0.f;
+    bool t_term = false;
+    float co[DC];  // the other agent's symbol (this step's)
+    auto tail_compute = [&]() {
+        const float ox = __shfl_xor(s.px, 1, kWave), oy = __shfl_xor(s.py, 1, kWave);
+        float glx = s.lmx[0], gly = s.lmy[0];
+        if (s.goal == 1) { glx = s.lmx[1]; gly = s.lmy[1]; }
+        if (s.goal == 2) { glx = s.lmx[2]; gly = s.lmy[2]; }
+        const float dx = ox - glx, dy = oy - gly;
+        const float rw = -(dx * dx + dy * dy);
+        const float r_other = __shfl_xor(rw, 1, kWave);
+        t_rw = rw;
+        t_acc = (0.0f + (a == 0 ? rw : r_other)) + (a == 0 ? r_other : rw);  // agent order
+        ep_step += 1;
+        t_term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
+    };
+    auto tail_stores = [&](const int t, const bool with_obs) {
+        const size_t row = (size_t)t * BN + g;
+        if (live) {
+            if (P.act_out) { P.act_out[2 * row] = ai; P.act_out[2 * row + 1] = ci; }
+            if (P.rew) P.rew[row] = t_rw;
+            if (P.done) P.done[row] = 0;
+            if (a == 0) {
+                if (P.rew_shared) P.rew_shared[(size_t)t * A.B + env] = t_acc;
+                if (P.terminal) P.terminal[(size_t)t * A.B + env] = t_term ? 1 : 0;
+            }
+            if (with_obs && P.obs) ref_write_obs<DC, false>(V, s, co, a, P.obs + row * D);
+        }
+    };
+    auto pre_hook = [&]() { if (tail_stage == 1) { tail_compute(); tail_stage = 2; } };
+    auto mid_hook = [&]() { if (tail_stage == 2) { tail_stores(tail_t, true); tail_stage = 0; } };
+
     for (int t = 0; t < P.T; ++t) {
         // ---- policy: observation rows (LDS) -> one sampled index per head and row (LDS)
-        actor16_forward<S1C>(A, S, W, s_obs, D, rows_here, envs_here, row_base, step0 + (uint64_t)t, nullptr, s_act);  // a barrier at its end
+        actor16_forward<S1C, false>(A, S, W, s_obs, D, rows_here, envs_here, row_base, step0 + (uint64_t)t, nullptr, s_act, pre_hook,
+                                    mid_hook);  // a barrier at its end
         // ---- environment step (pw_reference_rollout_kernel's arithmetic, index actions)
         if (env_wave) {
             const size_t row = (size_t)t * BN + g;
-            const int ai = s_act[2 * r], ci = s_act[2 * r + 1];
+            ai = s_act[2 * r]; ci = s_act[2 * r + 1];
             const float a1 = ai == 1, a2 = ai == 2, a3 = ai == 3, a4 = ai == 4;
             float cn[DC];
 #pragma unroll
@@ -93,43 +130,34 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
             }
 #pragma unroll
             for (int q = 0; q < DC; ++q) s.c[q] = cn[q] + 0.0f;
-            const float ox = __shfl_xor(s.px, 1, kWave), oy = __shfl_xor(s.py, 1, kWave);
-            float co[DC];
 #pragma unroll
             for (int q = 0; q < DC; ++q) co[q] = __shfl_xor(s.c[q], 1, kWave);
-            float glx = s.lmx[0], gly = s.lmy[0];
-            if (s.goal == 1) { glx = s.lmx[1]; gly = s.lmy[1]; }
-            if (s.goal == 2) { glx = s.lmx[2]; gly = s.lmy[2]; }
-            const float dx = ox - glx, dy = oy - gly;
-            const float rw = -(dx * dx + dy * dy);
-            const float r_other = __shfl_xor(rw, 1, kWave);
-            const float acc = (0.0f + (a == 0 ? rw : r_other)) + (a == 0 ? r_other : rw);  // agent order
-            ep_step += 1;
-            const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
-            if (live) {
-                if (P.act_out) { P.act_out[2 * row] = ai; P.act_out[2 * row + 1] = ci; }
-                if (P.rew) P.rew[row] = rw;
-                if (P.done) P.done[row] = 0;
-                if (a == 0) {
-                    if (P.rew_shared) P.rew_shared[(size_t)t * A.B + env] = acc;
-                    if (P.terminal) P.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
-                }
-            }
-            if (term && V.auto_reset) {
-                if (live && P.final_obs) ref_write_obs<DC, false>(V, s, co, a, P.final_obs + row * D);
-                ep_count += 1;
-                ep_step = 0;
-                ref_reset<DC, false>(V, V.env_id_base + (uint64_t)env, ep_count, a, s);
+            const bool ends = V.auto_reset && V.max_episode_len > 0 && ep_step + 1 >= V.max_episode_len;
+            if (__any(ends)) {
+                tail_compute();
+                tail_stores(t, false);
+                if (t_term && V.auto_reset) {
+                    if (live && P.final_obs) ref_write_obs<DC, false>(V, s, co, a, P.final_obs + row * D);
+                    ep_count += 1;
+                    ep_step = 0;
+                    ref_reset<DC, false>(V, V.env_id_base + (uint64_t)env, ep_count, a, s);
 #pragma unroll
-                for (int q = 0; q < DC; ++q) co[q] = 0.f;  // the other agent reset too
-            }
-            if (live) {
-                if (P.obs) ref_write_obs<DC, false>(V, s, co, a, P.obs + row * D);
-                ref_write_obs<DC, false>(V, s, co, a, s_obs + r * D);
+                    for (int q = 0; q < DC; ++q) co[q] = 0.f;  // the other agent reset too
+                }
+                if (live) {
+                    if (P.obs) ref_write_obs<DC, false>(V, s, co, a, P.obs + row * D);
+                    ref_write_obs<DC, false>(V, s, co, a, s_obs + r * D);
+                }
+            } else {
+                if (live) ref_write_obs<DC, false>(V, s, co, a, s_obs + r * D);
+                tail_stage = 1;
+                tail_t = t;
             }
         }
         wg_lds_barrier();
     }
+    if (tail_stage == 1) tail_compute();
+    if (tail_stage != 0) tail_stores(tail_t, true);
     if (live) {
         ref_store<DC>(V, env, a, s);
         if (a == 0) { V.ep_step[env] = ep_step; V.ep_count[env] = ep_count; }

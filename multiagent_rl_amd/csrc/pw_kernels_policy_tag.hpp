@@ -61,15 +61,18 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
     const int waves_full = (A.E + epw_max - 1) / epw_max;
     const int epw = (A.E + waves_full - 1) / waves_full;
     const int n_env_waves = (envs_here + epw - 1) / epw;
-    const bool env_wave = wave < n_env_waves;
+    // the LAST waves: the tail of an environment step (partner pass, rewards, stores) then runs beside the next actor pass's
+    // dense1 blocks and head tiles, which are dealt from wave 0 up (actor16_forward's pre / mid windows)
+    const int ewi = wave - (8 - n_env_waves);
+    const bool env_wave = ewi >= 0;
     int e_loc = lane / N, a = lane - e_loc * N;
-    int el = wave * epw + e_loc;
+    int el = ewi * epw + e_loc;
     const bool live = env_wave && e_loc < epw && el < envs_here;
-    if (!live) { e_loc = 0; a = 0; el = env_wave ? wave * epw : 0; }  // idle lanes shadow lane 0, store nothing
+    if (!live) { e_loc = 0; a = 0; el = env_wave ? ewi * epw : 0; }  // idle lanes shadow lane 0, store nothing
     const int base = e_loc * N, me = base + a, r = el * N + a;
     const long env = env0 + el;
     const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
-    const int ew = env_wave ? wave : 0;
+    const int ew = env_wave ? ewi : 0;
     float2 *s_pos = s_posb + ew * kWave, *s_vel = s_velb + ew * kWave;
     uint32_t *s_mlo = s_mlob + ew * kWave, *s_mhi = s_mhib + ew * kWave;
     float *s_rew = s_rewb + ew * kWave;
@@ -123,12 +126,72 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
     const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
     wg_lds_barrier();
 
+    // The rest of an environment step once the agents are advanced and the next observation rows published, in two pieces:
+    //   tail_compute  partner pass on the new positions (the next step's forces need its masks), rewards, episode bookkeeping
+    //   tail_stores   every global store of the step
+    // run by the environment waves inside the NEXT actor pass (before its dense1 blocks / before its head tiles).  A wave with an
+    // episode ending in this step runs both, the reset and the post-reset partner pass before it publishes the rows.
+    int ai = 0, tail_t = 0, tail_stage = 0;  // tail_stage: 0 nothing pending, 1 tail_compute pending, 2 tail_stores pending
+    size_t slot = 0;
+    float t_rw = 0.f, t_acc = 0.f;
+    bool t_term = false;
+    auto tail_compute = [&]() {
+        partner_pass();
+        // simple_tag.reward
+        if (live) { s_mlo[me] = (uint32_t)coll; s_mhi[me] = (uint32_t)(coll >> 32); }
+        wave_lds_sync();
+        float rw = 0.0f;
+        if (cls) {
+            for (int q = 0; q < NA; ++q)
+                if ((coll >> q) & 1) rw -= 10.0f;
+            rw -= tag_bound(fabsf(px));
+            rw -= tag_bound(fabsf(py));
+        } else {
+            for (int gj = NA; gj < N; ++gj) {
+                const uint64_t mg = ((uint64_t)s_mhi[base + gj] << 32) | s_mlo[base + gj];
+                rw += 10.0f * (float)__builtin_popcountll(mg & adv_bits);
+            }
+        }
+        if (live) s_rew[me] = rw;
+        wave_lds_sync();
+        float acc = 0.0f;
+        for (int i = 0; i < N; ++i) acc += s_rew[base + i];
+        ep_step += 1;
+        t_term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
+        t_rw = rw;
+        t_acc = acc;
+        if (SINK && live && a == 0 && P.episode_return) {
+            const float rsum = ep_ret + acc;
+            if (t_term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
+            else ep_ret = rsum;
+        }
+    };
+    auto tail_stores = [&](const int t, const bool with_obs) {  // with_obs: V.obs too (no reset in between: the same row)
+        const size_t tBN = (size_t)t * BN;
+        if (live) {
+            if (P.act_out) P.act_out[tBN + g] = ai;
+            if (V.rew) V.rew[tBN + g] = t_rw;
+            if (V.done) V.done[tBN + g] = 0;
+            if (a == 0) {
+                if (V.rew_shared) V.rew_shared[(size_t)t * A.B + env] = t_acc;
+                if (V.terminal) V.terminal[(size_t)t * A.B + env] = t_term ? 1 : 0;
+            }
+            if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
+                tag_write_obs<0, -1, 0>(P.ring.next_obs + (slot * N + a) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                if (a == 0) { P.ring.rew[slot] = t_acc; P.ring.done[slot] = 0.0f; }
+            }
+            if (with_obs && V.obs) tag_write_obs<0, -1, 0>(V.obs + (tBN + g) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+        }
+    };
+    auto pre_hook = [&]() { if (tail_stage == 1) { tail_compute(); tail_stage = 2; } };
+    auto mid_hook = [&]() { if (tail_stage == 2) { tail_stores(tail_t, true); tail_stage = 0; } };
+
     for (int t = 0; t < P.T; ++t) {
-        actor16_forward<S1C>(A, S, W, s_obs, D, rows_here, envs_here, row_base, step0 + (uint64_t)t, nullptr, s_act);  // a barrier at its end
+        actor16_forward<S1C, false>(A, S, W, s_obs, D, rows_here, envs_here, row_base, step0 + (uint64_t)t, nullptr, s_act, pre_hook,
+                                    mid_hook);  // a barrier at its end
         if (env_wave) {
             const size_t tBN = (size_t)t * BN;
-            const int ai = s_act[r];
-            size_t slot = 0;
+            ai = s_act[r];
             if (SINK && P.has_ring) {  // the observation the policy acted on (still in LDS) -> ring.obs
                 slot = (size_t)((P.ring_start + (int64_t)t * A.B + env) % P.ring.capacity);
                 if (live) {
@@ -169,71 +232,43 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
             wave_lds_sync();
             if (live) { s_pos[me] = make_float2(px, py); s_vel[me] = make_float2(vx, vy); }
             wave_lds_sync();
-            partner_pass();
-            // simple_tag.reward
-            if (live) { s_mlo[me] = (uint32_t)coll; s_mhi[me] = (uint32_t)(coll >> 32); }
-            wave_lds_sync();
-            float rw = 0.0f;
-            if (cls) {
-                for (int q = 0; q < NA; ++q)
-                    if ((coll >> q) & 1) rw -= 10.0f;
-                rw -= tag_bound(fabsf(px));
-                rw -= tag_bound(fabsf(py));
-            } else {
-                for (int gj = NA; gj < N; ++gj) {
-                    const uint64_t mg = ((uint64_t)s_mhi[base + gj] << 32) | s_mlo[base + gj];
-                    rw += 10.0f * (float)__builtin_popcountll(mg & adv_bits);
+            const bool ends = V.auto_reset && V.max_episode_len > 0 && ep_step + 1 >= V.max_episode_len;
+            if (__any(ends)) {
+                tail_compute();
+                tail_stores(t, false);
+                const bool term = t_term;
+                if (term && V.auto_reset) {  // same for every lane of an env
+                    if (live && V.final_obs)
+                        tag_write_obs<0, -1, 0>(V.final_obs + (tBN + g) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                    wave_lds_sync();
+                    ep_count += 1;
+                    ep_step = 0;
+                    pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
+                    vx = 0.f; vy = 0.f;
+                    if (live)
+                        for (int l = a; l < L; l += N) {
+                            float x, y;
+                            pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)(N + l), -0.9f, 0.9f, &x, &y);
+                            lmv[l] = make_float2(x, y);
+                        }
+                    if (live) { s_pos[me] = make_float2(px, py); s_vel[me] = make_float2(0.f, 0.f); }
                 }
-            }
-            if (live) s_rew[me] = rw;
-            wave_lds_sync();
-            float acc = 0.0f;
-            for (int i = 0; i < N; ++i) acc += s_rew[base + i];
-            ep_step += 1;
-            const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
-            if (live) {
-                if (P.act_out) P.act_out[tBN + g] = ai;
-                if (V.rew) V.rew[tBN + g] = rw;
-                if (V.done) V.done[tBN + g] = 0;
-                if (a == 0) {
-                    if (V.rew_shared) V.rew_shared[(size_t)t * A.B + env] = acc;
-                    if (V.terminal) V.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
-                }
-                if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
-                    tag_write_obs<0, -1, 0>(P.ring.next_obs + (slot * N + a) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
-                    if (a == 0) { P.ring.rew[slot] = acc; P.ring.done[slot] = 0.0f; }
-                }
-                if (SINK && a == 0 && P.episode_return) {
-                    const float rsum = ep_ret + acc;
-                    if (term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
-                    else ep_ret = rsum;
-                }
-            }
-            if (term && V.auto_reset) {  // same for every lane of an env
-                if (live && V.final_obs)
-                    tag_write_obs<0, -1, 0>(V.final_obs + (tBN + g) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
                 wave_lds_sync();
-                ep_count += 1;
-                ep_step = 0;
-                pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
-                vx = 0.f; vy = 0.f;
-                if (live)
-                    for (int l = a; l < L; l += N) {
-                        float x, y;
-                        pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)(N + l), -0.9f, 0.9f, &x, &y);
-                        lmv[l] = make_float2(x, y);
-                    }
-                if (live) { s_pos[me] = make_float2(px, py); s_vel[me] = make_float2(0.f, 0.f); }
-            }
-            wave_lds_sync();
-            if (V.auto_reset && __any(term)) partner_pass();
-            if (live) {
-                if (V.obs) tag_write_obs<0, -1, 0>(V.obs + (tBN + g) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
-                tag_write_obs<0, -1, 0>(s_obs + r * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                if (__any(term && V.auto_reset)) partner_pass();
+                if (live) {
+                    if (V.obs) tag_write_obs<0, -1, 0>(V.obs + (tBN + g) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                    tag_write_obs<0, -1, 0>(s_obs + r * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                }
+            } else {
+                if (live) tag_write_obs<0, -1, 0>(s_obs + r * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                tail_stage = 1;
+                tail_t = t;
             }
         }
         wg_lds_barrier();
     }
+    if (tail_stage == 1) tail_compute();
+    if (tail_stage != 0) tail_stores(tail_t, true);
 
     if (live) {
         V.pos_x[g] = px; V.pos_y[g] = py;
