@@ -176,11 +176,18 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
                 if (V.rew_shared) V.rew_shared[(size_t)t * A.B + env] = t_acc;
                 if (V.terminal) V.terminal[(size_t)t * A.B + env] = t_term ? 1 : 0;
             }
+            // with_obs: no reset in between, so next_obs and obs are both the row this lane published in LDS -- copied, not rebuilt
+            const float2 *row = reinterpret_cast<const float2 *>(s_obs + r * D);
             if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
-                tag_write_obs<0, -1, 0>(P.ring.next_obs + (slot * N + a) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                float *dst = P.ring.next_obs + (slot * N + a) * D;
+                if (with_obs) for (int c = 0; c < D / 2; ++c) reinterpret_cast<float2 *>(dst)[c] = row[c];
+                else tag_write_obs<0, -1, 0>(dst, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
                 if (a == 0) { P.ring.rew[slot] = t_acc; P.ring.done[slot] = 0.0f; }
             }
-            if (with_obs && V.obs) tag_write_obs<0, -1, 0>(V.obs + (tBN + g) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+            if (with_obs && V.obs) {
+                float2 *dst = reinterpret_cast<float2 *>(V.obs + (tBN + g) * D);
+                for (int c = 0; c < D / 2; ++c) dst[c] = row[c];
+            }
         }
     };
     auto pre_hook = [&]() { if (tail_stage == 1) { tail_compute(); tail_stage = 2; } };
