@@ -77,6 +77,30 @@ def test_handle_geometry_and_errors():
     assert lib.pw_config_default(C.byref(cfg), 7, 16, 6, -1, 0) == -1 and b'scenario' in lib.pw_last_error()
 
 
+def test_actor_precision_is_a_handle_property_outside_the_dispatch(monkeypatch):
+    """pw_set_actor_precision / pw_get_actor_precision: exact float32 by default, the opt-in bf16x3 mode by call or by
+    PW_ACTOR_BF16X3=1 in the environment of pw_create (read once, there), other values refused -- and it is NOT a pw_dispatch
+    field (the dispatch never changes results; this switch does).  pw_actor_set_bf16x3 returns the previous process-wide value."""
+    lib = _lib.load()
+    monkeypatch.delenv('PW_ACTOR_BF16X3', raising=False)
+    cfg = _lib.PwConfig()
+    lib.pw_config_default(C.byref(cfg), _lib.PW_SIMPLE_SPREAD, 64, 6, -1, 0)
+    h, h2 = C.c_void_p(), C.c_void_p()
+    assert lib.pw_create(C.byref(cfg), C.byref(h)) == 0
+    assert lib.pw_get_actor_precision(h) == 0
+    assert lib.pw_set_actor_precision(h, 1) == 0 and lib.pw_get_actor_precision(h) == 1
+    assert lib.pw_set_actor_precision(h, 2) == -1 and b'PW_ACTOR' in lib.pw_last_error()
+    assert lib.pw_get_actor_precision(h) == 1
+    assert lib.pw_set_actor_precision(h, 0) == 0 and lib.pw_get_actor_precision(h) == 0
+    monkeypatch.setenv('PW_ACTOR_BF16X3', '1')
+    assert lib.pw_create(C.byref(cfg), C.byref(h2)) == 0
+    assert lib.pw_get_actor_precision(h2) == 1 and lib.pw_get_actor_precision(h) == 0   # read once, at pw_create of h2
+    assert 'actor' not in ' '.join(n for n, _ in _lib.PwDispatch._fields_)
+    assert lib.pw_actor_set_bf16x3(0) == 0 and lib.pw_actor_set_bf16x3(1) == 0 and lib.pw_actor_set_bf16x3(0) == 1
+    lib.pw_destroy(h)
+    lib.pw_destroy(h2)
+
+
 def test_dispatch_lives_in_the_handle(monkeypatch):
     """pw_dispatch (kernel selection): defaults, the one-time overlay of PWORLD_* at pw_create, set / get, range checks --
     and the launch path of csrc/pworld.hip contains no getenv at all (the only reads are in dispatch_from_environment)."""
