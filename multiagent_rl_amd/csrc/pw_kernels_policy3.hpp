@@ -24,13 +24,20 @@ namespace {
 // issued before the barrier of timestep ts, so the matrix pipe has work while the workgroup meets.
 //   dense1 + ReLU: as 32 x 32 blocks on v_mfma_f32_32x32x2_f32 (one block per wave, once per workgroup), scattered to LDS
 //   directly in the B-fragment order of the timestep loop.
-//   head, Gumbel noise, environment step: as in the second form.
+//   head: logits^T = W2 * relu(h)^T on the same 16x16x4 tiles (W2 as A fragments, C-in = b2), minus the Gumbel noise, arg-max in
+//   the lanes.  Gumbel noise: one Philox block per four logits, drawn for the NEXT step by the waves without environment duty
+//   while the environment waves advance the agents.
+//   environment step: on the LAST waves (lane = (env, agent), pw_spread_stream_kernel's arithmetic), in three pieces: advance the
+//   agents and publish the next observation rows (all the other waves wait for); partner pass + episode step count beside the next
+//   step's dense1 blocks; rewards and every global store beside its head tiles (both on the first waves).  A wave with an episode
+//   ending in the step does everything, the reset included, before it publishes.
+//   (pw_kernels_actor16.hpp holds the same pass as a function for the kernels that are not built around it.)
 // Bits: v_mfma_f32_16x16x4_f32 is a chain of fused multiply-adds over k = 0..3 in order (tools/mfma16_probe.hip: 0 of
 // 512000 elements differ), as the 32x32x2 form is over its two k; the input projection feeds k in the order the other
 // forms' 32x32x2 chains use (pairs {k, k + 4}), the bias is added to the finished sum, the recurrence continues the same
 // accumulator with k ascending -- element for element the operation sequence of pw_bilstm_kernel.  (At the first timestep
 // h = 0 and the other forms run the chain with zeros, which leaves every nonzero accumulator unchanged; here it is skipped.)
-// LDS (N = 6, D = 16): 24 KB x1 fragments + 8 KB h exchange + 26 KB head input + 20 KB small = 78 KB.
+// LDS (N = 6, D = 16): 24 KB x1 fragments + 8 KB h exchange + 24 KB head input + 18 KB small = 74 KB.
 // ------------------------------------------------------------------------------------------
 struct Roll3Lds {
     float4 *s_xf;    // [N timesteps][4 j][64 lane]: element e of (j, lane (n, kq)) = x1[row (ts, n)][kpos(16 j + 4 e + kq)]
@@ -46,7 +53,6 @@ struct Roll3Lds {
     float2 *s_lmb;   // [E * L]
     double *s_fs;    // [16]
     int *s_fc;       // [16]
-    float *s_lg;     // perturbed logits [rows * 5] -- aliases s_xf, dead once the timestep loop is done
 };
 __host__ __device__ inline size_t roll3_lds_bytes(int E, int N, int L, int D, int S1)
 {
@@ -77,7 +83,6 @@ __device__ __forceinline__ Roll3Lds roll3_carve(unsigned char *raw, int E, int N
     S.s_lmb = reinterpret_cast<float2 *>(base + o); o += E * L * 2;
     S.s_fs = reinterpret_cast<double *>(base + o); o += 32;
     S.s_fc = reinterpret_cast<int *>(base + o);
-    S.s_lg = reinterpret_cast<float *>(S.s_xf);
     return S;
 }
 
