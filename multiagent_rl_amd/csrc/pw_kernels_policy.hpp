@@ -25,6 +25,14 @@ __device__ __forceinline__ float fast_tanh(float x)
     return copysignf(t, x);
 }
 
+// One LSTM cell (PyTorch's gate order i, f, g, o): pre-activations -> new cell state c and output h.  Every kernel form calls this
+// one function, so the forms agree bit for bit whatever the activations' rounding is.
+__device__ __forceinline__ void lstm_cell(const float gi, const float gf, const float gg, const float go, float &c, float &h)
+{
+    c = fast_sigmoid(gf) * c + fast_sigmoid(gi) * fast_tanh(gg);
+    h = fast_sigmoid(go) * fast_tanh(c);
+}
+
 // One hidden unit's four W_hh rows, gate pairs (i, f) and (g, o) packed so that a recurrence step is 64
 // v_pk_fma_f32 (two gates per instruction, h broadcast through op_sel) instead of 128 scalar FMAs.  Each
 // gate still accumulates over k in ascending order with fused multiply-adds: the same bits either way.
@@ -64,8 +72,7 @@ __device__ __forceinline__ void lstm_step(const LstmUnitW &w, const float *hs, f
         ago = __builtin_elementwise_fma(w.wgo[4 * q + 3], f32x2{hv.w, hv.w}, ago);
     }
     wave_lds_sync();  // all reads of h done before the caller overwrites it
-    c = fast_sigmoid(aif.y) * c + fast_sigmoid(aif.x) * fast_tanh(ago.x);
-    h = fast_sigmoid(ago.y) * fast_tanh(c);
+    lstm_cell(aif.x, aif.y, ago.x, ago.y, c, h);
 }
 
 __global__ void __launch_bounds__(256) pw_bilstm_kernel(const float *__restrict__ G, const float *__restrict__ w_fw,

@@ -159,8 +159,7 @@ __device__ __forceinline__ void lstm_step4(const LstmUnitW &w, const float *hs, 
     wave_lds_sync();  // all reads of h done before the caller overwrites it
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        c[i] = fast_sigmoid(aif[i].y) * c[i] + fast_sigmoid(aif[i].x) * fast_tanh(ago[i].x);
-        h[i] = fast_sigmoid(ago[i].y) * fast_tanh(c[i]);
+        lstm_cell(aif[i].x, aif[i].y, ago[i].x, ago[i].y, c[i], h[i]);
     }
 }
 

@@ -396,10 +396,9 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
                     acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ahh[1][7], h1.w, acc[1], 0, 0, 0);
                 }
                 // the two cells of this lane: accumulator registers = gates i, f, g, o
-                c0 = fast_sigmoid(acc[0][1]) * c0 + fast_sigmoid(acc[0][0]) * fast_tanh(acc[0][2]);
-                c1 = fast_sigmoid(acc[1][1]) * c1 + fast_sigmoid(acc[1][0]) * fast_tanh(acc[1][2]);
-                const float h0v = fast_sigmoid(acc[0][3]) * fast_tanh(c0);
-                const float h1v = fast_sigmoid(acc[1][3]) * fast_tanh(c1);
+                float h0v, h1v;
+                lstm_cell(acc[0][0], acc[0][1], acc[0][2], acc[0][3], c0, h0v);
+                lstm_cell(acc[1][0], acc[1][1], acc[1][2], acc[1][3], c1, h1v);
                 // h exchange: unit u = hq * 8 + 4 T + kq is k quarter kq of k step 2 hq + T: fragment j = hq / 2, elements
                 // (2 hq) % 4 + T of this very lane slot
                 reinterpret_cast<float2 *>(S.s_hx + (((s2 & 1) * 2 + dir) * 2 + (hq >> 1)) * 64 + lane)[hq & 1] = make_float2(h0v, h1v);
