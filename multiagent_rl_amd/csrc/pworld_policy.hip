@@ -116,6 +116,7 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
         PW_HIP_CHECK(hipGetLastError());
         return PW_OK;
     }
+    if (a.bf16x3) return fail(PW_EINVAL, "pw_actor_set_bf16x3 serves N <= 16 only");
     const size_t shm = actor_lds_bytes(S1);
     const unsigned grid = (unsigned)((B + a.E - 1) / a.E);
     static unsigned long long attr_set[9] = {};  // per kernel: bit = device
@@ -161,7 +162,8 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         ra.frag = frag; ra.b1 = b1; ra.bih = b_ih; ra.whh_f = w_hh_fw; ra.whh_r = w_hh_bw; ra.w2 = w2; ra.b2 = b2;
         ra.B = kp.B; ra.N = 2; ra.D = kp.D; ra.relu_out = relu_out; ra.n_out0 = 5; ra.n_out1 = PW_DIM_C;
         ra.E = 16;
-        ra.seed = seed; ra.step = step; ra.step_dev = step_dev; ra.bf16x3 = h->actor_bf16x3;
+        ra.seed = seed; ra.step = step; ra.step_dev = step_dev;
+        if (h->actor_bf16x3) return fail(PW_EINVAL, "PW_ACTOR_BF16X3 serves the simple_spread rollout (and pw_actor_fused) only");
         R.V = ref_params(h);
         R.T = num_steps; R.act_out = act_out;
         R.obs = io->obs; R.final_obs = io->final_obs; R.rew = io->rew; R.rew_shared = io->rew_shared;
@@ -207,7 +209,8 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         qa.frag = frag; qa.b1 = b1; qa.bih = b_ih; qa.whh_f = w_hh_fw; qa.whh_r = w_hh_bw; qa.w2 = w2; qa.b2 = b2;
         qa.B = kp.B; qa.N = kp.N; qa.D = kp.D; qa.relu_out = relu_out; qa.n_out0 = 5; qa.n_out1 = 0;
         qa.E = 96 / kp.N < 16 ? 96 / kp.N : 16;
-        qa.seed = seed; qa.step = step; qa.step_dev = step_dev; qa.bf16x3 = h->actor_bf16x3;
+        qa.seed = seed; qa.step = step; qa.step_dev = step_dev;
+        if (h->actor_bf16x3) return fail(PW_EINVAL, "PW_ACTOR_BF16X3 serves the simple_spread rollout (and pw_actor_fused) only");
         Q.V = h->tp;
         TagParams &tv = Q.V;
         tv.pos_x = kp.pos_x; tv.pos_y = kp.pos_y; tv.vel_x = kp.vel_x; tv.vel_y = kp.vel_y;
@@ -288,6 +291,8 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     bool use_v3 = form == 3 ? E3 > 0 : form == 0 ? E3 >= (kp.B < 8 ? kp.B : 8) : (form == 1 && !v1_fits && E3 >= 8);
     bool use_v2 = !use_v3 && (!v1_fits || kp.N <= 6 || form >= 2);
     if (form == 1 && v1_fits) { use_v2 = false; use_v3 = false; }
+    if (a.bf16x3 && !use_v3)
+        return fail(PW_EINVAL, "PW_ACTOR_BF16X3 needs the third kernel form (policy_form 0 or 3, N <= 16 with 8+ environments per workgroup)");
     int E2 = use_v3 ? E3 : 0;
     if (use_v2) {
         for (int e = a.E; e >= 1; --e)

@@ -325,6 +325,11 @@ def test_bf16x3_mode_in_the_one_launch_rollout():
     for k in outs['f32']:
         if k != 'final_obs':            # written at terminal steps only
             assert torch.equal(outs['f32'][k], outs['f32-again'][k]), k
+    tag = make_batched_env('simple_tag', 64, num_adversaries=4, num_good=2, auto_reset=True, max_episode_len=25, seed=1)
+    tag.reset()
+    tag.set_actor_precision('bf16x3')
+    with pytest.raises(Exception, match='simple_spread'):   # refused, not silently run in float32
+        FusedActor(ActorNetwork(tag.obs_dim, 5).cuda().eval(), seed=2).rollout(tag, 10)
     a, b = outs['f32'], outs['bf16x3']
     assert torch.isfinite(b['obs']).all() and torch.isfinite(b['rew_shared']).all()
     same = (a['act'] == b['act']).float().mean().item()
