@@ -18,12 +18,25 @@ FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC',
          '-Wall', '-Wno-unused-function', '-Wno-cuda-compat', '-Wno-pass-failed', '-I', os.path.join(ROOT, 'include')]
 
 
-def _unit_deps(src):
-    """pworld.hip does not include the policy headers: an actor experiment leaves the env unit alone and vice versa."""
-    env_only = os.path.basename(src) == 'pworld.hip'
-    return [d for d in DEPS if not (env_only and 'policy' in os.path.basename(d))
-            and not (not env_only and os.path.basename(d) in ('pworld.hip', 'pw_kernels_spread_quad.hpp', 'pw_kernels_generic.hpp',
-                                                             'pw_kernels_reference.hpp', 'pw_kernels_replay.hpp'))]
+def _unit_deps(obj):
+    """The files one object was compiled from, as hipcc itself recorded them (-MD -MF <obj>.d): the unit's source, every
+    header it includes under csrc/ and include/.  None if there is no record yet (-> compile)."""
+    dep = obj + '.d'
+    if not os.path.exists(dep):
+        return None
+    words = open(dep).read().replace('\\\n', ' ').split()
+    files = [w for w in words[1:] if not w.endswith(':')]
+    return [f for f in files if f.startswith(ROOT)] or None
+
+
+def _stale(obj):
+    if not os.path.exists(obj):
+        return True
+    deps = _unit_deps(obj)
+    if deps is None:
+        return True
+    t = os.path.getmtime(obj)
+    return any(not os.path.exists(d) or os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=False):
@@ -36,9 +49,9 @@ def build(force=False, verbose=False):
     for src in SRCS:  # the two units compile in parallel
         obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
-        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _unit_deps(src)):
+        if not force and not _stale(obj):   # an actor experiment leaves the env unit alone and vice versa
             continue
-        cmd = [hipcc] + FLAGS + ['-c', '-o', obj, src]
+        cmd = [hipcc] + FLAGS + ['-MD', '-MF', obj + '.d', '-c', '-o', obj, src]
         if verbose:
             print(' '.join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

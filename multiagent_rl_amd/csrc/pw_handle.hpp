@@ -41,15 +41,32 @@ int check_ready(const pw_handle *h)
 }
 
 // Kernels that ask for more than 64 KB of dynamic LDS need the opt-in once per (kernel, DEVICE): a process driving
-// several GPUs must not skip it on the second one.
-bool lds_optin_needed(unsigned long long *done_mask)
+// several GPUs must not skip it on the second one.  The device's bit is set only AFTER hipFuncSetAttribute succeeded
+// (lds_optin_done), atomically: a failed call is retried by the next launch, and two host threads on different devices
+// cannot lose each other's bit.
+bool lds_optin_needed(const unsigned long long *done_mask, int *dev_out)
 {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;  // unknown: set it every time (cheap)
-    if (*done_mask >> dev & 1ull) return false;
-    *done_mask |= 1ull << dev;
-    return true;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *dev_out = -1; return true; }  // unknown: set it every time (cheap)
+    *dev_out = dev;
+    return !(__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) >> dev & 1ull);
 }
+
+void lds_optin_done(unsigned long long *done_mask, int dev)
+{
+    if (dev >= 0) __atomic_fetch_or(done_mask, 1ull << dev, __ATOMIC_RELEASE);
+}
+
+// hipFuncSetAttribute(kernel, MaxDynamicSharedMemorySize, 160 KB) once per (kernel, device); returns from the caller on failure
+#define PW_LDS_OPTIN(mask_ptr, kernel_expr)                                                                              \
+    do {                                                                                                                 \
+        int optin_dev_;                                                                                                  \
+        if (lds_optin_needed((mask_ptr), &optin_dev_)) {                                                                 \
+            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel_expr),                                \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+            lds_optin_done((mask_ptr), optin_dev_);                                                                      \
+        }                                                                                                                \
+    } while (0)
 
 // The chunk / tail / packed / wire entry points and the rollout sink write the plain ring layout only.
 int plain_ring_only(const pw_replay_store *st, const char *who)

@@ -101,10 +101,7 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
 #define PW_FUSED16B(C, BF)                                                                                               \
     do {                                                                                                                 \
         static unsigned long long attr_set16 = 0; /* bit = device */                                                     \
-        if (lds_optin_needed(&attr_set16)) {                                                                             \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_actor_fused16_kernel<C, BF>),             \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
+        PW_LDS_OPTIN(&attr_set16, (pw_actor_fused16_kernel<C, BF>)); \
         hipLaunchKernelGGL((pw_actor_fused16_kernel<C, BF>), dim3(grid16), dim3(512), shm16, st, a);                     \
     } while (0)
 #define PW_FUSED16(C) case C: if (a.bf16x3) PW_FUSED16B(C, true); else PW_FUSED16B(C, false); break;
@@ -122,10 +119,7 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
     static unsigned long long attr_set[9] = {};  // per kernel: bit = device
 #define PW_FUSED(C)                                                                                                      \
     case C:                                                                                                              \
-        if (lds_optin_needed(&attr_set[C])) {                                                                            \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_actor_fused_kernel<C>),                   \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
+        PW_LDS_OPTIN(&attr_set[C], (pw_actor_fused_kernel<C>)); \
         hipLaunchKernelGGL(pw_actor_fused_kernel<C>, dim3(grid), dim3(512), shm, st, a);                                 \
         break;
     switch (S1C) {
@@ -172,12 +166,11 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         if (rS1C != 3) return fail(PW_EINVAL, "simple_reference one-launch rollout: the observation is 21 numbers (3 landmarks)");
         const size_t rshm = actor16_lds_floats(2, 32, 4 * rS1C) * sizeof(float) + (size_t)kFusedRows * kp.D * sizeof(float) + 2 * kFusedRows * sizeof(int32_t);
         static unsigned long long attr_set = 0; /* bit = device */
-        if (lds_optin_needed(&attr_set))
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_ref_kernel<3>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PW_LDS_OPTIN(&attr_set, (pw_policy_rollout_ref_kernel<3>));
         hipLaunchKernelGGL((pw_policy_rollout_ref_kernel<3>), dim3((unsigned)((kp.B + 15) / 16)), dim3(512), rshm,
                            static_cast<hipStream_t>(stream), R);
         PW_HIP_CHECK(hipGetLastError());
+        h->last_kernel = "pw_policy_rollout_ref_kernel<3>";
         return PW_OK;
     }
     const bool tag = h->cfg.scenario == PW_SIMPLE_TAG && h->tag_fast;
@@ -232,10 +225,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
 #define PW_TG3(C, SK)                                                                                                    \
     do {                                                                                                                 \
         static unsigned long long attr_set = 0; /* bit = device */                                            \
-        if (lds_optin_needed(&attr_set)) {                                                                                \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_tag_kernel<C, SK>),        \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
+        PW_LDS_OPTIN(&attr_set, (pw_policy_rollout_tag_kernel<C, SK>)); \
         hipLaunchKernelGGL((pw_policy_rollout_tag_kernel<C, SK>), dim3(tgrid), dim3(512), tshm, tst, Q);                 \
     } while (0)
 #define PW_TG(C) case C: if (sink) PW_TG3(C, true); else PW_TG3(C, false); break;
@@ -243,6 +233,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
 #undef PW_TG3
 #undef PW_TG
         PW_HIP_CHECK(hipGetLastError());
+        h->last_kernel = "pw_policy_rollout_tag_kernel";
         return PW_OK;
     }
     PolicyRolloutArgs P;
@@ -306,10 +297,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
 #define PW_R24(C, NT, SK, BF)                                                                                            \
     do {                                                                                                                 \
         static unsigned long long attr_set3 = 0; /* bit = device */                                                      \
-        if (lds_optin_needed(&attr_set3)) {                                                                               \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout3_kernel<C, NT, SK, BF>),   \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
+        PW_LDS_OPTIN(&attr_set3, (pw_policy_rollout3_kernel<C, NT, SK, BF>)); \
         hipLaunchKernelGGL((pw_policy_rollout3_kernel<C, NT, SK, BF>), dim3(grid2), dim3(512), shm2, st, P);             \
     } while (0)
 #define PW_R23(C, NT, SK)                                                                                                \
@@ -319,10 +307,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
             break;                                                                                                       \
         }                                                                                                                \
         static unsigned long long attr_set = 0; /* bit = device */                                                       \
-        if (lds_optin_needed(&attr_set)) {                                                                                \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout2_kernel<C, NT, SK>),       \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
+        PW_LDS_OPTIN(&attr_set, (pw_policy_rollout2_kernel<C, NT, SK>)); \
         hipLaunchKernelGGL((pw_policy_rollout2_kernel<C, NT, SK>), dim3(grid2), dim3(512), shm2, st, P);                 \
     } while (0)
 #define PW_R22(C, NT) do { if (sink) PW_R23(C, NT, true); else PW_R23(C, NT, false); } while (0)
@@ -336,16 +321,14 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
 #undef PW_R22
 #undef PW_R2
         PW_HIP_CHECK(hipGetLastError());
+        h->last_kernel = use_v3 ? (a.bf16x3 ? "pw_policy_rollout3_kernel<bf16x3>" : "pw_policy_rollout3_kernel") : "pw_policy_rollout2_kernel";
         return PW_OK;
     }
     const unsigned grid = (unsigned)((kp.B + a.E - 1) / a.E);
 #define PW_PR3(C, NT, SK)                                                                                                \
     do {                                                                                                                 \
         static unsigned long long attr_set = 0; /* bit = device */                                            \
-        if (lds_optin_needed(&attr_set)) {                                                                                \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_policy_rollout_kernel<C, NT, SK>),        \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
+        PW_LDS_OPTIN(&attr_set, (pw_policy_rollout_kernel<C, NT, SK>)); \
         hipLaunchKernelGGL((pw_policy_rollout_kernel<C, NT, SK>), dim3(grid), dim3(512), shm, st, P);                    \
     } while (0)
 #define PW_PR2(C, NT) do { if (sink) PW_PR3(C, NT, true); else PW_PR3(C, NT, false); } while (0)
@@ -359,6 +342,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
 #undef PW_PR2
 #undef PW_PR
     PW_HIP_CHECK(hipGetLastError());
+    h->last_kernel = "pw_policy_rollout_kernel";
     return PW_OK;
 }
 
@@ -453,10 +437,7 @@ int pw_actor_front(const float *X, const float *frag, const float *b1, const flo
     static unsigned long long attr_set[9] = {};  // per kernel: bit = device
 #define PW_FRONT(C)                                                                                                      \
     case C:                                                                                                              \
-        if (lds_optin_needed(&attr_set[C])) { /* > 64 KB of dynamic LDS needs the opt-in */                              \
-            PW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pw_actor_front_kernel<C>),                   \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
-        }                                                                                                                \
+        PW_LDS_OPTIN(&attr_set[C], (pw_actor_front_kernel<C>)); \
         hipLaunchKernelGGL(pw_actor_front_kernel<C>, dim3((unsigned)tiles), dim3(256), shm, st, X, frag, b1, b_ih,       \
                            (long)rows, in_dim, G);                                                                       \
         break;
