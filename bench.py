@@ -43,6 +43,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s copy ceiling)
+STORE_CEILING_GBPS = 5500.0  # what a pure store stream reaches on this chip: 5.0-6.0 TB/s (tools/write_bw_probe.hip)
+F32_MFMA_PEAK_TFLOPS = 157.3  # same guide: exact-f32 MFMA (16x16x4 / 32x32x2) = 64 flop/clk/SIMD; 155 TF measured
+
+
+def actor_flops_per_env_step(N, D, n_out):
+    """The reference actor (rls/model/ac_network_multi_gumbel.py:52-67) on one env's N observation rows: dense1 D->64, the BiLSTM's
+    input projection 64->256 (2 directions x 4 gates x 32), its recurrence 2 x (32->128), the head 64->n_out; 2 flop per MAC."""
+    return 2 * N * (64 * D + 64 * 256 + 2 * 32 * 128 + 64 * n_out)
 STUB = bool(os.environ.get('PW_BENCH_STUB'))  # tests only: gloo + a no-op "kernel" (tests/test_bench_launcher.py)
 
 
@@ -90,10 +98,39 @@ def _cpu_worker(args):
     return cpu_baseline(seconds, n_agents)['value']
 
 
+def _cgroup_cpu_quota():
+    """CPUs this process's cgroup may use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        return None if q == 'max' else max(1, int(float(q) / float(per) + 0.999))
+    except Exception:
+        pass
+    try:
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        return None if q <= 0 else max(1, (q + per - 1) // per)
+    except Exception:
+        return None
+
+
 def _host_workers():
-    """Worker count for the all-core legs: every core this process may run on, capped at one GPU's share of
-    the box (16).  Both figures are reported (BASELINE.md section 3 asks for os.cpu_count())."""
-    return max(1, min(len(os.sched_getaffinity(0)), 16))
+    """Worker count for the all-core legs = the cores this process can really run on at once: its affinity mask, cut to the
+    cgroup's CPU quota where there is one, and to one GPU's share of the host (os.cpu_count() / 8 GPUs: 32 of 256 on the
+    MI355X box; the N = 1 line must not claim the cores of the other seven GPUs' jobs).  PW_BENCH_CPU_WORKERS overrides.
+    cores, os_cpu_count, the affinity and the quota are all reported."""
+    forced = os.environ.get('PW_BENCH_CPU_WORKERS')
+    if forced:
+        return max(1, int(forced))
+    n = len(os.sched_getaffinity(0))
+    quota = _cgroup_cpu_quota()
+    if quota:
+        n = min(n, quota)
+    return max(1, min(n, max(8, (os.cpu_count() or 8) // 8)))
+
+
+def _host_workers_note():
+    return dict(affinity=len(os.sched_getaffinity(0)), cgroup_quota=_cgroup_cpu_quota(), os_cpu_count=os.cpu_count(),
+                rule='min(affinity, cgroup CPU quota, os.cpu_count() / 8 GPUs)')
 
 
 def cpu_baseline_all_cores(seconds, n_agents):
@@ -265,6 +302,7 @@ def main():
             cpu_line['all_cores'] = cpu_baseline_all_cores(min(6.0, args.cpu_seconds), args.agents)
             cpu_line['c_oracle_f32_all_cores'] = c_oracle_all_cores(args.envs, args.agents)
         cpu_line['os_cpu_count'] = os.cpu_count()
+        cpu_line['all_cores_workers'] = _host_workers_note()
 
     import torch
     import torch.distributed as dist
@@ -514,9 +552,13 @@ def main():
                            exchanges=shard.exchanges, rows_ingested_root=shard.rows_ingested,
                            error=exchange_state['error']),
                        'outputs_finite': finite, 'timed_region_s': elapsed},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS,
+            # `bound` names what the kernel is measured to be limited by (profiles/*_summary.json SQ shares and the
+            # store-ceiling probe), `frac` stays on SURVEY 8(d)'s algorithmic bytes against the 8 TB/s peak (the contract)
+            'roofline': {'bound': 'latency' if B * N <= 65536 else 'valu-issue+store', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'priced_against': 'hbm',
                          'traffic': traffic, 'frac_by_traffic': frac_by_traffic,
+                         'frac_vs_store_ceiling': None if traffic is None else traffic / (launch_ms * 1e-3) / 1e9 / STORE_CEILING_GBPS,
+                         'store_ceiling_GBps': STORE_CEILING_GBPS,
                          'traffic_source': None if prof is None else
                          '%s: %.1f B/env-step (FETCH_SIZE + WRITE_SIZE passes of a %s-step launch) x %d env-steps'
                          % (prof['_file'], prof['traffic_bytes_per_env_step'],
@@ -529,7 +571,8 @@ def main():
                                     if B * N <= 65536 else 'mix of VALU issue and the HBM write path (DESIGN.md 4)',
                          'note': 'achieved = %d B (SURVEY 8(d) algorithmic bytes per env-step) x env-steps per launch / '
                                  'launch_ms; the T-step fused launch keeps state in registers, so counter traffic is BELOW '
-                                 'the algorithmic bytes' % env.bytes_per_env_step},
+                                 'the algorithmic bytes; frac_vs_store_ceiling = counter traffic (97 %% stores) against the '
+                                 '%.1f TB/s a pure store stream reaches' % (env.bytes_per_env_step, STORE_CEILING_GBPS / 1e3)},
         }
         if world == 1:
             line['cpu_baseline'] = cpu_line
@@ -559,6 +602,11 @@ def main():
     if rank == 0:
         line = line_holder['line']
         line['policy_in_loop'] = policy_line
+        # Compact (config -> value, frac) strings where a reader of a truncated record still finds them: short scalars inside
+        # `config` (records keep scalars of config / roofline and cut strings at ~120 characters) and once more as the LAST key
+        # of the line (a tail of the line keeps its end); the long arrays stay under other_configs / policy_in_loop.
+        summ = _compact_summary(line.get('other_configs'), policy_line)
+        line['config'].update(summ)
         if use_dist:
             # what matters at N > 1, at the top level of the line: the FULL gather's per-link rate and completeness
             # (north_star's collective, measured in the policy-in-the-loop extra) and the cost of the sampled exchange
@@ -577,6 +625,7 @@ def main():
                                       error=exchange_state['error']),
                 note='value = sharded rollout + sampled exchange (a full gather at this rate would need TB/s per peer: '
                      'DESIGN.md 6); the full gather is measured with the policy in the loop')
+        line['other_configs_summary'] = summ
         print(json.dumps(line, allow_nan=False), flush=True)
     if isinstance(policy_line, dict) and policy_line.get('fatal'):
         # the extra raised on THIS rank: its peers are inside collectives it will not join -- leave, loudly, once the root's
@@ -603,6 +652,38 @@ def main():
             sys.stdout.flush()
             os._exit(3)
         bye.cancel()
+
+
+def _compact_summary(other, policy):
+    """-> dict of two strings of at most ~120 characters: 'other_configs_frac' (label value frac | ...) and
+    'policy_in_loop_frac' (label value mfma-frac | ...)."""
+    def short(name):
+        for key, lab in (('simple_tag', 'C3'), ('N=3,', 'N3'), ('N=12', 'N12'), ('N=24', 'N24'), ('N=48', 'N48'), ('B=65536', 'B64k'),
+                         ('simple_reference', 'ref')):
+            if key in name:
+                return lab
+        return name[:6]
+    out = {}
+    if isinstance(other, list):
+        out['other_configs_frac'] = '|'.join('%s %.2g %.2f' % (short(o['config']), o['value'], o['frac']) for o in other
+                                             if isinstance(o, dict) and 'frac' in o)[:120]
+    elif isinstance(other, dict) and other.get('error'):
+        out['other_configs_frac'] = 'error: ' + other['error'][:100]
+    if isinstance(policy, dict) and policy.get('value'):
+        parts = []
+        rf = policy.get('roofline') or {}
+        parts.append('C2 %.3g mfma %.2f' % (policy['value'], rf.get('frac', float('nan'))) if rf else 'C2 %.3g' % policy['value'])
+        for o in policy.get('other_scenarios') or []:
+            if 'value' in o:
+                parts.append('%s %.3g %.2f' % (short(o['config']), o['value'], (o.get('roofline') or {}).get('frac', float('nan'))))
+        b = policy.get('bf16x3_input_projection') or {}
+        if b.get('value'):
+            parts.append('bf16x3(inexact) %.3g' % b['value'])
+        g = policy.get('gather') or {}
+        if g.get('GBps_per_link') is not None:
+            parts.append('gather %.0f GB/s/link %d B/env-step' % (g['GBps_per_link'], g.get('bytes_per_env_step', 0)))
+        out['policy_in_loop_frac'] = '|'.join(parts).replace('nan', '-')[:120]
+    return out
 
 
 # The other BASELINE.json configurations, each at the longest launch its outputs allow: (label, scenario, B, kwargs, T)
@@ -705,58 +786,89 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
     label = 'FusedActor (reference ActorNetwork: Linear-BiLSTM-Linear, random init) + Gumbel sampling'
 
     if not use_dist:
+        def timed_collect(ro, chunks):
+            """One warm-up chunk, then `chunks` chunks bracketed by a HIP-event pair on the launch stream (torch's current
+            stream is the one every launch of BatchedRollout goes to) and by the host clock."""
+            ro.collect_one_launch(Tp, chunk=Tp)
+            sync()
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            t = time.perf_counter()
+            ev[0].record()
+            ro.collect_one_launch(chunks * Tp, chunk=Tp)
+            ev[1].record()
+            sync()
+            return time.perf_counter() - t, ev[0].elapsed_time(ev[1]) * 1e-3
+
+        def mfma_roofline(env, n_out, seconds, steps, launches):
+            """The actor's dense products are the path's flops (north_star reserves MFMA for them): algorithmic flops per env-step
+            x env-steps per launch / the HIP-event launch time, against the exact-f32 matrix peak."""
+            fl = actor_flops_per_env_step(env.n, env.obs_dim, n_out)
+            per_launch = float(fl) * env.num_envs * steps / launches
+            launch_s = seconds / launches
+            ach = per_launch / launch_s / 1e12
+            return dict(bound='mfma_f32', achieved=ach, peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F32_MFMA_PEAK_TFLOPS,
+                        flops_per_env_step=fl, algorithmic_flops_per_launch=per_launch, launch_ms=launch_s * 1e3,
+                        kernel=env.last_kernel(), env_steps_per_launch=env.num_envs * steps // launches,
+                        note='2 N (64 D + 64x256 + 2x32x128 + 64 n_out) flop per env-step (rls/model/ac_network_multi_gumbel.py:52-67), '
+                             'exact f32 on v_mfma_f32_16x16x4_f32; the environment step, sampling and ring append ride in the same launch')
+
         ro = BatchedRollout(penv, actor, ReplayBuffer(1e6, N, penv.obs_dim))
-        ro.collect_one_launch(Tp, chunk=Tp)
-        sync()
-        tp = time.perf_counter()
-        ro.collect_one_launch(n_chunks * Tp, chunk=Tp)
-        sync()
-        tp = time.perf_counter() - tp
+        tp, tp_ev = timed_collect(ro, n_chunks)
         line = dict(value=B * n_chunks * Tp / tp, unit='env-steps/s', us_per_step=tp / (n_chunks * Tp) * 1e6,
-                    steps=n_chunks * Tp, policy=label,
+                    steps=n_chunks * Tp, policy=label, actor_precision=penv.get_actor_precision(),
+                    exact=penv.get_actor_precision() == 'f32',
                     loop='%d-step chunks, one launch each: pw_policy_rollout (actor + sampling + env step + device '
-                         'replay append + episode stats)' % Tp)
+                         'replay append + episode stats)' % Tp,
+                    roofline=mfma_roofline(penv, 5, tp_ev, n_chunks * Tp, n_chunks))
+        # every further figure is an extra of this extra: one that fails is recorded under its own key, the figure above stays
         # the per-step form: actor, env step, replay append + bookkeeping = 3 launches per step in a hipGraph
-        ro.capture(2)
-        ro.collect(50)
-        sync()
-        tg = time.perf_counter()
-        ro.collect(500)
-        sync()
-        tg = time.perf_counter() - tg
-        line['three_launches_per_step_hipgraph'] = dict(value=B * 500 / tg, us_per_step=tg / 500 * 1e6)
-        # labelled extra, never the figure above: the OPT-IN, NOT exact actor mode (LSTM input projection on bfloat16 matrix
-        # instructions, three products per k step -- pw_set_actor_precision in include/pworld.h) on a fresh env + ring
-        benv = BatchedParticleEnv('simple_spread', B, num_agents=N, max_episode_len=25, auto_reset=True,
-                                  seed=12345678, env_id_base=rank * B)
-        benv.set_actor_precision('bf16x3')
-        rb = BatchedRollout(benv, actor, ReplayBuffer(1e6, N, benv.obs_dim))
-        rb.collect_one_launch(Tp, chunk=Tp)
-        sync()
-        tb = time.perf_counter()
-        rb.collect_one_launch(n_chunks * Tp, chunk=Tp)
-        sync()
-        tb = time.perf_counter() - tb
+        try:
+            ro.capture(2)
+            ro.collect(50)
+            sync()
+            tg = time.perf_counter()
+            ro.collect(500)
+            sync()
+            tg = time.perf_counter() - tg
+            line['three_launches_per_step_hipgraph'] = dict(value=B * 500 / tg, us_per_step=tg / 500 * 1e6)
+        except Exception as e:
+            line['three_launches_per_step_hipgraph'] = dict(error=repr(e)[:200])
         # the other scenarios of the reference's sweep with their actors in the loop (same one-launch form, ring append included)
         others = []
-        tenv = BatchedParticleEnv('simple_tag', 8192, num_adversaries=4, num_good=2, max_episode_len=25, auto_reset=True, seed=1)
-        tro = BatchedRollout(tenv, FusedActor(ActorNetwork(tenv.obs_dim, 5).to(dev).eval(), seed=2), ReplayBuffer(1e6, tenv.n, tenv.obs_dim))
-        renv = BatchedParticleEnv('simple_reference', B, max_episode_len=25, auto_reset=True, seed=3)
-        rro = BatchedRollout(renv, FusedActor(ActorNetwork(renv.obs_dim, [5, 10]).to(dev).eval(), seed=7),
-                             ReplayBuffer(int(8e6), 2, renv.obs_dim, act_heads=(5, 10)))
-        for name, o_env, o_ro in (('simple_tag 4+2, B=8192', tenv, tro), ('simple_reference (two-head actor [5|10]), B=%d' % B, renv, rro)):
-            o_ro.collect_one_launch(Tp, chunk=Tp)
-            sync()
-            to = time.perf_counter()
-            o_ro.collect_one_launch(5 * Tp, chunk=Tp)
-            sync()
-            to = time.perf_counter() - to
-            others.append(dict(config=name, value=o_env.num_envs * 5 * Tp / to, unit='env-steps/s', us_per_step=to / (5 * Tp) * 1e6))
+        for name, mk_env, heads, cap in (
+                ('simple_tag 4+2, B=8192',
+                 lambda: BatchedParticleEnv('simple_tag', 8192, num_adversaries=4, num_good=2, max_episode_len=25, auto_reset=True, seed=1), 5, 1e6),
+                ('simple_reference (two-head actor [5|10]), B=%d' % B,
+                 lambda: BatchedParticleEnv('simple_reference', B, max_episode_len=25, auto_reset=True, seed=3), [5, 10], 8e6)):
+            try:
+                o_env = mk_env()
+                o_env.set_actor_precision('f32')     # whatever the process environment says: these rollouts serve float32 only
+                two = isinstance(heads, list)
+                o_ro = BatchedRollout(o_env, FusedActor(ActorNetwork(o_env.obs_dim, heads).to(dev).eval(), seed=2 if not two else 7),
+                                      ReplayBuffer(int(cap), o_env.n, o_env.obs_dim, **(dict(act_heads=(5, 10)) if two else {})))
+                to, to_ev = timed_collect(o_ro, 5)
+                others.append(dict(config=name, value=o_env.num_envs * 5 * Tp / to, unit='env-steps/s', us_per_step=to / (5 * Tp) * 1e6,
+                                   roofline=mfma_roofline(o_env, sum(heads) if two else heads, to_ev, 5 * Tp, 5)))
+                del o_ro, o_env
+            except Exception as e:
+                others.append(dict(config=name, error=repr(e)[:200]))
         line['other_scenarios'] = others
-        line['bf16x3_input_projection'] = dict(value=B * n_chunks * Tp / tb, us_per_step=tb / (n_chunks * Tp) * 1e6, exact=False,
-                                               note='opt-in (PW_ACTOR_BF16X3=1 / pw_set_actor_precision), within 2e-5 of the '
-                                                    'float32 logits, does not reproduce the exact form\'s sampled actions; '
-                                                    'never the default, never the headline')
+        # labelled extra, never the figure above: the OPT-IN, NOT exact actor mode (LSTM input projection on bfloat16 matrix
+        # instructions, three products per k step -- pw_set_actor_precision in include/pworld.h) on a fresh env + ring;
+        # served by the third kernel form only (N <= 16 at 8+ environments per workgroup): skipped, not failed, elsewhere
+        try:
+            benv = BatchedParticleEnv('simple_spread', B, num_agents=N, max_episode_len=25, auto_reset=True,
+                                      seed=12345678, env_id_base=rank * B)
+            benv.set_actor_precision('bf16x3')
+            rb = BatchedRollout(benv, actor, ReplayBuffer(1e6, N, benv.obs_dim))
+            tb, _ = timed_collect(rb, n_chunks)
+            line['bf16x3_input_projection'] = dict(value=B * n_chunks * Tp / tb, us_per_step=tb / (n_chunks * Tp) * 1e6, exact=False,
+                                                   kernel=benv.last_kernel(),
+                                                   note='opt-in (pw_set_actor_precision), within 2e-5 of the float32 logits, does '
+                                                        'not reproduce the exact form\'s sampled actions; never the default, never '
+                                                        'the headline')
+        except Exception as e:
+            line['bf16x3_input_projection'] = dict(skipped=repr(e)[:200], exact=False)
         return line
 
     if stub_env is None:

@@ -203,7 +203,8 @@ int pw_get_dispatch(const pw_handle *h, pw_dispatch *out);
  * LSTM input projection runs on bfloat16 matrix instructions with both operands split in high and low halves, three products per k
  * step, float32 accumulation; dense1, the recurrence and the head stay float32.  Within the 2e-5 bound of the PyTorch float32
  * comparison on the reference's weights (tests/test_gpu_engine.py), but sampled actions can differ from the exact form's.
- * PW_ACTOR_BF16X3=1 in the environment of the creating process selects it at pw_create; never a default, never a headline figure.
+ * Selected by this call only (no environment variable changes results: a process-wide switch would silently turn every "exact"
+ * rollout of the process into this mode); never a default, never a headline figure.
  * Served by the simple_spread rollout in its third kernel form and by pw_actor_fused at N <= 16; anything else returns PW_EINVAL
  * rather than run in float32 unannounced.
  * pw_actor_set_bf16x3: the same switch for the handle-less pw_actor_fused (process-wide, off until set; N <= 16 only). */

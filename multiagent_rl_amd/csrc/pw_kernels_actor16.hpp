@@ -12,7 +12,7 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------
-// Opt-in, NOT exact (ActorFusedArgs.bf16x3; pw_set_actor_precision / PW_ACTOR_BF16X3=1; never the default, never a headline):
+// Opt-in, NOT exact (ActorFusedArgs.bf16x3; pw_set_actor_precision; never the default, never a headline):
 // the input projection W_ih * x1 -- two thirds of the pass's matrix time -- on v_mfma_f32_16x16x16_bf16 with both operands split
 // into bfloat16 high and low parts and three products per k step (lo*hi + hi*lo + hi*hi, f32 accumulate; the lo*lo term and the
 // parts' rounding are ~2^-16 relative).  dense1, the recurrence and the head stay exact f32.  tests/test_gpu_engine.py holds the

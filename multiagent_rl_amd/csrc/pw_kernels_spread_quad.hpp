@@ -55,8 +55,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
     float *s_min = reinterpret_cast<float *>(s_ftab + 2 * EPP * N * N);    // [64] OA
     float *s_rew = s_min + kWave;                                          // [64] OA
     float2 *s_lmB = reinterpret_cast<float2 *>(s_rew + kWave);             // [8 * 6] OB (16-byte aligned)
-    float4 *s_rowB = reinterpret_cast<float4 *>(s_lmB + EPW * L);          // [64] (unused since round 3: OB reads the ring slot itself)
-    int32_t *s_act = reinterpret_cast<int32_t *>(s_rowB + kWave);          // [2 P waves][4 steps][64] action indices
+    int32_t *s_act = reinterpret_cast<int32_t *>(s_lmB + EPW * L);         // [2 P waves][4 steps][64] action indices
     float2 *s_utab = reinterpret_cast<float2 *>(s_act + 2 * 4 * kWave);    // [2 P waves][8] action force per index
 
     // Roles by wave index, swapped in every other batch of 256 workgroups: the hardware places a workgroup's waves 0..3 on

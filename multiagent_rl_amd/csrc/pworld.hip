@@ -203,8 +203,7 @@ void dispatch_defaults(pw_dispatch *d)
 void dispatch_from_environment(pw_dispatch *d, int *actor_bf16x3)
 {
     dispatch_defaults(d);
-    *actor_bf16x3 = 0;  // not a selection (it changes results): kept beside the dispatch, set by pw_set_actor_precision
-    if (const char *e = std::getenv("PW_ACTOR_BF16X3")) *actor_bf16x3 = std::atoi(e) != 0;
+    *actor_bf16x3 = 0;  // not a selection (it changes results): no environment variable reaches it, only pw_set_actor_precision
     if (std::getenv("PWORLD_FORCE_GENERIC")) d->force_generic = 1;
     if (std::getenv("PWORLD_NO_STREAM")) d->no_stream = 1;
     if (std::getenv("PWORLD_FORCE_DUO")) d->duo = 1;
@@ -383,7 +382,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
             if (dp.quad >= 0) quad = quad_ok && dp.quad != 0;
             if (quad) {
                 const size_t qshm = 4 * kWave * sizeof(float4) + 2 * 4 * 6 * 6 * sizeof(float2) + 2 * kWave * sizeof(float) +
-                                    8 * 6 * sizeof(float2) + kWave * sizeof(float4) + 2 * kActRingBytes + 2 * 8 * sizeof(float2);
+                                    8 * 6 * sizeof(float2) + 2 * kActRingBytes + 2 * 8 * sizeof(float2);
                 const bool k1 = h->fc.k1 != 0;  // the canonical margin 1e-3 qualifies
                 if (wc && k1) PW_LAUNCH(h, (pw_spread_quad_kernel<true, true, true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
                 else if (wc) PW_LAUNCH(h, (pw_spread_quad_kernel<true, true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);

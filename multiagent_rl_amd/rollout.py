@@ -51,6 +51,133 @@ def _action_heads(env, action_type):
     return (int(space.n),) if hasattr(space, 'n') else None
 
 
+class EpisodeLedger(object):
+    """Reward accounting of the rollout loops.  ``totals[k]`` = summed reward of episode k over all agents, ``by_agent[i][k]`` the
+    share of agent i; the last entry is the episode in progress (which is why a finished run's history ends with a 0, as the
+    reference's does: run.py:62-65,96).  ``report()`` closes a window of ``window`` episodes (run.py:84-93)."""
+
+    def __init__(self, num_agents, window):
+        self.window = int(window)
+        self.totals = [0.0]
+        self.by_agent = [[0.0] for _ in range(num_agents)]
+        self.window_means, self.window_agent_means = [], []
+
+    @property
+    def episodes(self):
+        return len(self.totals)
+
+    def credit(self, rew_n):
+        for i, r in enumerate(rew_n):
+            self.totals[-1] += r
+            self.by_agent[i][-1] += r
+
+    def open_next(self):
+        self.totals.append(0)
+        for track in self.by_agent:
+            track.append(0)
+
+    def window_full(self):
+        return self.episodes % self.window == 0
+
+    def report(self):
+        mean = np.mean(self.totals[-self.window:])
+        self.window_means.append(mean)
+        for track in self.by_agent:
+            self.window_agent_means.append(np.mean(track[-self.window:]))
+        return mean
+
+    def history(self):
+        """The dict the reference pickles (run.py:96-100); experiments/reward_plot.py:35-50 reads these two keys."""
+        return {'reward_episodes': self.totals, 'reward_episodes_by_agents': self.by_agent}
+
+
+class LearnGate(object):
+    """When the learner runs: every ``update_rate`` env steps once more than ``warmup_steps`` have been taken, while
+    ``is_training`` (run.py:78-81).  ``due(step)`` is the host loop's per-step test; ``due_between(a, b)`` counts the gate's
+    openings inside a chunk of env steps (a, b] for the batched engine, which advances many steps per launch."""
+
+    def __init__(self, cfg):
+        self.warmup, self.rate, self.cfg = int(cfg.warmup_steps), int(cfg.update_rate), cfg
+
+    def due(self, train_step):
+        return train_step > self.warmup and train_step % self.rate == 0 and self.cfg.is_training
+
+    def due_between(self, before, after):
+        if not self.cfg.is_training:
+            return 0
+        lo = max(before, self.warmup)
+        return max(0, after // self.rate - lo // self.rate)
+
+
+def write_history(hist, out_dir, scenario_name, cnt, evaluate=False):
+    """``Models/history_<scenario>_<cnt>.pkl`` (run.py:96-100) / ``test_history_...`` (run.py:193-195)."""
+    if out_dir is None:
+        return None
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, ('test_history_' if evaluate else 'history_') + scenario_name + '_' + str(cnt) + '.pkl')
+    with open(path, 'wb') as fp:
+        pickle.dump(hist, fp)
+    return path
+
+
+class _HostSession(object):
+    """One run()/run_test() call on a B = 1 env: the order of calls on ``env`` and the learner is the contract
+    (tests/golden/run_trace.json, run_test_trace.json, run_multidiscrete_trace.json were recorded from the reference's loop)."""
+
+    def __init__(self, env, learner, cfg, action_type, per_agent_transition, evaluate, log):
+        self.env, self.learner, self.cfg, self.log = env, learner, cfg, log
+        self.multi = action_type == 'MultiDiscrete'
+        self.per_agent, self.evaluate = per_agent_transition, evaluate
+        self.ledger = EpisodeLedger(env.n, 10 if evaluate else cfg.save_rate)
+        self.gate = LearnGate(cfg)
+        self.steps = self.episode_step = 0
+
+    def _act(self, obs_n):
+        """Learner output -> what env.step takes: list[N] of float64 one-hot rows (run.py:37-41)."""
+        out = self.learner.get_exploration_action(obs_n)
+        if self.multi:      # one array per head; an agent's action is the concatenation of its heads' one-hots
+            return [np.concatenate(pair, axis=-1) for pair in zip(out[0][0], out[1][0])]
+        return [np.array(row) for row in out[0].tolist()]
+
+    def _store(self, obs_n, action_n_env, rew_n, new_obs_n, done_n):
+        if self.per_agent:  # BiCNet tuple, run_BIC.py:46,50
+            self.learner.memory.add(obs_n, action_n_env, rew_n, new_obs_n, [float(d) for d in done_n])
+        else:               # run.py:46,49,52
+            self.learner.memory.add(obs_n, action_n_env, np.sum(rew_n), new_obs_n, float(all(done_n)))
+
+    def play(self):
+        env, cfg, led = self.env, self.cfg, self.ledger
+        obs_n = env.reset()
+        clock = time.time()
+        self.log('Starting iterations...')
+        while led.episodes <= cfg.num_episodes:
+            action_n_env = self._act(obs_n)
+            new_obs_n, rew_n, done_n, _ = env.step(action_n_env)
+            self.episode_step += 1
+            self.steps += 1
+            over = self.episode_step >= cfg.max_episode_len     # run.py:50 "terminal"
+            self._store(obs_n, action_n_env, rew_n, new_obs_n, done_n)
+            led.credit(rew_n)
+            if over or all(done_n):
+                obs_n, self.episode_step = env.reset(), 0
+                led.open_next()
+            else:
+                obs_n = new_obs_n
+            if cfg.display:                                      # run.py:70-74: rendering skips learning and reports
+                time.sleep(0.1)
+                env.render()
+                continue
+            if self.gate.due(self.steps):
+                self.learner.optimize()
+            if over and led.window_full():
+                mean = led.report()
+                self.log('steps: {}, episodes: {}, mean episode reward: {}, time: {}'.format(
+                    self.steps, led.episodes, mean, round(time.time() - clock, 3)))
+                clock = time.time()
+        self.log('...Finished total of {} episodes.'.format(led.episodes))
+        return led.history()
+
+
 def _loop(env, actor, critic, Trainer, scenario_name, action_type, cnt, arglist, memory, out_dir, log,
           evaluate, per_agent_transition):
     cfg = _default_arglist if arglist is None else arglist
@@ -62,70 +189,16 @@ def _loop(env, actor, critic, Trainer, scenario_name, action_type, cnt, arglist,
         from .replay_buffer import ReplayBuffer
         memory = ReplayBuffer(size=1e+6, act_heads=_action_heads(env, action_type), per_agent=per_agent_transition)
     learner = Trainer(actor, critic, memory, action_type=action_type)
+    model_name = scenario_name + '_fin_' + str(cnt)
     if evaluate:
-        learner.load_models(getattr(cfg, 'appx', '') + scenario_name + '_fin_' + str(cnt))
-    report_every = 10 if evaluate else cfg.save_rate
-
-    episode_rewards = [0.0]
-    agent_rewards = [[0.0] for _ in range(env.n)]
-    final_ep_rewards, final_ep_ag_rewards = [], []
-    obs_n = env.reset()
-    episode_step = train_step = 0
-    t_start = time.time()
-    log('Starting iterations...')
-    while True:
-        if action_type == 'Discrete':
-            action_n = learner.get_exploration_action(obs_n)[0]
-            action_n_env = [np.array(row) for row in action_n.tolist()]
-        else:  # MultiDiscrete (run.py:39-41): one array per head; each agent's action is their concatenation
-            action_n = learner.get_exploration_action(obs_n)
-            action_n_env = [np.concatenate([u, c], axis=-1) for u, c in zip(action_n[0][0], action_n[1][0])]
-        new_obs_n, rew_n, done_n, info_n = env.step(action_n_env)
-        episode_step += 1
-        done = all(done_n)
-        terminal = episode_step >= cfg.max_episode_len
-        if per_agent_transition:
-            learner.memory.add(obs_n, action_n_env, rew_n, new_obs_n, [float(d) for d in done_n])
-        else:
-            learner.memory.add(obs_n, action_n_env, np.sum(rew_n), new_obs_n, float(done))
-        obs_n = new_obs_n
-        for i, rew in enumerate(rew_n):
-            episode_rewards[-1] += rew
-            agent_rewards[i][-1] += rew
-        if done or terminal:
-            obs_n = env.reset()
-            episode_step = 0
-            episode_rewards.append(0)
-            for track in agent_rewards:
-                track.append(0)
-        train_step += 1
-        if cfg.display:
-            time.sleep(0.1)
-            env.render()
-            continue
-        if train_step > cfg.warmup_steps and train_step % cfg.update_rate == 0 and cfg.is_training:
-            learner.optimize()
-        if terminal and len(episode_rewards) % report_every == 0:
-            log('steps: {}, episodes: {}, mean episode reward: {}, time: {}'.format(
-                train_step, len(episode_rewards), np.mean(episode_rewards[-report_every:]),
-                round(time.time() - t_start, 3)))
-            t_start = time.time()
-            final_ep_rewards.append(np.mean(episode_rewards[-report_every:]))
-            for track in agent_rewards:
-                final_ep_ag_rewards.append(np.mean(track[-report_every:]))
-        if len(episode_rewards) > cfg.num_episodes:
-            hist = {'reward_episodes': episode_rewards, 'reward_episodes_by_agents': agent_rewards}
-            if evaluate:
-                hist['memory'] = memory
-            if out_dir is not None:
-                os.makedirs(out_dir, exist_ok=True)
-                name = ('test_history_' if evaluate else 'history_') + scenario_name + '_' + str(cnt) + '.pkl'
-                with open(os.path.join(out_dir, name), 'wb') as fp:
-                    pickle.dump(hist, fp)
-            log('...Finished total of {} episodes.'.format(len(episode_rewards)))
-            if not evaluate:
-                learner.save_models(scenario_name + '_fin_' + str(cnt))
-            return hist
+        learner.load_models(getattr(cfg, 'appx', '') + model_name)
+    hist = _HostSession(env, learner, cfg, action_type, per_agent_transition, evaluate, log).play()
+    if evaluate:
+        hist['memory'] = memory
+    write_history(hist, out_dir, scenario_name, cnt, evaluate)
+    if not evaluate:
+        learner.save_models(model_name)
+    return hist
 
 
 class BatchedRollout(object):
