@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define PW_VERSION 104 /* 0.1.4: + pw_set_actor_precision / pw_actor_set_bf16x3 (opt-in bf16x3 input projection); pw_actor_front_pack's
+#define PW_VERSION 105 /* 0.1.5: + pw_state_wire_* / pw_replay_add_state_wire (state-only wire blocks); PW_ACTOR_BF16X3 environment switch removed; 0.1.4: + pw_set_actor_precision / pw_actor_set_bf16x3 (opt-in bf16x3 input projection); pw_actor_front_pack's
                           image grew a third section.  0.1.3: + pw_dispatch (kernel selection frozen in the handle; no environment reads at launch)
                           (0.1.2: + pw_rollout_kernel; 0.1.1: pw_replay_store grew act_heads / per_agent / head_width; wire-block entry points) */
 #define PW_MAX_AGENTS 64
@@ -324,6 +324,45 @@ int pw_chunk_wire_finalize(const pw_chunk_wire *w, void *wire, const float *obs0
  * (start + t*B + e) % capacity -- the order T pw_replay_add calls would have used -- bit-identical to
  * pw_replay_add_rollout on the sender's buffers.  One launch. */
 int pw_replay_add_wire(const pw_replay_store *st, int64_t start, const pw_chunk_wire *w, const void *wire, void *stream);
+
+/* ---- the same gather on a diet: STATE-ONLY wire blocks (simple_spread, local observation) ---------------------------
+ * A local observation row is a pure function of the agent's {vel, pos} and the episode's landmarks
+ * (experiments/scenarios.py:6-20: [p_vel, p_pos, landmark.p_pos - p_pos ...]); each entry is ONE float32 operation, so the
+ * root can rebuild obs / next_obs rows bit for bit from 16 bytes per agent instead of receiving 4 + 2L floats per agent
+ * (C2: 384 B of the 395 B per env-step of the row block above).  Planes, 256-B aligned:
+ *   state0 [B,N] float4 {vx, vy, px, py}      the state the policy acted on at step 0 (written by pw_state_wire_begin)
+ *   state [T,B,N] float4                      post-step (post-reset) state = columns 0..3 of the rollout's obs rows
+ *   final_state [F,B,N] float4                pre-reset state of env e's k-th episode end inside the chunk
+ *   lm [(F+1),B,L] float2                     landmarks of the episode in progress at step 0 (k = 0, copied from the state
+ *                                             block by pw_state_wire_begin) and after the k-th reset (k >= 1: re-derived by
+ *                                             pw_state_wire_finalize from the reset's Philox key (seed, global env id,
+ *                                             episode number) -- the in-kernel auto-reset draws exactly these)
+ *   ep0 [B] u32                               episode number of every env at step 0 (pw_state_wire_begin; sender-side only,
+ *                                             it travels with the block and lets the root audit the landmark planes)
+ *   rew_shared [T,B] f32                      written in place by the rollout
+ *   act [T,B,N] u8
+ *   epi [T,B] u8                              bits 0..6: k = episode ends of env e before step t (which lm / final_state
+ *                                             plane applies), bit 7: step (t, e) ended an episode
+ * = 17N + 5 bytes per env-step + (1 + F) state and landmark batches per chunk (C2, T = 100: 107 + 7 = 114 B per
+ * env-step, 28 % of the row block's 414).
+ * Sender:  pw_state_wire_begin (BEFORE the chunk's rollout launch, same stream)  ->  rollout with rew_shared pointing into
+ * the block  ->  pw_state_wire_finalize.  Root: pw_replay_add_state_wire = ReplayBuffer.add() of the block's T*B transitions,
+ * bit-identical to pw_replay_add_rollout on the sender's buffers (tests/test_gpu_engine.py). */
+typedef struct pw_state_wire {
+    int32_t T, B, N, L, D, F;
+    size_t state0, state, final_state, lm, ep0, rew_shared, act, epi; /* byte offsets into the block */
+    size_t total_bytes;
+} pw_state_wire;
+/* Host arithmetic only (as pw_chunk_wire_layout).  begin / finalize return PW_EINVAL unless h is a simple_spread handle with the
+ * local observation (D = 4 + 2L) of the block's B, N, L. */
+int pw_state_wire_layout(int32_t T, int32_t B, int32_t N, int32_t L, int32_t max_episode_len, pw_state_wire *out);
+int pw_state_wire_begin(const pw_handle *h, const pw_state_wire *w, void *wire, void *stream);
+/* obs [T,B,N,D] and final_obs [T,B,N,D] (may be NULL when F = 0) are the rollout's outputs, terminal [T,B], act [T,B,N]
+ * int32.  One launch. */
+int pw_state_wire_finalize(const pw_handle *h, const pw_state_wire *w, void *wire, const float *obs, const float *final_obs,
+                           const uint8_t *terminal, const int32_t *act, void *stream);
+/* Root; needs no handle: the rebuild is the observation's own arithmetic on the block's data.  One launch. */
+int pw_replay_add_state_wire(const pw_replay_store *st, int64_t start, const pw_state_wire *w, const void *wire, void *stream);
 
 /* Episode bookkeeping of the rollout loop (experiments/run.py:55-65) over B envs in one launch:
  * episode_return[b] += rew_shared[b]; where terminal[b]: *finished_sum += return (double),

@@ -69,6 +69,11 @@ class PwChunkWire(C.Structure):
                [(n, C.c_size_t) for n in ('obs0', 'obs', 'final_rows', 'rew_shared', 'act', 'fin_slot', 'total_bytes')]
 
 
+class PwStateWire(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('T', 'B', 'N', 'L', 'D', 'F')] + \
+               [(n, C.c_size_t) for n in ('state0', 'state', 'final_state', 'lm', 'ep0', 'rew_shared', 'act', 'epi', 'total_bytes')]
+
+
 # name -> (restype, argtypes): every symbol include/pworld.h declares
 SIGNATURES = {
     'pw_version': (C.c_int, []),
@@ -109,6 +114,10 @@ SIGNATURES = {
     'pw_chunk_wire_layout': (C.c_int, [C.c_int32] * 5 + [C.POINTER(PwChunkWire)]),
     'pw_chunk_wire_finalize': (C.c_int, [C.POINTER(PwChunkWire)] + [C.c_void_p] * 6),
     'pw_replay_add_wire': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.POINTER(PwChunkWire), C.c_void_p, C.c_void_p]),
+    'pw_state_wire_layout': (C.c_int, [C.c_int32] * 5 + [C.POINTER(PwStateWire)]),
+    'pw_state_wire_begin': (C.c_int, [C.c_void_p, C.POINTER(PwStateWire), C.c_void_p, C.c_void_p]),
+    'pw_state_wire_finalize': (C.c_int, [C.c_void_p, C.POINTER(PwStateWire)] + [C.c_void_p] * 6),
+    'pw_replay_add_state_wire': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.POINTER(PwStateWire), C.c_void_p, C.c_void_p]),
     'pw_dense': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                           C.c_void_p]),
     'pw_actor_front_pack_floats': (C.c_size_t, [C.c_int32]),

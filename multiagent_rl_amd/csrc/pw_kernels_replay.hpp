@@ -424,4 +424,150 @@ __global__ void __launch_bounds__(256) pw_replay_add_wire_kernel(const pw_replay
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// State-only wire block (include/pworld.h, pw_state_wire): simple_spread with the local observation.  The row of agent
+// a is {vx, vy, px, py, lm_0 - p, lm_1 - p, ...} (stream_write_obs in pw_kernels_spread.hpp; experiments/scenarios.py:6-20):
+// columns 0..3 ARE the state, every other column is one float32 subtraction of two numbers the block carries.
+// ------------------------------------------------------------------------------------------
+struct StateWirePtrs {
+    float4 *state0, *state, *final_state;
+    float2 *lm;
+    uint32_t *ep0;
+    float *rew_shared;
+    uint8_t *act, *epi;
+};
+__host__ __device__ inline StateWirePtrs state_wire_ptrs(const pw_state_wire &w, void *wire)
+{
+    unsigned char *b = static_cast<unsigned char *>(wire);
+    StateWirePtrs p;
+    p.state0 = reinterpret_cast<float4 *>(b + w.state0);
+    p.state = reinterpret_cast<float4 *>(b + w.state);
+    p.final_state = reinterpret_cast<float4 *>(b + w.final_state);
+    p.lm = reinterpret_cast<float2 *>(b + w.lm);
+    p.ep0 = reinterpret_cast<uint32_t *>(b + w.ep0);
+    p.rew_shared = reinterpret_cast<float *>(b + w.rew_shared);
+    p.act = b + w.act;
+    p.epi = b + w.epi;
+    return p;
+}
+
+// Before the chunk's rollout: what the chunk starts from, read from the bound state planes (SoA over g = env * N + agent).
+__global__ void __launch_bounds__(256) pw_state_wire_begin_kernel(const pw_state_wire w, void *wire, const float *pos_x,
+                                                                  const float *pos_y, const float *vel_x, const float *vel_y,
+                                                                  const float *lm_x, const float *lm_y, const uint32_t *ep_count)
+{
+    const StateWirePtrs p = state_wire_ptrs(w, wire);
+    const size_t BN = (size_t)w.B * w.N, BL = (size_t)w.B * w.L;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < BN) p.state0[i] = make_float4(vel_x[i], vel_y[i], pos_x[i], pos_y[i]);
+    if (i < BL) p.lm[i] = make_float2(lm_x[i], lm_y[i]);
+    if (i < (size_t)w.B) p.ep0[i] = ep_count[i];
+}
+
+// After the chunk's rollout.  Workgroups [0, copy_blocks): columns 0..3 of every observation row -> state (grid-stride).
+// Workgroups [copy_blocks, copy_blocks + env_blocks): thread = (env, agent) walks the env's T terminal flags: the k-th
+// episode end's pre-reset state goes to final_state[k], the landmarks the reset drew (Philox key: seed, global env id,
+// episode number ep0 + k + 1, entity N + l: reset_lane in pw_common.hpp) to lm[k + 1], and agent 0 writes the step's
+// epi byte.  The remaining workgroups narrow the int32 action indices to bytes.
+__global__ void __launch_bounds__(256) pw_state_wire_finalize_kernel(const pw_state_wire w, void *wire, const float *obs,
+                                                                     const float *final_obs, const uint8_t *terminal,
+                                                                     const int32_t *act, const uint64_t seed,
+                                                                     const uint64_t env_id_base, const unsigned copy_blocks,
+                                                                     const unsigned env_blocks)
+{
+    const StateWirePtrs p = state_wire_ptrs(w, wire);
+    const size_t BN = (size_t)w.B * w.N;
+    const int D = w.D;
+    auto row_state = [&](const float *row) {  // rows are 8-byte aligned for every D = 4 + 2L
+        const float2 v = *reinterpret_cast<const float2 *>(row), q = *reinterpret_cast<const float2 *>(row + 2);
+        return make_float4(v.x, v.y, q.x, q.y);
+    };
+    if (blockIdx.x < copy_blocks) {
+        const size_t total = (size_t)w.T * BN;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)copy_blocks * blockDim.x)
+            p.state[i] = row_state(obs + i * D);
+        return;
+    }
+    if (blockIdx.x < copy_blocks + env_blocks) {
+        const size_t i = (size_t)(blockIdx.x - copy_blocks) * blockDim.x + threadIdx.x;
+        if (i >= BN) return;
+        const size_t e = i / w.N;
+        const int a = (int)(i - e * w.N);
+        const uint32_t ep0 = p.ep0[e];
+        int k = 0;
+        for (int t = 0; t < w.T; ++t) {
+            const size_t te = (size_t)t * w.B + e;
+            const bool term = terminal[te] != 0 && final_obs != nullptr && k < w.F;
+            if (a == 0) p.epi[te] = (uint8_t)(k | (term ? 0x80 : 0));
+            if (term) {
+                p.final_state[(size_t)k * BN + i] = row_state(final_obs + ((size_t)t * BN + i) * D);
+                for (int l = a; l < w.L; l += w.N) {
+                    float x, y;
+                    pw_reset_xy(seed, env_id_base + e, ep0 + (uint32_t)k + 1u, (uint32_t)(w.N + l), -1.0f, 1.0f, &x, &y);
+                    p.lm[((size_t)(k + 1) * w.B + e) * w.L + l] = make_float2(x, y);
+                }
+                ++k;
+            }
+        }
+        return;
+    }
+    const size_t total = (size_t)w.T * BN;
+    const unsigned first = copy_blocks + env_blocks, nb = gridDim.x - first;
+    for (size_t i = (size_t)(blockIdx.x - first) * blockDim.x + threadIdx.x; i < total; i += (size_t)nb * blockDim.x)
+        p.act[i] = (uint8_t)act[i];
+}
+
+// Root side: ReplayBuffer.add() of the block's T*B transitions with the observation rows REBUILT from the states.
+// Thread = one V-float chunk of one agent's row pair (obs_t, next_obs_t).  V = 4 (even L): chunk 0 = the state itself, chunk
+// c >= 1 = landmarks 2c-2, 2c-1 relative to the agent; V = 2 (odd L): {vel}, {pos}, then one landmark per chunk.
+template <int V>
+__global__ void __launch_bounds__(256) pw_replay_add_state_wire_kernel(const pw_replay_store st, const int64_t start,
+                                                                       const pw_state_wire w, const void *wire)
+{
+    typedef float vec_t __attribute__((ext_vector_type(V)));
+    const StateWirePtrs p = state_wire_ptrs(w, const_cast<void *>(wire));
+    const int N = w.N, L = w.L, CH = w.D / V;
+    const size_t BN = (size_t)w.B * N, per_step = BN * CH, total = (size_t)w.T * per_step;
+    vec_t *r_obs = reinterpret_cast<vec_t *>(st.obs), *r_next = reinterpret_cast<vec_t *>(st.next_obs);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / per_step, rem = i - t * per_step, ea = rem / CH, e = ea / N;
+        const int c = (int)(rem - ea * CH), a = (int)(ea - e * N);
+        const size_t te = t * w.B + e;
+        const unsigned epi = p.epi[te], k = epi & 0x7fu;
+        const float4 s_obs = t == 0 ? p.state0[ea] : p.state[(t - 1) * BN + ea];
+        const float4 s_next = (epi & 0x80u) ? p.final_state[(size_t)k * BN + ea] : p.state[t * BN + ea];
+        const float2 *lm = p.lm + ((size_t)k * w.B + e) * L;
+        vec_t o, n;
+        if (V == 4) {
+            if (c == 0) {
+                o[0] = s_obs.x; o[1] = s_obs.y; o[2] = s_obs.z; o[3] = s_obs.w;
+                n[0] = s_next.x; n[1] = s_next.y; n[2] = s_next.z; n[3] = s_next.w;
+            } else {
+                const float2 l0 = lm[2 * c - 2], l1 = lm[2 * c - 1];
+                o[0] = l0.x - s_obs.z; o[1] = l0.y - s_obs.w; o[2] = l1.x - s_obs.z; o[3] = l1.y - s_obs.w;
+                n[0] = l0.x - s_next.z; n[1] = l0.y - s_next.w; n[2] = l1.x - s_next.z; n[3] = l1.y - s_next.w;
+            }
+        } else {
+            if (c == 0) { o[0] = s_obs.x; o[1] = s_obs.y; n[0] = s_next.x; n[1] = s_next.y; }
+            else if (c == 1) { o[0] = s_obs.z; o[1] = s_obs.w; n[0] = s_next.z; n[1] = s_next.w; }
+            else {
+                const float2 l0 = lm[c - 2];
+                o[0] = l0.x - s_obs.z; o[1] = l0.y - s_obs.w;
+                n[0] = l0.x - s_next.z; n[1] = l0.y - s_next.w;
+            }
+        }
+        const size_t slot = (size_t)((start + (int64_t)te) % st.capacity);
+        const size_t at = (slot * N + a) * CH + c;
+        r_obs[at] = o;
+        r_next[at] = n;
+        if (c == 0) {
+            st.act[slot * N + a] = p.act[te * N + a];
+            if (a == 0) {
+                st.rew[slot] = p.rew_shared[te];
+                st.done[slot] = 0.0f;
+            }
+        }
+    }
+}
+
 }  // namespace

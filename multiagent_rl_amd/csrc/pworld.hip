@@ -1076,4 +1076,114 @@ int pw_replay_add_wire(const pw_replay_store *st, int64_t start, const pw_chunk_
     return PW_OK;
 }
 
+namespace {
+void fill_state_wire(int32_t T, int32_t B, int32_t N, int32_t L, int32_t F, pw_state_wire *out)
+{
+    std::memset(out, 0, sizeof(*out));
+    out->T = T; out->B = B; out->N = N; out->L = L; out->D = 4 + 2 * L; out->F = F;
+    const size_t st = (size_t)B * N * sizeof(float4);
+    size_t off = 0;
+    auto plane = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    out->state0 = plane(st);
+    out->state = plane((size_t)T * st);
+    out->final_state = plane((size_t)F * st);
+    out->lm = plane((size_t)(F + 1) * B * L * sizeof(float2));
+    out->ep0 = plane((size_t)B * sizeof(uint32_t));
+    out->rew_shared = plane((size_t)T * B * sizeof(float));
+    out->act = plane((size_t)T * B * N);
+    out->epi = plane((size_t)T * B);
+    out->total_bytes = off;
+}
+
+int check_state_wire(const pw_state_wire *w, const void *wire)
+{
+    if (!w || !wire) return fail(PW_EINVAL, "null argument");
+    if (w->T < 1 || w->B < 1 || w->N < 1 || w->L < 0 || w->D != 4 + 2 * w->L || w->F < 0 || w->F > 126)
+        return fail(PW_EINVAL, "bad state-wire layout");
+    pw_state_wire ref;  // offsets must be the ones pw_state_wire_layout produces
+    fill_state_wire(w->T, w->B, w->N, w->L, w->F, &ref);
+    if (std::memcmp(&ref, w, sizeof(ref)) != 0) return fail(PW_EINVAL, "wire layout was not produced by pw_state_wire_layout");
+    if (reinterpret_cast<uintptr_t>(wire) & 255) return fail(PW_EINVAL, "wire block must be 256-byte aligned");
+    return PW_OK;
+}
+
+int state_wire_handle_ok(const pw_handle *h, const pw_state_wire *w)
+{
+    if (!h) return fail(PW_EINVAL, "null handle");
+    if (h->cfg.scenario != PW_SIMPLE_SPREAD || h->cfg.obs_mode != PW_OBS_LOCAL || h->kp.D != 4 + 2 * h->kp.L)
+        return fail(PW_EINVAL, "state-only wire blocks serve simple_spread with the local observation (rows that are a function "
+                               "of {vel, pos} and the landmarks); use pw_chunk_wire_* elsewhere");
+    if (w && (w->B != h->kp.B || w->N != h->kp.N || w->L != h->kp.L)) return fail(PW_EINVAL, "wire / handle shape mismatch");
+    return PW_OK;
+}
+}  // namespace
+
+int pw_state_wire_layout(int32_t T, int32_t B, int32_t N, int32_t L, int32_t max_episode_len, pw_state_wire *out)
+{
+    if (!out) return fail(PW_EINVAL, "null argument");
+    if (T < 1 || B < 1 || N < 1 || L < 0 || max_episode_len < 0) return fail(PW_EINVAL, "bad sizes");
+    const int64_t F = max_episode_len > 0 ? ((int64_t)T + max_episode_len - 1) / max_episode_len : 0;
+    if (F > 126) return fail(PW_EINVAL, "more than 126 episode ends per env and chunk: use shorter chunks");
+    fill_state_wire(T, B, N, L, (int32_t)F, out);
+    return PW_OK;
+}
+
+int pw_state_wire_begin(const pw_handle *h, const pw_state_wire *w, void *wire, void *stream)
+{
+    if (int rc = check_ready(h)) return rc;
+    if (int rc = check_state_wire(w, wire)) return rc;
+    if (int rc = state_wire_handle_ok(h, w)) return rc;
+    const KParams &kp = h->kp;
+    const size_t n = (size_t)w->B * (w->N > w->L ? w->N : w->L);
+    hipLaunchKernelGGL(pw_state_wire_begin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       *w, wire, kp.pos_x, kp.pos_y, kp.vel_x, kp.vel_y, kp.lm_x, kp.lm_y, kp.ep_count);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_state_wire_finalize(const pw_handle *h, const pw_state_wire *w, void *wire, const float *obs, const float *final_obs,
+                           const uint8_t *terminal, const int32_t *act, void *stream)
+{
+    if (int rc = check_state_wire(w, wire)) return rc;
+    if (int rc = state_wire_handle_ok(h, w)) return rc;
+    if (!obs || !terminal || !act) return fail(PW_EINVAL, "null argument");
+    if ((reinterpret_cast<uintptr_t>(obs) | reinterpret_cast<uintptr_t>(final_obs)) & 7)
+        return fail(PW_EINVAL, "obs and final_obs must be 8-byte aligned");
+    const size_t BN = (size_t)w->B * w->N, total = (size_t)w->T * BN;
+    size_t copy_blocks = (total + 255) / 256;
+    if (copy_blocks > 8192) copy_blocks = 8192;
+    const unsigned env_blocks = (unsigned)((BN + 255) / 256);
+    size_t act_blocks = (total + 255) / 256;
+    if (act_blocks > 2048) act_blocks = 2048;
+    hipLaunchKernelGGL(pw_state_wire_finalize_kernel, dim3((unsigned)(copy_blocks + env_blocks + act_blocks)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *w, wire, obs, final_obs, terminal, act, (uint64_t)h->kp.seed,
+                       (uint64_t)h->kp.env_id_base, (unsigned)copy_blocks, env_blocks);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_replay_add_state_wire(const pw_replay_store *st, int64_t start, const pw_state_wire *w, const void *wire, void *stream)
+{
+    if (!st) return fail(PW_EINVAL, "null argument");
+    if (int rc = plain_ring_only(st, "pw_replay_add_state_wire")) return rc;
+    if (int rc = check_state_wire(w, wire)) return rc;
+    if (st->num_agents != w->N || st->obs_dim != w->D) return fail(PW_EINVAL, "ring / wire shape mismatch");
+    if (st->capacity < 1 || (int64_t)w->T * w->B > st->capacity || start < 0)
+        return fail(PW_EINVAL, "bad ring arguments (the chunk must fit the ring)");
+    const uintptr_t al = reinterpret_cast<uintptr_t>(st->obs) | reinterpret_cast<uintptr_t>(st->next_obs);
+    const bool v4 = w->L % 2 == 0 && (al & 15) == 0;
+    if (!v4 && (al & 7)) return fail(PW_EINVAL, "ring observation planes must be 8-byte aligned");
+    const size_t total = (size_t)w->T * w->B * w->N * (v4 ? w->D / 4 : w->D / 2);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (v4)
+        hipLaunchKernelGGL(pw_replay_add_state_wire_kernel<4>, dim3((unsigned)blocks), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), *st, start, *w, wire);
+    else
+        hipLaunchKernelGGL(pw_replay_add_state_wire_kernel<2>, dim3((unsigned)blocks), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), *st, start, *w, wire);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
 }  // extern "C"

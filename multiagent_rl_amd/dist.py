@@ -249,14 +249,31 @@ class FullTransitionGather(object):
     ``(x*world + r)*T*B + t*B + e``.
 
     Usage per chunk:  ``out = g.outputs()``; ``policy.rollout(env, T, out)``; ``g(obs0)``; at the end ``g.finish()``.
+
+    ``wire='state'`` (the default wherever it applies: simple_spread with the local observation) ships STATE-ONLY
+    blocks (``pw_state_wire``): 16 B per agent and step instead of the 4 + 2L floats of its observation row, the
+    landmarks once per episode, the pre-reset state only for the steps that ended an episode; the root REBUILDS the
+    ``obs`` / ``next_obs`` rows (``pw_replay_add_state_wire``; every entry of a local row is the state itself or one float32
+    subtraction, so the ring is bit-identical).  C2, T = 100: 114 B per env-step instead of 414 -- 32 GB/s per inbound xGMI
+    link at 2.8e8 env-steps/s per rank instead of 115 (of ~153).  In this mode ``outputs()`` also snapshots the chunk's
+    start (state, landmarks, episode numbers) into the block: call it right before the chunk's rollout launch.
+    ``wire='rows'`` keeps the row block (any scenario).
     """
 
-    def __init__(self, env, T, rank, world, device, memory=None, group=None, capacity=int(1e6)):
-        from ._lib import PwChunkWire
+    def __init__(self, env, T, rank, world, device, memory=None, group=None, capacity=int(1e6), wire='auto'):
+        from ._lib import PwChunkWire, PwStateWire
         self.rank, self.world, self.device, self.group = rank, world, torch.device(device), group
         self.B, self.N, self.D, self.T = env.num_envs, env.n, env.obs_dim, int(T)
+        self.L = int(getattr(env, 'num_landmarks', 0))
+        self.env = env
         self.max_episode_len = int(env.cfg.max_episode_len) if hasattr(env, 'cfg') else int(env.max_episode_len)
-        self.lay = self._layout(PwChunkWire)
+        if wire not in ('auto', 'state', 'rows'):
+            raise ValueError("wire must be 'auto', 'state' or 'rows'")
+        fits = self._state_wire_applies(env)
+        if wire == 'state' and not fits:
+            raise ValueError('state-only wire blocks serve simple_spread with the local observation (D = 4 + 2L)')
+        self.state_wire = fits and wire != 'rows'
+        self.lay = self._layout(PwStateWire if self.state_wire else PwChunkWire)
         nbytes = self.lay.total_bytes
         dev = self.device
         self.wire = [torch.zeros(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -271,6 +288,8 @@ class FullTransitionGather(object):
                          act=torch.zeros(self.T, B, N, dtype=torch.int32, device=dev),
                          rew=torch.empty(self.T, B, N, dtype=torch.float32, device=dev),
                          done=torch.zeros(self.T, B, N, dtype=torch.bool, device=dev))
+        if self.state_wire:   # the rows stay on the sender: only their first four columns travel
+            self.side['obs'] = torch.empty(self.T, B, N, D, dtype=torch.float32, device=dev)
         self.memory = memory
         self.capacity = int(capacity)
         if rank == 0 and self.memory is None:
@@ -280,9 +299,18 @@ class FullTransitionGather(object):
         self._pending = None
 
     # -- layout / views
-    def _layout(self, PwChunkWire):
-        lay = PwChunkWire()
-        check(_lib.load().pw_chunk_wire_layout(self.T, self.B, self.N, self.D, self.max_episode_len, C.byref(lay)))
+    def _state_wire_applies(self, env):
+        """Rows that are a function of {vel, pos} and the landmarks: simple_spread, local observation."""
+        name = getattr(env, 'scenario_name', None)
+        local = env.cfg.obs_mode == _lib.PW_OBS_LOCAL if hasattr(env, 'cfg') else getattr(env, 'local_observation', True)
+        return name == 'simple_spread' and local and self.D == 4 + 2 * self.L
+
+    def _layout(self, Struct):
+        lay = Struct()
+        if Struct is _lib.PwStateWire:
+            check(_lib.load().pw_state_wire_layout(self.T, self.B, self.N, self.L, self.max_episode_len, C.byref(lay)))
+        else:
+            check(_lib.load().pw_chunk_wire_layout(self.T, self.B, self.N, self.D, self.max_episode_len, C.byref(lay)))
         return lay
 
     def _view(self, block, off, shape, dtype):
@@ -295,6 +323,16 @@ class FullTransitionGather(object):
     def views(self, block):
         """Typed views of one wire block (a uint8 tensor of ``lay.total_bytes``)."""
         lay, T, B, N, D = self.lay, self.T, self.B, self.N, self.D
+        if self.state_wire:
+            F, L = max(lay.F, 0), self.L
+            return dict(state0=self._view(block, lay.state0, (B, N, 4), torch.float32),
+                        state=self._view(block, lay.state, (T, B, N, 4), torch.float32),
+                        final_state=self._view(block, lay.final_state, (F, B, N, 4), torch.float32),
+                        lm=self._view(block, lay.lm, (F + 1, B, L, 2), torch.float32),
+                        ep0=self._view(block, lay.ep0, (B,), torch.int32),
+                        rew_shared=self._view(block, lay.rew_shared, (T, B), torch.float32),
+                        act=self._view(block, lay.act, (T, B, N), torch.uint8),
+                        epi=self._view(block, lay.epi, (T, B), torch.uint8))
         return dict(obs0=self._view(block, lay.obs0, (B, N, D), torch.float32),
                     obs=self._view(block, lay.obs, (T, B, N, D), torch.float32),
                     final_rows=self._view(block, lay.final_rows, (max(lay.F, 0), B, N, D), torch.float32),
@@ -307,8 +345,10 @@ class FullTransitionGather(object):
         ``BatchedParticleEnv.rollout``): obs and rew_shared are views INTO the wire block."""
         slot = self.exchanges & 1 if slot is None else slot
         v = self.views(self.wire[slot])
-        out = dict(obs=v['obs'], rew_shared=v['rew_shared'], terminal=self.side['terminal'], act=self.side['act'],
-                   rew=self.side['rew'], done=self.side['done'])
+        if self.state_wire:
+            self._begin(self.wire[slot])
+        out = dict(obs=self.side['obs'] if self.state_wire else v['obs'], rew_shared=v['rew_shared'],
+                   terminal=self.side['terminal'], act=self.side['act'], rew=self.side['rew'], done=self.side['done'])
         if self.side['final_obs'] is not None:
             out['final_obs'] = self.side['final_obs']
         return out
@@ -330,16 +370,25 @@ class FullTransitionGather(object):
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _begin(self, block):
+        """State-only wire: the chunk's start (state, landmarks, episode numbers) from the env's bound state planes."""
+        check(_lib.load().pw_state_wire_begin(self.env._h, C.byref(self.lay), C.c_void_p(block.data_ptr()), self._stream()))
+
     def _finalize(self, block, obs0):
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        if self.state_wire:   # obs0 is already in the block as state0 (pw_state_wire_begin)
+            check(_lib.load().pw_state_wire_finalize(self.env._h, C.byref(self.lay), p(block), p(self.side['obs']),
+                                                     p(self.side['final_obs']), p(self.side['terminal']), p(self.side['act']),
+                                                     self._stream()))
+            return
         assert obs0.is_contiguous() and obs0.dtype == torch.float32 and tuple(obs0.shape) == (self.B, self.N, self.D)
         check(_lib.load().pw_chunk_wire_finalize(C.byref(self.lay), p(block), p(obs0), p(self.side['final_obs']),
                                                  p(self.side['terminal']), p(self.side['act']), self._stream()))
 
     def _ingest(self, block):
         m = self.memory
-        check(_lib.load().pw_replay_add_wire(C.byref(m._store), m._next_idx, C.byref(self.lay),
-                                             C.c_void_p(block.data_ptr()), self._stream()))
+        add = _lib.load().pw_replay_add_state_wire if self.state_wire else _lib.load().pw_replay_add_wire
+        check(add(C.byref(m._store), m._next_idx, C.byref(self.lay), C.c_void_p(block.data_ptr()), self._stream()))
         n = self.T * self.B
         m._next_idx = (m._next_idx + n) % m._maxsize
         m._len = min(m._len + n, m._maxsize)

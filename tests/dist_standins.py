@@ -73,6 +73,61 @@ def wire_transitions_reference(g, block):
                 done=torch.zeros(T * B))
 
 
+# ---- state-only wire blocks (include/pworld.h pw_state_wire): simple_spread, local observation --------------------------
+def rows_from_state(state, lm):
+    """The local observation rows (experiments/scenarios.py:6-20) of agents with ``state`` [..., N, 4] = {vx, vy, px, py}
+    among landmarks ``lm`` [..., L, 2]: [vel, pos, lm_0 - pos, lm_1 - pos, ...], float32, one subtraction per entry."""
+    pos = state[..., 2:4]
+    rel = lm[..., None, :, :] - pos[..., :, None, :]                      # [..., N, L, 2]
+    return torch.cat([state, rel.reshape(*rel.shape[:-2], -1)], dim=-1)
+
+
+def state_wire_begin_reference(g, block, state0, lm0, ep0):
+    """pw_state_wire_begin: the chunk's start, from the env's state planes."""
+    v = g.views(block)
+    v['state0'].copy_(state0)
+    v['lm'][0].copy_(lm0)
+    v['ep0'].copy_(ep0.to(torch.int32))
+
+
+def state_wire_finalize_reference(g, block, landmarks_of_episode):
+    """pw_state_wire_finalize: columns 0..3 of every row, the k-th episode end's pre-reset state, the landmarks the k-th reset
+    drew (``landmarks_of_episode(env_indices, episode_numbers) -> [n, L, 2]``: the reset's own generator), byte actions, and per
+    step: episode ends before it (bits 0..6) | this step ended one (bit 7)."""
+    v = g.views(block)
+    T, B, F = g.T, g.B, g.lay.F
+    v['state'].copy_(g.side['obs'][..., :4])
+    term, fin = g.side['terminal'].bool(), g.side['final_obs']
+    ep0 = v['ep0'].long()
+    k = torch.zeros(B, dtype=torch.long)
+    for t in range(T):
+        m = term[t] & (k < F) if fin is not None else torch.zeros(B, dtype=torch.bool)
+        v['epi'][t] = (k + 128 * m.long()).to(torch.uint8)
+        e = torch.nonzero(m).flatten()
+        if e.numel():
+            v['final_state'][k[e], e] = fin[t, e][..., :4]
+            v['lm'][k[e] + 1, e] = landmarks_of_episode(e, ep0[e] + k[e] + 1)
+        k = k + m.long()
+    v['act'].copy_(g.side['act'].to(torch.uint8))
+
+
+def state_wire_transitions_reference(g, block):
+    """pw_replay_add_state_wire: the block's T*B transitions in (t, e) order with the rows REBUILT from the states."""
+    v = g.views(block)
+    T, B, N, D = g.T, g.B, g.N, g.D
+    epi = v['epi'].long()
+    k, ended = epi & 127, (epi & 128) != 0
+    e_idx = torch.arange(B)[None, :].expand(T, B)
+    lm = v['lm'][k, e_idx]                                                # [T, B, L, 2]: the episode in progress at step t
+    s_obs = torch.cat([v['state0'][None], v['state'][:-1]], 0)
+    s_next = v['state'].clone()
+    t, e = torch.nonzero(ended, as_tuple=True)
+    if t.numel():
+        s_next[t, e] = v['final_state'][k[t, e], e]
+    return dict(obs=rows_from_state(s_obs, lm).reshape(T * B, N, D), next_obs=rows_from_state(s_next, lm).reshape(T * B, N, D),
+                act=v['act'].reshape(T * B, N).clone(), rew=v['rew_shared'].reshape(T * B).clone(), done=torch.zeros(T * B))
+
+
 class CpuFullGather(FullTransitionGather):
     def _layout(self, PwChunkWire):
         # the layout arithmetic is host code of libpworld (no GPU needed)
@@ -81,8 +136,15 @@ class CpuFullGather(FullTransitionGather):
     def _make_memory(self):
         return HostRing()
 
+    def _begin(self, block):
+        state_wire_begin_reference(self, block, *self.env.wire_start())     # the stub env's (state0, landmarks, episode numbers)
+
     def _finalize(self, block, obs0):
-        wire_finalize_reference(self, block, obs0)
+        if self.state_wire:
+            state_wire_finalize_reference(self, block, self.env.landmarks_of_episode)
+        else:
+            wire_finalize_reference(self, block, obs0)
 
     def _ingest(self, block):
-        self.memory.transitions.append(wire_transitions_reference(self, block))
+        self.memory.transitions.append(state_wire_transitions_reference(self, block) if self.state_wire
+                                       else wire_transitions_reference(self, block))

@@ -17,14 +17,70 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from multiagent_rl_amd.dist import broadcast_actor, row_width, shard_env_ids
-from tests.dist_standins import CpuFullGather, CpuSampledGather, pack_reference
+from tests.dist_standins import CpuFullGather, CpuSampledGather, pack_reference, rows_from_state
 
 B, N, D, T = 8, 3, 10, 5
 EP = 3  # episode length of the full-gather test: chunks of T = 5 steps see 1 or 2 episode ends per env
 
 
+L = (D - 4) // 2
+
+
 class _Env(object):
-    num_envs, n, obs_dim, max_episode_len = B, N, D, EP
+    num_envs, n, obs_dim, max_episode_len, num_landmarks = B, N, D, EP, L
+
+
+class _SpreadEnv(_Env):
+    """What FullTransitionGather's state-only wire asks of an env, as a stub: simple_spread with the local observation, the
+    chunk's start (state, landmarks, episode numbers) and the landmarks a reset draws for (env, episode number)."""
+    scenario_name, local_observation = 'simple_spread', True
+
+    def __init__(self, rank):
+        self.rank, self.start = rank, None
+
+    def wire_start(self):
+        return self.start
+
+    def landmarks_of_episode(self, e, epn):
+        return landmarks_of(self.rank, e, epn)
+
+
+def landmarks_of(rank, e, epn):
+    """Stand-in for the reset's Philox draw: landmarks [n, L, 2] of env e's episode number epn on this rank."""
+    e, epn = torch.as_tensor(e).double()[:, None, None], torch.as_tensor(epn).double()[:, None, None]
+    l, c = torch.arange(L).double()[None, :, None], torch.arange(2).double()[None, None, :]
+    return torch.sin(1.3 * rank + 0.7 * e + 2.1 * epn + 0.37 * l + 1.9 * c).float()
+
+
+def episode_number(e, s):
+    """Episode number of env e before global step s: its clock starts at e % EP, an episode ends every EP steps."""
+    return 1 + (s + e % EP) // EP
+
+
+def spread_chunk(rank, k, step0):
+    """A rollout chunk of a simple_spread env: random states, rows that ARE the local observation of those states among the
+    landmarks of the episode in progress, pre-reset rows among the landmarks of the episode that just ended."""
+    g = torch.Generator()
+    g.manual_seed(4242 + 1000 * rank + k)
+    state = torch.randn(T, B, N, 4, generator=g)
+    final_state = torch.randn(T, B, N, 4, generator=g)
+    out = dict(rew_shared=torch.randn(T, B, generator=g), act=torch.randint(0, 5, (T, B, N), generator=g, dtype=torch.int32))
+    t = torch.arange(T)[:, None] + step0
+    e = torch.arange(B)[None, :].expand(T, B)
+    out['terminal'] = ((t + e) % EP) == EP - 1
+    lm_after = landmarks_of(rank, e.reshape(-1), episode_number(e, t + 1).reshape(-1)).reshape(T, B, L, 2)
+    lm_before = landmarks_of(rank, e.reshape(-1), episode_number(e, t).reshape(-1)).reshape(T, B, L, 2)
+    out['obs'] = rows_from_state(state, lm_after)
+    out['final_obs'] = rows_from_state(final_state, lm_before)
+    return out
+
+
+def spread_start(rank):
+    """(state, landmarks, episode numbers) before global step 0."""
+    g = torch.Generator()
+    g.manual_seed(999 + rank)
+    e = torch.arange(B)
+    return torch.randn(B, N, 4, generator=g), landmarks_of(rank, e, episode_number(e, 0)), episode_number(e, 0)
 
 
 def chunk(rank, k):
@@ -67,6 +123,25 @@ def _worker(rank, world, port, q):
         full(obs0)
         obs0 = src['obs'][T - 1].clone()
     full.finish()
+    assert not full.state_wire and full.bytes_per_env_step > 4 * N * D
+    dist.barrier()
+
+    # ---- the same gather on state-only wire blocks (simple_spread): the root REBUILDS the rows
+    senv = _SpreadEnv(rank)
+    sfull = CpuFullGather(senv, T, rank, world, 'cpu')
+    assert sfull.state_wire and sfull.lay.F == 2 and sfull.bytes_per_env_step < 0.6 * full.bytes_per_env_step
+    state0, lm0, ep0 = spread_start(rank)
+    for k in range(3):
+        src = spread_chunk(rank, k, k * T)
+        senv.start = (state0, lm0, ep0)
+        out = sfull.outputs()                    # snapshots the chunk's start into the block
+        for name in ('obs', 'rew_shared', 'terminal', 'act', 'final_obs'):
+            out[name].copy_(src[name])           # "the rollout kernel wrote its outputs"
+        sfull(None)
+        e = torch.arange(B)
+        state0, ep0 = src['obs'][T - 1][..., :4].clone(), episode_number(e, (k + 1) * T)
+        lm0 = landmarks_of(rank, e, ep0)
+    sfull.finish()
     dist.barrier()
 
     # ---- sampled gather
@@ -91,9 +166,11 @@ def _worker(rank, world, port, q):
     assert same and n_moved == sum(p.numel() for p in want.parameters())
     if rank == 0:
         ring = [{k: v.numpy() for k, v in tr.items()} for tr in full.memory.transitions]
-        q.put((gat.exchanges, gat.rows_ingested, [r.numpy() for r in gat.memory.rows], full.rows_ingested, ring))
+        sring = [{k: v.numpy() for k, v in tr.items()} for tr in sfull.memory.transitions]
+        q.put((gat.exchanges, gat.rows_ingested, [r.numpy() for r in gat.memory.rows], full.rows_ingested, ring,
+               sfull.rows_ingested, sring))
     else:
-        q.put((gat.exchanges, gat.rows_ingested, None, full.rows_ingested, None))
+        q.put((gat.exchanges, gat.rows_ingested, None, full.rows_ingested, None, sfull.rows_ingested, None))
     dist.destroy_process_group()
 
 
@@ -168,6 +245,36 @@ def test_full_transition_gather_world2(worldn):
     assert n_final > 0 and n_final < 3 * world * T * B  # both kinds of rows were exercised
 
 
+@pytest.mark.timeout(240)
+def test_full_transition_gather_state_only_wire(worldn):
+    """The same fan-in on STATE-ONLY wire blocks (2, 4, 8 ranks): what reaches the root's ring are the rows rebuilt from
+    {vel, pos} + the episode's landmarks, and they equal the senders' dense rows exactly -- obs_t, the pre-reset next_obs,
+    actions, rewards, in (exchange, rank, step, env) order."""
+    world, root = worldn
+    ingested, ring = root[5], root[6]
+    assert ingested == 3 * world * T * B and len(ring) == 3 * world
+    i = n_final = 0
+    for k in range(3):
+        for r in range(world):
+            src = spread_chunk(r, k, k * T)
+            if k == 0:
+                st, lm, _ = spread_start(r)
+                obs0 = rows_from_state(st, lm)
+            else:
+                obs0 = spread_chunk(r, k - 1, (k - 1) * T)['obs'][T - 1]
+            want_obs = torch.cat([obs0[None], src['obs'][:-1]], 0).reshape(T * B, N, D)
+            want_next = torch.where(src['terminal'][:, :, None, None], src['final_obs'], src['obs']).reshape(T * B, N, D)
+            got = ring[i]
+            np.testing.assert_array_equal(got['obs'], want_obs.numpy())
+            np.testing.assert_array_equal(got['next_obs'], want_next.numpy())
+            np.testing.assert_array_equal(got['act'], src['act'].reshape(T * B, N).numpy().astype(np.uint8))
+            np.testing.assert_array_equal(got['rew'], src['rew_shared'].reshape(T * B).numpy())
+            assert not got['done'].any()
+            n_final += int(src['terminal'].sum())
+            i += 1
+    assert 0 < n_final < 3 * world * T * B
+
+
 @pytest.mark.timeout(120)
 def test_sampled_transition_gather_world2(world2):
     world, root = world2
@@ -211,6 +318,14 @@ def test_root_receive_memory_at_c4():
     assert 413.0 < per_env_step < 416.0                       # 395 B + (1 + F) / T observation batches
     got = FullTransitionGather.root_receive_bytes(8, lay.total_bytes)
     assert got == 2 * 7 * lay.total_bytes and 2.3e9 < got < 2.5e9       # ~2.4 GB of the root's 288 GB
+    # the state-only block of the same chunk (what simple_spread ships): 17 N + 5 per step + 5 state / landmark batches
+    slay = _lib.PwStateWire()
+    assert _lib.load().pw_state_wire_layout(100, 4096, 6, 6, 25, C.byref(slay)) == 0
+    assert slay.F == 4 and slay.D == 16 and slay.total_bytes % 256 == 0
+    per_env_step = slay.total_bytes / (100 * 4096.0)
+    assert 113.0 < per_env_step < 116.0 and per_env_step <= 130.0
+    assert 6.0e8 < FullTransitionGather.root_receive_bytes(8, slay.total_bytes) < 7.0e8
+    assert _lib.load().pw_state_wire_layout(1000, 8, 3, 3, 2, C.byref(slay)) < 0    # 500 episode ends per env and chunk
     # the constructor allocates exactly that (checked on the CPU stand-in at a small shape, every rank count)
     class E(object):
         num_envs, n, obs_dim, max_episode_len = 8, 3, 10, 3

@@ -635,8 +635,8 @@ def test_chunk_wire_finalize_and_add_wire_equal_add_rollout(B, N, T, ep):
     cap = T * B * 3 + 17
     mem = ReplayBuffer(cap, N, D)
     mem._next_idx = mem._len = cap - 5                        # the first chunk wraps around the ring end
-    full = FullTransitionGather(env, T, 0, 1, torch.device('cuda', 0), memory=mem)
-    assert full.lay.F == (0 if ep == 0 else -(-T // ep))
+    full = FullTransitionGather(env, T, 0, 1, torch.device('cuda', 0), memory=mem, wire='rows')
+    assert not full.state_wire and full.lay.F == (0 if ep == 0 else -(-T // ep))
     assert abs(full.bytes_per_env_step - full.lay.total_bytes / (T * B)) < 1e-9
     want = ReplayBuffer(cap, N, D)
     want._next_idx = want._len = cap - 5
@@ -659,7 +659,7 @@ def test_chunk_wire_finalize_and_add_wire_equal_add_rollout(B, N, T, ep):
         full(obs0)
         # the block equals the CPU restatement of finalize
         cpu = FullTransitionGather.__new__(FullTransitionGather)
-        cpu.__dict__.update(T=T, B=B, N=N, D=D, lay=full.lay,
+        cpu.__dict__.update(T=T, B=B, N=N, D=D, lay=full.lay, state_wire=False,
                             side={n_: (None if v is None else v.cpu()) for n_, v in full.side.items()})
         ref_block = block.cpu().clone()
         for name in ('obs0', 'final_rows', 'act', 'fin_slot'):
@@ -686,6 +686,136 @@ def test_chunk_wire_finalize_and_add_wire_equal_add_rollout(B, N, T, ep):
     lo, n = (cap - 5) % cap, 3 * T * B
     idx = [(lo + i) % cap for i in range(0, n, max(1, n // 999))]
     assert not mem.sample_index(idx)[4].any()
+
+
+def _reset_landmarks_numpy(seed, env_ids, episodes, N, L):
+    """pw_reset_xy (include/pworld_math.h) for the landmark entities, restated with the oracle's Philox: counter = (entity,
+    episode, env id lo, hi), key = (seed lo, hi); u = (r >> 8) * 2^-24; coordinate = 2 u - 1 in float32."""
+    from oracle import c_oracle as co
+    out = np.zeros((len(env_ids), L, 2), np.float32)
+    for i, (e, ep) in enumerate(zip(env_ids, episodes)):
+        for l in range(L):
+            r = co.philox4x32_10((N + l, int(ep) & 0xFFFFFFFF, int(e) & 0xFFFFFFFF, int(e) >> 32), (seed & 0xFFFFFFFF, seed >> 32))
+            u = (np.array(r[:2], np.uint32) >> 8).astype(np.float32) * np.float32(5.9604644775390625e-8)
+            out[i, l] = np.float32(2.0) * u + np.float32(-1.0)
+    return out
+
+
+@pytest.mark.parametrize('B,N,L,T,ep', [(300, 3, None, 31, 25), (4096, 6, None, 100, 25), (77, 6, None, 26, 7), (50, 5, None, 12, 0),
+                                        (64, 2, None, 9, 1), (90, 6, 4, 30, 11), (33, 12, None, 27, 25)])
+def test_state_wire_ring_equals_add_rollout_bitwise(B, N, L, T, ep):
+    """The full gather on STATE-ONLY wire blocks, on one GPU: pw_state_wire_begin snapshots the chunk's start, the rollout writes
+    its rows to the sender's side buffer and rew_shared into the block, pw_state_wire_finalize condenses rows to states (+ the
+    pre-reset states, the landmarks each reset drew, byte actions, the episode map), pw_replay_add_state_wire REBUILDS the rows:
+    the ring must equal pw_replay_add_rollout on the sender's dense outputs BIT FOR BIT (obs, the pre-reset next_obs, actions,
+    rewards; incl. a wrap of the ring end), and the block must equal the torch restatement the gloo tests use.
+    Odd L (float2 path), L != N, ep = 0 (episodes never end) and ep = 1 (every step ends one) included."""
+    from tests.dist_standins import (state_wire_begin_reference, state_wire_finalize_reference,
+                                     state_wire_transitions_reference)
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.dist import FullTransitionGather
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    torch.manual_seed(3)
+    seed = 5
+    kw = {} if L is None else dict(num_landmarks=L)
+    env = make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=ep, seed=seed, **kw)
+    D, L = env.obs_dim, env.num_landmarks
+    cap = T * B * 3 + 17
+    mem = ReplayBuffer(cap, N, D)
+    mem._next_idx = mem._len = cap - 5                        # the first chunk wraps around the ring end
+    full = FullTransitionGather(env, T, 0, 1, torch.device('cuda', 0), memory=mem)
+    assert full.state_wire and full.lay.F == (0 if ep == 0 else -(-T // ep))
+    rows = FullTransitionGather(env, T, 0, 1, torch.device('cuda', 0), wire='rows')
+    assert not rows.state_wire and full.bytes_per_env_step < (0.5 if ep != 1 else 0.7) * rows.bytes_per_env_step
+    want = ReplayBuffer(cap, N, D)
+    want._next_idx = want._len = cap - 5
+    for rb in (mem, want):                                    # 17 slots stay unwritten: make them comparable
+        for plane in (rb.obs, rb.next_obs, rb.act, rb.rew, rb.done):
+            plane.zero_()
+    obs0 = env.reset()
+    if ep > 1:                                                # desynchronise the episode clocks
+        st = env.get_state()
+        env.set_state(st['pos'], st['vel'], st['landmarks'],
+                      ep_step=(torch.arange(B, device='cuda') % ep).int(), ep_count=st['ep_count'])
+    lm_fn = lambda e, epn: torch.from_numpy(_reset_landmarks_numpy(seed, e.tolist(), epn.tolist(), N, L))  # noqa: E731
+    for k in range(3):
+        acts = torch.randint(0, 5, (T, B, N), device='cuda', dtype=torch.int32)
+        st0 = env.get_state()
+        out = full.outputs()                                   # also: pw_state_wire_begin on this chunk's block
+        out['act'].copy_(acts)
+        env.rollout(acts, out={n_: v for n_, v in out.items() if n_ != 'act'})
+        block = full.wire[full.exchanges & 1]
+        dense = {n_: v.clone() for n_, v in out.items()}
+        full(obs0)
+        # the block equals the CPU restatement of begin + finalize
+        cpu = FullTransitionGather.__new__(FullTransitionGather)
+        cpu.__dict__.update(T=T, B=B, N=N, D=D, L=L, lay=full.lay, state_wire=True,
+                            side={n_: (None if v is None else v.cpu()) for n_, v in full.side.items()})
+        ref_block = torch.zeros_like(block, device='cpu')
+        cpu.views(ref_block)['rew_shared'].copy_(dense['rew_shared'].cpu())
+        state0 = torch.cat([st0['vel'], st0['pos']], -1).cpu()
+        state_wire_begin_reference(cpu, ref_block, state0, st0['landmarks'].cpu(), st0['ep_count'].cpu())
+        state_wire_finalize_reference(cpu, ref_block, lm_fn)
+        got_v, ref_v = full.views(block), cpu.views(ref_block)
+        for name in ('state0', 'state', 'ep0', 'rew_shared', 'act', 'epi'):
+            assert torch.equal(got_v[name].cpu(), ref_v[name]), name
+        assert torch.equal(got_v['state0'].cpu(), obs0[..., :4].cpu())
+        epi = ref_v['epi'].long()
+        ended, kk = (epi & 128) != 0, epi & 127
+        assert ended.equal(dense['terminal'].cpu() & (ep > 0))
+        tt, ee = torch.nonzero(ended, as_tuple=True)
+        if tt.numel():
+            assert torch.equal(got_v['final_state'].cpu()[kk[tt, ee], ee], ref_v['final_state'][kk[tt, ee], ee])
+            assert torch.equal(got_v['lm'].cpu()[kk[tt, ee] + 1, ee], ref_v['lm'][kk[tt, ee] + 1, ee])
+        assert torch.equal(got_v['lm'][0].cpu(), ref_v['lm'][0])
+        # the landmarks the block carries for the LAST episode are the ones the env itself holds now
+        last_k = (kk[-1] + ended[-1].long())
+        assert torch.equal(got_v['lm'].cpu()[last_k, torch.arange(B)], env.get_state()['landmarks'].cpu())
+        want.add_rollout(obs0, dense)
+        tr = state_wire_transitions_reference(cpu, block.cpu())
+        assert torch.equal(tr['next_obs'].reshape(T, B, N, D),
+                           torch.where(dense['terminal'][:, :, None, None], dense['final_obs'], dense['obs']).cpu()
+                           if ep > 0 else dense['obs'].cpu())
+        assert torch.equal(tr['obs'].reshape(T, B, N, D), torch.cat([obs0[None], dense['obs'][:-1]], 0).cpu())
+        obs0 = dense['obs'][T - 1]
+    full.finish()
+    assert full.rows_ingested == 3 * T * B and mem._next_idx == want._next_idx and len(mem) == len(want) == cap
+    for name, x, y in (('obs', mem.obs, want.obs), ('next_obs', mem.next_obs, want.next_obs), ('act', mem.act, want.act),
+                       ('rew', mem.rew, want.rew), ('done', mem.done, want.done)):
+        assert torch.equal(x, y), name
+
+
+def test_state_wire_carries_the_policy_rollout_and_stays_under_130_bytes_per_env_step():
+    """C2 (B = 4096, N = 6, 100-step chunks) with the policy in the loop, as bench.py --gpus N drives it: FusedActor.rollout
+    writes into FullTransitionGather.outputs(); the root ring equals the ring the same launch's own sink fills
+    (pw_rollout_sink) bit for bit; the block is <= 130 B per env-step (the row block: 414)."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.dist import FullTransitionGather
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    torch.manual_seed(0)
+    B, N, T = 4096, 6, 100
+    mk = lambda: make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=25, seed=12345678)  # noqa: E731
+    env_a, env_b = mk(), mk()
+    actor = ActorNetwork(env_a.obs_dim, 5).cuda().eval()
+    wire_actor, sink_actor = FusedActor(actor, seed=3), FusedActor(actor, seed=3)
+    full = FullTransitionGather(env_a, T, 0, 1, torch.device('cuda', 0), capacity=2 * T * B)
+    assert full.state_wire and full.bytes_per_env_step <= 130.0, full.bytes_per_env_step
+    assert 113.0 < full.bytes_per_env_step < 116.0            # 17 N + 5 per step + (1 + F) state / landmark batches per chunk
+    want = ReplayBuffer(2 * T * B, N, env_b.obs_dim)
+    env_a.reset()
+    env_b.reset()
+    obs0 = env_a.observe()
+    for k in range(2):
+        out = full.outputs()
+        wire_actor.rollout(env_a, T, out)
+        full(obs0)
+        obs0 = out['obs'][T - 1]
+        sink_actor.rollout(env_b, T, False, memory=want)
+    full.finish()
+    assert full.rows_ingested == 2 * T * B == len(full.memory) == len(want)
+    for name in ('obs', 'next_obs', 'act', 'rew', 'done'):
+        assert torch.equal(getattr(full.memory, name), getattr(want, name)), name
 
 
 def test_wire_functions_reject_foreign_layouts():
