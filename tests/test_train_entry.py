@@ -1,0 +1,198 @@
+"""The batched entry path (multiagent_rl_amd/train.py, examples/train_batched.py) -- counterpart of main.py:29-67 +
+experiments/run.py:11-103.  CPU: the control flow with a stub Trainer and a stub rollout (collect -> optimize() gate in env-steps
+-> actor refresh -> report -> history + save_models); GPU: two chunks of the real thing."""
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from multiagent_rl_amd.rollout import LearnGate
+from multiagent_rl_amd.train import ChunkLedger, dims_from_env, train_batched
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Args(object):
+    max_episode_len, num_episodes, is_training = 25, 64, True
+    batch_size, warmup_steps, update_rate, save_rate, display = 8, 1024, 100, 32, False
+
+
+class _Space(object):
+    def __init__(self, n):
+        self.n, self.shape = n, (10,)
+
+
+class _StubEnv(object):
+    num_envs, n, obs_dim = 16, 3, 10
+    observation_space = [_Space(5)] * 3
+    action_space = [_Space(5)] * 3
+
+
+class _StubTrainer(object):
+    trace = None
+
+    def __init__(self, actor, critic, memory, action_type='Discrete'):
+        self.actor, self.memory = actor, memory
+        self.trace.append(('trainer_init', action_type))
+
+    def optimize(self):
+        self.trace.append(('optimize', len(self.memory)))
+
+    def save_models(self, name):
+        self.trace.append(('save_models', name))
+
+
+class _StubMemory(object):
+    def __init__(self):
+        self.n = 0
+
+    def __len__(self):
+        return self.n
+
+
+class _StubFused(object):
+    def __init__(self, trace):
+        self.trace = trace
+
+    def refresh(self):
+        self.trace.append(('refresh',))
+
+
+class _StubRollout(object):
+    """BatchedRollout's surface as train_batched uses it: every env finishes an episode every 25 steps."""
+
+    def __init__(self, env, memory, trace):
+        self.env, self.memory, self.trace = env, memory, trace
+        self.obs = torch.zeros(env.num_envs, env.n, env.obs_dim)
+        self.env_steps, self.steps = 0, 0
+        self.episode_return = torch.zeros(env.num_envs)
+        self.finished_return_sum = torch.zeros((), dtype=torch.float64)
+        self.finished_episodes = torch.zeros((), dtype=torch.int64)
+
+    def collect_one_launch(self, num_steps, chunk=100, keep_outputs=False):
+        B, N = self.env.num_envs, self.env.n
+        self.trace.append(('collect', num_steps, keep_outputs))
+        t = torch.arange(self.steps, self.steps + num_steps)
+        term = ((t + 1) % 25 == 0)[:, None].expand(num_steps, B)
+        self.last_chunk = dict(rew=-torch.ones(num_steps, B, N), terminal=term)
+        self.steps += num_steps
+        self.env_steps += num_steps * B
+        self.memory.n += num_steps * B
+        self.finished_episodes += int(term[:, 0].sum()) * B
+        self.finished_return_sum += -75.0 * int(term[:, 0].sum()) * B
+
+    def stats(self):
+        n = float(self.finished_episodes)
+        return dict(env_steps=self.env_steps, episodes=int(n), mean_episode_reward=float(self.finished_return_sum) / n if n else float('nan'))
+
+
+def test_learn_gate_counts_openings_in_env_steps():
+    """run.py:78-81: optimize() when train_step > warmup_steps and train_step % update_rate == 0."""
+    cfg = _Args()
+    g = LearnGate(cfg)
+    per_step = [s for s in range(1, 3001) if g.due(s)]
+    assert per_step[0] == 1100 and per_step[-1] == 3000 and len(per_step) == 20
+    for a, b in ((0, 3000), (0, 1024), (1024, 1100), (1099, 1100), (1100, 1100), (950, 2150), (2999, 3000), (0, 99)):
+        assert g.due_between(a, b) == len([s for s in per_step if a < s <= b]), (a, b)
+    cfg2 = _Args()
+    cfg2.is_training = False
+    assert LearnGate(cfg2).due_between(0, 10 ** 6) == 0
+
+
+def test_chunk_ledger_splits_a_chunk_into_episode_returns():
+    """Per-episode returns out of [T, B, N] rewards with desynchronised episode ends, carried across chunks."""
+    torch.manual_seed(0)
+    T, B, N = 40, 5, 3
+    rew = torch.randn(2 * T, B, N)
+    term = torch.zeros(2 * T, B, dtype=torch.bool)
+    for e in range(B):
+        term[(7 + 3 * e)::(11 + e), e] = True
+    led = ChunkLedger(B, N, 'cpu')
+    led.absorb(rew[:T], term[:T])
+    led.absorb(rew[T:], term[T:])
+    want = []
+    for half in (slice(0, T), slice(T, 2 * T)):           # (chunk, episode index inside the chunk, env) order
+        per_env = []
+        for e in range(B):
+            ends = [t for t in range(half.start, half.stop) if term[t, e]]
+            per_env.append(ends)
+        for k in range(max(len(x) for x in per_env)):
+            for e in range(B):
+                if k < len(per_env[e]):
+                    t1 = per_env[e][k]
+                    prev = [t for t in range(0, t1) if term[t, e]]
+                    t0 = prev[-1] + 1 if prev else 0
+                    want.append(rew[t0:t1 + 1, e].double().sum(0).numpy())
+    got = np.stack([np.array(a) for a in led.by_agent], 1)
+    np.testing.assert_allclose(got, np.stack(want), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(led.totals, np.stack(want).sum(1), rtol=0, atol=1e-9)
+    assert sorted(led.history().keys()) == ['reward_episodes', 'reward_episodes_by_agents']
+
+
+def test_train_batched_orders_collect_learn_refresh_and_writes_the_history(tmp_path):
+    """The loop of train_batched with a stub Trainer and a stub rollout: chunks of 10 steps x 16 envs = 160 env-steps; the
+    gate opens once per 100 env-steps after 1024; every batch of updates is followed by ONE refresh of the rollout's weight
+    snapshot; it stops once num_episodes episodes finished, pickles the reference's history keys and saves the models."""
+    trace = []
+    _StubTrainer.trace = trace
+    env, mem, cfg = _StubEnv(), _StubMemory(), _Args()
+    logs = []
+    hist = train_batched(env, 'actor', 'critic', _StubTrainer, 'simple_spread', 'Discrete', cnt=3, arglist=cfg, memory=mem,
+                         out_dir=str(tmp_path), log=lambda *a: logs.append(a), chunk=10,
+                         make_rollout=lambda e, actor, memory, seed: (_StubFused(trace), _StubRollout(e, memory, trace)))
+    kinds = [e[0] for e in trace]
+    assert kinds[0] == 'trainer_init' and kinds[-1] == 'save_models' and trace[-1] == ('save_models', 'simple_spread_fin_3')
+    n_chunks = kinds.count('collect')
+    assert n_chunks == 10                                   # 64 episodes = 4 per env: 100 steps = 10 chunks of 10
+    # gate: env-steps after chunk i = 160 i; openings in (160 (i-1), 160 i] beyond 1024
+    steps, want = 0, []
+    g = LearnGate(cfg)
+    for i in range(n_chunks):
+        want.append(('collect', 10, True))
+        due = g.due_between(steps, steps + 160)
+        steps += 160
+        want += [('optimize', steps)] * due + ([('refresh',)] if due else [])
+    assert trace[1:-1] == want
+    assert kinds.count('optimize') == g.due_between(0, 1600) == 6      # at 1100, 1200, ..., 1600 env-steps
+    assert hist['stats']['env_steps'] == 1600 and hist['stats']['updates'] == 6 and hist['stats']['episodes'] == 64
+    assert len(hist['reward_episodes']) == 64 and all(abs(x + 75.0) < 1e-9 for x in hist['reward_episodes'])
+    assert len(hist['reward_episodes_by_agents']) == 3 and len(hist['reward_episodes_by_agents'][0]) == 64
+    saved = pickle.load(open(tmp_path / 'history_simple_spread_3.pkl', 'rb'))
+    assert saved['reward_episodes'] == hist['reward_episodes']
+    assert any('mean episode reward' in str(a[0]) for a in logs)          # the report line at save_rate episodes
+    # a cap on the updates owed per chunk
+    trace.clear()
+    train_batched(env, 'actor', 'critic', _StubTrainer, 'simple_spread', 'Discrete', arglist=cfg, memory=_StubMemory(),
+                  out_dir=None, log=lambda *a: None, chunk=50, max_updates_per_chunk=2,
+                  make_rollout=lambda e, actor, memory, seed: (_StubFused(trace), _StubRollout(e, memory, trace)))
+    assert [e[0] for e in trace].count('optimize') == 2      # chunk 1: 800 env-steps (warm-up), chunk 2: 6 owed, 2 run
+    assert dims_from_env(env) == (10, 5, 'Discrete')
+
+
+@pytest.mark.gpu
+def test_entry_script_two_chunks_on_the_gpu(tmp_path):
+    """examples/train_batched.py end to end on cuda:0 with the stand-in learner: 256 envs, 50-step chunks, two chunks
+    (4 episodes per env), learner updates between them, history + model files written, actor weights changed."""
+    sys.path.insert(0, os.path.join(ROOT, 'examples'))
+    import train_batched as entry
+    from multiagent_rl_amd import arglist
+    saved = (arglist.num_episodes, arglist.save_rate, arglist.warmup_steps, arglist.batch_size)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        arglist.warmup_steps, arglist.batch_size = 1024, 1024
+        res = entry.main(['--scenario', 'simple_spread', '--envs', '256', '--agents', '3', '--episodes', '1024', '--chunk', '50',
+                          '--save-rate', '512', '--max-updates-per-chunk', '3', '--out-dir', str(tmp_path / 'Models')])
+    finally:
+        os.chdir(cwd)
+        arglist.num_episodes, arglist.save_rate, arglist.warmup_steps, arglist.batch_size = saved
+    (name, cnt, st), = res
+    assert name == 'simple_spread' and cnt == 0 and st['episodes'] == 1024 and st['env_steps'] == 100 * 256
+    assert st['updates'] == 6 and np.isfinite(st['mean_episode_reward']) and st['mean_episode_reward'] < 0
+    hist = pickle.load(open(tmp_path / 'Models' / 'history_simple_spread_0.pkl', 'rb'))
+    assert len(hist['reward_episodes']) == 1024 and len(hist['reward_episodes_by_agents']) == 3
+    assert abs(np.mean(hist['reward_episodes']) - st['mean_episode_reward']) < 1e-3 * abs(st['mean_episode_reward'])
+    assert os.path.exists(tmp_path / 'Models' / 'simple_spread_fin_0_actor.pt')
