@@ -180,7 +180,7 @@ int pw_rollout(pw_handle *h, const pw_step_io *io, int num_steps, void *stream);
  * pw_create initialises it from pw_dispatch_default() overlaid, once, with the PWORLD_* environment variables of the
  * creating process (for A/B runs of unmodified host programs: PWORLD_FORCE_GENERIC, PWORLD_NO_STREAM, PWORLD_NO_DUO,
  * PWORLD_FORCE_DUO, PWORLD_NO_QUAD, PWORLD_FORCE_QUAD, PWORLD_OBS_BLOCK, PWORLD_SPREAD_TRIO / PWORLD_TAG_TRIO,
- * PWORLD_P_PRIO, PWORLD_EPW, PWORLD_POLICY_V1 / PWORLD_POLICY_V2); pw_set_dispatch replaces it.  Results never depend
+ * PWORLD_P_PRIO, PWORLD_EPW, PWORLD_POLICY_V2 / PWORLD_POLICY_V3 / PWORLD_POLICY_V3J); pw_set_dispatch replaces it.  Results never depend
  * on it: every form produces the same bits (tests/test_gpu_parity.py runs them all against the oracle). */
 typedef struct pw_dispatch {
     uint32_t struct_size;  /* = sizeof(pw_dispatch); checked */
@@ -192,7 +192,8 @@ typedef struct pw_dispatch {
     int32_t trio;          /* -1 auto; 0 / 1: the three-wave variants of the duo kernels (spread: block-store forms, N >= 6) */
     int32_t p_prio;        /* -1 auto; >= 0: issue-priority bits of the duo kernels' waves (2 bits per wave; simple_tag: 0 / 1) */
     int32_t envs_per_wave; /* 0 auto; n >= 1: envs per wave, clamped to 64 / N */
-    int32_t policy_form;   /* 0 auto; 1 / 2 / 3: pw_policy_rollout_kernel / pw_policy_rollout2_kernel / pw_policy_rollout3_kernel */
+    int32_t policy_form;   /* 0 auto; 2 / 3: pw_policy_rollout2_kernel / pw_policy_rollout3_kernel; 4: pw_policy_rollout3j_kernel; 1: retired (PW_EINVAL)
+                            * (the third form with dense1 just in time: long agent axes, N <= 32) */
 } pw_dispatch;
 int pw_dispatch_default(pw_dispatch *d);                    /* every choice automatic */
 int pw_set_dispatch(pw_handle *h, const pw_dispatch *d);    /* between launches; the bound state is untouched */

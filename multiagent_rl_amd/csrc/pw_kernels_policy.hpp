@@ -638,11 +638,10 @@ __global__ void __launch_bounds__(512) pw_actor_fused_kernel(const ActorFusedArg
 // ------------------------------------------------------------------------------------------
 // Policy-in-the-loop rollout as ONE launch: T x (actor forward + Gumbel sampling + environment step) with the
 // observations, the sampled actions and the world state of a workgroup's 16 environments never leaving the
-// CU between steps.  Per step a workgroup runs actor_forward_wg on the observation rows it keeps in LDS,
-// then its first one or two waves advance the environments exactly as pw_spread_stream_kernel does (lane =
-// (env, agent); same expressions, same order, same bits) and write the step's outputs -- and the next
-// observation rows back into LDS.  HBM sees the outputs of a step once; there is no launch, no kernel
-// boundary and no weight-constant refill between steps (only the per-direction W_ih / W_hh tiles, from L2).
+// CU between steps (pw_kernels_policy2.hpp, pw_kernels_policy3.hpp, pw_kernels_policy3j.hpp hold the kernels).  The
+// environment lanes advance their envs exactly as pw_spread_stream_kernel does (lane = (env, agent); same expressions,
+// same order, same bits) and write the step's outputs -- and the next observation rows (or states) back into LDS.  HBM
+// sees the outputs of a step once; there is no launch and no kernel boundary between steps.
 // simple_spread fast-path configurations (local observation, homogeneous agents, L <= N), one 5-logit head.
 // ------------------------------------------------------------------------------------------
 struct PolicyRolloutArgs {
@@ -662,230 +661,9 @@ struct PolicyRolloutArgs {
     unsigned long long *scratch;    // [2 * gridDim.x + 1] words, zero before first use
 };
 
-template <int S1C, int NT, bool SINK>
-__global__ void __launch_bounds__(512) pw_policy_rollout_kernel(const PolicyRolloutArgs P)
-{
-    constexpr int LT = NT;  // NT > 0: N = L = NT at compile time (the environment loops unroll)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const ActorFusedArgs &A = P.A;
-    const StreamParams &V = P.V;
-    const ActorLds S = actor_carve(smem_raw, 4 * S1C);
-    const int N = NT ? NT : A.N, L = LT ? LT : V.L, D = A.D;
-    float *s_obs = reinterpret_cast<float *>(S.end);                       // [96][D] observation rows
-    int32_t *s_act = reinterpret_cast<int32_t *>(s_obs + kFusedRows * D);  // [96]
-    float2 *s_posb = reinterpret_cast<float2 *>(s_act + kFusedRows);       // [2 env waves][64]
-    float2 *s_lmb = s_posb + 2 * kWave;                                    // [E * L]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long env0 = (long)blockIdx.x * A.E;
-    const int envs_here = (int)((long)A.B - env0 < (long)A.E ? (long)A.B - env0 : (long)A.E);
-    const int rows_here = envs_here * N;
-    const long row_base = env0 * N;
-    const size_t BN = (size_t)A.B * N;
-
-    // ---- environment lanes: wave w < n_env_waves owns local envs [w * epw, ...), lane = e_loc * N + a
-    // balanced over the fewest waves that can hold E envs: N = 6 -> two waves of 8 envs (not 10 + 6)
-    const int epw_max = A.E < kWave / N ? A.E : kWave / N;
-    const int waves_full = (A.E + epw_max - 1) / epw_max;
-    const int epw = (A.E + waves_full - 1) / waves_full;
-    const int n_env_waves = (envs_here + epw - 1) / epw;
-    const bool env_wave = wave < n_env_waves;
-    int e_loc = lane / N, a = lane - e_loc * N;
-    int el = wave * epw + e_loc;                       // local env index in the workgroup
-    const bool live = env_wave && e_loc < epw && el < envs_here;
-    if (!live) { e_loc = 0; a = 0; el = env_wave ? wave * epw : 0; }  // idle lanes shadow lane 0, store nothing
-    const int base = e_loc * N, r = el * N + a;
-    const long env = env0 + el;
-    const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
-    float2 *s_pos = s_posb + (env_wave ? wave : 0) * kWave;
-    const float2 *pp = s_pos + base;
-    float2 *lmv = s_lmb + el * L;
-    const int la = a < L ? a : 0;
-
-    float px = 0.f, py = 0.f, vx = 0.f, vy = 0.f, olx = 0.f, oly = 0.f, best = 0.f;
-    int ep_step = 0;
-    uint32_t ep_count = 0;
-    uint64_t coll = 0, near = 0;
-    float ep_ret = 0.f;
-    double fin_sum = 0.0;
-    int fin_cnt = 0;
-    if (env_wave) {
-        if (SINK && P.episode_return && live && a == 0) ep_ret = P.episode_return[env];
-        px = V.pos_x[g]; py = V.pos_y[g]; vx = V.vel_x[g]; vy = V.vel_y[g];
-        ep_step = V.ep_step[env];
-        ep_count = V.ep_count[env];
-        if (L > 0) {
-            olx = V.lm_x[(size_t)env * L + la];
-            oly = V.lm_y[(size_t)env * L + la];
-            if (live) lmv[la] = make_float2(olx, oly);
-        }
-        if (live) s_pos[base + a] = make_float2(px, py);
-        wave_lds_sync();
-        stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
-        if (live) stream_write_obs<LT>(s_obs + r * D, L, lmv, px, py, vx, vy);
-    }
-    const float k = V.contact_margin, cf = V.contact_force, dt = V.dt, damp = V.damp, mass = V.mass;
-    const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
-    wg_lds_barrier();
-
-#ifdef PW_STAMPS
-    unsigned long long mt[4] = {0, 0, 0, 0}, m0 = 0, m1 = 0;
-#define PW_MSTAMP(i) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(m1)::"memory"); mt[i] += m1 - m0; m0 = m1; } while (0)
-#else
-#define PW_MSTAMP(i)
-#endif
-    for (int t = 0; t < P.T; ++t) {
-#ifdef PW_STAMPS
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(m0)::"memory");
-#endif
-        // ---- policy: observation rows (LDS) -> sampled action index per row (LDS)
-        actor_forward_wg<S1C>(A, S, s_obs, rows_here, envs_here, row_base, t == 0, t == 0, step0 + (uint64_t)t, nullptr,
-                              s_act);
-        PW_MSTAMP(0);
-        wg_lds_barrier();
-        PW_MSTAMP(1);
-        // ---- environment step (pw_spread_stream_kernel's arithmetic)
-        if (env_wave) {
-            const size_t tBN = (size_t)t * BN;
-            const int ai = s_act[r];
-            size_t slot = 0;
-            if (SINK && P.has_ring) {  // the observation the policy acted on (still in LDS) -> ring.obs
-                slot = (size_t)((P.ring_start + (int64_t)t * A.B + env) % P.ring.capacity);
-                if (live) {
-                    const float2 *src = reinterpret_cast<const float2 *>(s_obs + r * D);
-                    float2 *dst = reinterpret_cast<float2 *>(P.ring.obs + (slot * N + a) * D);
-                    for (int c = 0; c < D / 2; ++c) dst[c] = src[c];
-                    P.ring.act[slot * N + a] = (uint8_t)ai;
-                }
-            }
-            float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
-            float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
-            ux *= V.sens; uy *= V.sens;
-            if (V.fscale != 1.0f) { ux = V.fscale * ux; uy = V.fscale * uy; }
-            float fx = ux + 0.0f, fy = uy + 0.0f;
-            near_force_loop<uint64_t, float2>(live ? near : 0, pp, px, py, V.dist_min, k, cf, fx, fy);
-            vx = vx * damp; vy = vy * damp;
-            vx = vx + (fx / mass) * dt;
-            vy = vy + (fy / mass) * dt;
-            px = px + vx * dt;
-            py = py + vy * dt;
-            wave_lds_sync();
-            if (live) s_pos[base + a] = make_float2(px, py);
-            wave_lds_sync();
-            stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
-            const float own = sqrtf(best);
-            float rw = 0.0f;
-#pragma unroll(LT > 0 ? LT : 1)
-            for (int l = 0; l < L; ++l) rw -= __shfl(own, base + l, kWave);
-#pragma unroll(NT > 0 ? NT : 1)
-            for (int j = 0; j < N; ++j)
-                if ((coll >> j) & 1) rw -= 1.0f;
-            float acc = 0.0f;
-#pragma unroll(NT > 0 ? NT : 1)
-            for (int i = 0; i < N; ++i) acc += __shfl(rw, base + i, kWave);
-            ep_step += 1;
-            const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
-            if (live) {
-                if (P.act_out) P.act_out[tBN + g] = ai;
-                if (V.rew) V.rew[tBN + g] = rw;
-                if (V.done) V.done[tBN + g] = 0;
-                if (a == 0) {
-                    if (V.rew_shared) V.rew_shared[(size_t)t * A.B + env] = acc;
-                    if (V.terminal) V.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
-                }
-                if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
-                    stream_write_obs<LT>(P.ring.next_obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
-                    if (a == 0) { P.ring.rew[slot] = acc; P.ring.done[slot] = 0.0f; }
-                }
-                if (SINK && a == 0 && P.episode_return) {  // run.py:55-65, per env
-                    const float rsum = ep_ret + acc;
-                    if (term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
-                    else ep_ret = rsum;
-                }
-            }
-            if (term && V.auto_reset) {  // same for every lane of an env
-                if (live && V.final_obs) stream_write_obs<LT>(V.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
-                wave_lds_sync();
-                ep_count += 1;
-                ep_step = 0;
-                const uint64_t env_id = V.env_id_base + (uint64_t)env;
-                pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
-                vx = 0.f; vy = 0.f;
-                if (L > 0) {
-                    pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)(N + la), -1.0f, 1.0f, &olx, &oly);
-                    if (live) lmv[la] = make_float2(olx, oly);
-                }
-                if (live) s_pos[base + a] = make_float2(px, py);
-            }
-            wave_lds_sync();
-            if (V.auto_reset && __any(term))
-                stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
-            if (live) {
-                if (V.obs) stream_write_obs<LT>(V.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
-                stream_write_obs<LT>(s_obs + r * D, L, lmv, px, py, vx, vy);
-            }
-        } else if (t + 1 < P.T) {
-            // the other waves fetch the next pass's forward-direction weights meanwhile (their LDS tiles are idle)
-            const int nw = 8 - n_env_waves;
-            actor_fill_dir(A, S, 0, tid - n_env_waves * kWave, nw * kWave);
-        }
-        PW_MSTAMP(2);
-        wg_lds_barrier();
-        PW_MSTAMP(3);
-    }
-#ifdef PW_STAMPS
-    if (blockIdx.x == 0 && tid == 0)
-        for (int i_ = 0; i_ < 4; ++i_) g_pw_stamps[8 + i_] = mt[i_];
-#endif
-#undef PW_MSTAMP
-
-    if (live) {
-        V.pos_x[g] = px; V.pos_y[g] = py;
-        V.vel_x[g] = vx; V.vel_y[g] = vy;
-        if (L > 0 && a < L) {
-            V.lm_x[(size_t)env * L + la] = olx;
-            V.lm_y[(size_t)env * L + la] = oly;
-        }
-        if (a == 0) {
-            V.ep_step[env] = ep_step;
-            V.ep_count[env] = ep_count;
-            if (SINK && P.episode_return) P.episode_return[env] = ep_ret;
-        }
-    }
-    if (SINK && P.episode_return) {
-        // finished-episode statistics: fixed-order sum over this workgroup's envs, the partial into scratch, and the
-        // workgroup that arrives last adds the partials in index order (reproducible; no float atomics)
-        double *s_fs = reinterpret_cast<double *>(s_lmb + A.E * L);  // [16] (+ [16] ints): dynamic LDS, after the landmarks
-        int *s_fc = reinterpret_cast<int *>(s_fs + 16);
-        wg_lds_barrier();
-        if (live && a == 0) { s_fs[el] = fin_sum; s_fc[el] = fin_cnt; }
-        wg_lds_barrier();
-        if (tid == 0) {
-            double ws = 0.0;
-            long long wc = 0;
-            for (int i = 0; i < envs_here; ++i) { ws += s_fs[i]; wc += s_fc[i]; }
-            double *part_sum = reinterpret_cast<double *>(P.scratch);
-            long long *part_cnt = reinterpret_cast<long long *>(P.scratch + gridDim.x);
-            unsigned long long *ticket = P.scratch + 2 * gridDim.x;
-            part_sum[blockIdx.x] = ws;
-            part_cnt[blockIdx.x] = wc;
-            __threadfence();
-            if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1) {
-                __threadfence();
-                double ssum = 0.0;
-                long long scnt = 0;
-                for (unsigned i = 0; i < gridDim.x; ++i) {
-                    ssum += __builtin_nontemporal_load(part_sum + i);
-                    scnt += __builtin_nontemporal_load(part_cnt + i);
-                }
-                *P.finished_sum += ssum;
-                *P.finished_count += scnt;
-                *ticket = 0;
-            }
-        }
-    }
-}
+// (The first, phase-by-phase form of the rollout kernel -- pw_policy_rollout_kernel: actor_forward_wg per step, the environment
+// on the first waves -- was retired in round 4: since the third form and its just-in-time variant nothing selected it
+// automatically, and the forms that run are each compared with the CPU oracle directly.)
 
 // Test hook: evaluate one device math primitive element-wise so that tests can compare the exact bits
 // against the CPU contract (include/pworld_math.h, restated in oracle/pworld_oracle.c) over millions of

@@ -215,9 +215,9 @@ void dispatch_from_environment(pw_dispatch *d, int *actor_bf16x3)
     if (const char *e = std::getenv("PWORLD_TAG_TRIO")) d->trio = std::atoi(e) != 0;
     if (const char *e = std::getenv("PWORLD_P_PRIO")) d->p_prio = std::atoi(e) & 0xFFFF;
     if (const char *e = std::getenv("PWORLD_EPW")) d->envs_per_wave = std::atoi(e) >= 1 ? std::atoi(e) : 0;
+    if (std::getenv("PWORLD_POLICY_V3J")) d->policy_form = 4;
     if (std::getenv("PWORLD_POLICY_V3")) d->policy_form = 3;
     if (std::getenv("PWORLD_POLICY_V2")) d->policy_form = 2;
-    if (std::getenv("PWORLD_POLICY_V1")) d->policy_form = 1;
 }
 
 // Everything the selection decides ahead of a launch: envs per wave and which specialised paths apply.
@@ -691,7 +691,7 @@ int pw_set_dispatch(pw_handle *h, const pw_dispatch *d)
     if (!h || !d) return fail(PW_EINVAL, "null argument");
     if (d->struct_size != sizeof(pw_dispatch)) return fail(PW_EINVAL, "pw_dispatch.struct_size mismatch (ABI)");
     if (d->duo < -1 || d->duo > 1 || d->quad < -1 || d->quad > 1 || d->obs_block < -1 || d->obs_block > 1 || d->trio < -1 ||
-        d->trio > 1 || d->p_prio < -1 || d->p_prio > 0xFFFF || d->envs_per_wave < 0 || d->policy_form < 0 || d->policy_form > 3)
+        d->trio > 1 || d->p_prio < -1 || d->p_prio > 0xFFFF || d->envs_per_wave < 0 || d->policy_form < 0 || d->policy_form > 4)
         return fail(PW_EINVAL, "pw_dispatch field out of range");
     h->disp = *d;
     h->disp.force_generic = d->force_generic != 0;

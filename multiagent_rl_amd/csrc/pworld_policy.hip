@@ -25,6 +25,7 @@
 #include "pw_kernels_actor16.hpp"
 #include "pw_kernels_policy2.hpp"
 #include "pw_kernels_policy3.hpp"
+#include "pw_kernels_policy3j.hpp"
 #include "pw_kernels_policy_tag.hpp"
 #include "pw_kernels_policy_ref.hpp"
 
@@ -57,18 +58,13 @@ int pw_actor_head(const float *H, const float *w2, const float *b2, int64_t rows
 }
 
 namespace {
-int &actor_bf16x3_flag()
-{
-    static int flag = 0;  // process-wide, off unless pw_actor_set_bf16x3 turns it on (no environment reads outside pw_create)
-    return flag;
-}
+int g_actor_bf16x3 = 0;  // process-wide, off unless pw_actor_set_bf16x3 turns it on (no environment reads)
 }  // namespace
 
 int pw_actor_set_bf16x3(int32_t on)
 {
-    int &f = actor_bf16x3_flag();
-    const int prev = f;
-    f = on != 0;
+    const int prev = g_actor_bf16x3;
+    g_actor_bf16x3 = on != 0;
     return prev;
 }
 
@@ -89,7 +85,7 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
     a.B = (int)B; a.N = N; a.D = in_dim; a.relu_out = relu_out; a.n_out0 = n_out0; a.n_out1 = n_out1;
     a.E = 96 / N < 16 ? 96 / N : 16;
     a.seed = seed; a.step = step; a.step_dev = step_dev; a.H = H; a.logits = logits; a.act = act;
-    a.bf16x3 = actor_bf16x3_flag();  // honoured by the 16x16x4-core kernel (N <= 16) only
+    a.bf16x3 = g_actor_bf16x3;  // honoured by the 16x16x4-core kernel (N <= 16) only
     const int S1C = (in_dim + 7) / 8, S1 = 4 * S1C;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // N <= 16: the BiLSTM on v_mfma_f32_16x16x4_f32 (pw_kernels_actor16.hpp), 16 environments per workgroup whatever N is; same
@@ -263,32 +259,58 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     }
     const int S1C = (kp.D + 7) / 8, S1 = 4 * S1C;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // Three forms.  pw_policy_rollout_kernel: workgroup-wide phases, weights refilled through LDS, 16 envs per workgroup,
-    // LDS bounds the observation length (D <= 36).  pw_policy_rollout2_kernel (pw_kernels_policy2.hpp): role-specialised
-    // waves, weights resident in registers, as many environments per workgroup as fit 160 KB of LDS (D <= 64: N <= 30).
-    // pw_policy_rollout3_kernel (pw_kernels_policy3.hpp): the whole BiLSTM on v_mfma_f32_16x16x4_f32, one timestep per
-    // barrier, 16 environments per workgroup at any N; its dense1 output takes 4 KB of LDS per agent, so the environments per
-    // workgroup shrink past N = 12.  Measured at B = 4096, us per step, forms 1 / 2 / 3 (profiles/r3_policy_phases.txt):
-    // N = 3: 15.9 / 13.7 / 8.5; N = 6: 23.2 / 21.0 / 13.9; N = 12: 65.3 / 64.8 / 32.5; N = 16: 113.7 / 165.0 / 86.4;
-    // N = 24: - / 404 / 485 -- the third form runs wherever it keeps >= 8 environments per workgroup, then the old rule
-    // (the second where it wins, N <= 6, or where the first does not fit).  pw_dispatch.policy_form overrides.
-    const size_t shm = actor_lds_bytes(S1) + (size_t)kFusedRows * kp.D * sizeof(float) + kFusedRows * sizeof(int32_t) +
-                       2 * kWave * sizeof(float2) + (size_t)a.E * kp.L * sizeof(float2) + 16 * (sizeof(double) + sizeof(int));
-    const bool v1_fits = shm <= 160 * 1024;
+    // Kernel forms.  pw_policy_rollout2_kernel (pw_kernels_policy2.hpp): role-specialised waves, weights resident in registers, as
+    // many environments per workgroup as fit 160 KB of LDS (D <= 64: N <= 30).  pw_policy_rollout3_kernel
+    // (pw_kernels_policy3.hpp): the whole BiLSTM on v_mfma_f32_16x16x4_f32, one timestep per barrier, 16 environments per
+    // workgroup at any N; its dense1 output takes 4 KB of LDS per agent, so the environments per workgroup shrink past N = 12.
+    // pw_policy_rollout3j_kernel (pw_kernels_policy3j.hpp): the same with dense1 just in time.  (A first, phase-by-phase form --
+    // policy_form 1 -- was retired in 0.1.5: nothing selected it.)  pw_dispatch.policy_form overrides the choice.
     const int form = h->disp.policy_form;
+    if (form == 1)
+        return fail(PW_EINVAL, "policy_form 1 (the phase-by-phase rollout kernel) was retired in 0.1.5; use 0 (automatic), 2, 3 or 4");
     int E3 = 0;
     for (int e = kp.B < 16 ? kp.B : 16; e >= 1; --e)  // 16 MFMA columns = 16 environments whatever N is (no 96-row limit here)
         if (roll3_lds_bytes(e, kp.N, kp.L, kp.D, S1) <= 160 * 1024) { E3 = e; break; }
-    bool use_v3 = form == 3 ? E3 > 0 : form == 0 ? E3 >= (kp.B < 8 ? kp.B : 8) : (form == 1 && !v1_fits && E3 >= 8);
-    bool use_v2 = !use_v3 && (!v1_fits || kp.N <= 6 || form >= 2);
-    if (form == 1 && v1_fits) { use_v2 = false; use_v3 = false; }
+    const int full = kp.B < 16 ? kp.B : 16;     // environments per workgroup that fill the 16 MFMA columns
+    bool use_v3 = form == 3 ? E3 > 0 : form == 0 && E3 >= full;
+    // Long agent axes: the third form with dense1 just in time and no observation rows in LDS (pw_kernels_policy3j.hpp) keeps 16
+    // environments per workgroup up to N = 24 and >= 12 up to N = 30, where the plain third form has to drop columns (N >= 13)
+    // and the second form costs 400 us per step (N = 24).  us per step at B = 4096, forms 2 / 3 / 3j (profiles/r4_policy_forms.txt):
+    // N = 12: 67 / 33.0 / 34.1; N = 14: 111 / 77 / 39.8; N = 16: 170 / 89 / 48.1; N = 20: 270 / 211 / 59.7; N = 24: 414 / 495 / 76.7;
+    // N = 30: 494 / - / 194.  Automatic wherever the plain third form does not keep its 16 columns busy; policy_form 4 forces it
+    // (tests run it at small N too).
+    int E3j = 0;
+    if (kp.N <= 32 && kp.D == 4 + 2 * kp.L && kp.L <= kp.N && !a.bf16x3 && (form == 4 || (form == 0 && !use_v3)))
+        for (int e = kp.B < 16 ? kp.B : 16; e >= 1; --e)
+            if (roll3j_lds_bytes(e, kp.N, kp.L) <= 160 * 1024) { E3j = e; break; }
+    if (form == 4 && E3j == 0) return fail(PW_EINVAL, "policy_form 4 (just-in-time dense1) serves N <= 32 with the local observation");
+    if (form == 0 && !use_v3 && E3j < (kp.B < 8 ? kp.B : 8) && E3 >= (kp.B < 8 ? kp.B : 8)) use_v3 = true;  // the round-3 rule
+    if (!use_v3 && E3j > 0 && (form == 4 || E3j >= (kp.B < 8 ? kp.B : 8))) {
+        a.E = E3j;
+        const size_t shmj = roll3j_lds_bytes(E3j, kp.N, kp.L);
+        const unsigned gridj = (unsigned)((kp.B + E3j - 1) / E3j);
+#define PW_R3J2(C, SK)                                                                                                   \
+    do {                                                                                                                 \
+        static unsigned long long attr_setj = 0; /* bit = device */                                                      \
+        PW_LDS_OPTIN(&attr_setj, (pw_policy_rollout3j_kernel<C, SK>));                                                   \
+        hipLaunchKernelGGL((pw_policy_rollout3j_kernel<C, SK>), dim3(gridj), dim3(512), shmj, st, P);                    \
+    } while (0)
+#define PW_R3J(C) case C: if (sink) PW_R3J2(C, true); else PW_R3J2(C, false); break;
+        switch (S1C) { PW_R3J(1) PW_R3J(2) PW_R3J(3) PW_R3J(4) PW_R3J(5) PW_R3J(6) PW_R3J(7) PW_R3J(8) }
+#undef PW_R3J2
+#undef PW_R3J
+        PW_HIP_CHECK(hipGetLastError());
+        h->last_kernel = "pw_policy_rollout3j_kernel";
+        return PW_OK;
+    }
+    const bool use_v2 = !use_v3;
     if (a.bf16x3 && !use_v3)
         return fail(PW_EINVAL, "PW_ACTOR_BF16X3 needs the third kernel form (policy_form 0 or 3, N <= 16 with 8+ environments per workgroup)");
     int E2 = use_v3 ? E3 : 0;
     if (use_v2) {
         for (int e = a.E; e >= 1; --e)
             if (roll2_lds_bytes(e, kp.N, kp.L, kp.D, S1) <= 160 * 1024) { E2 = e; break; }
-        if (E2 == 0 && !v1_fits) return fail(PW_EINVAL, "observation too long for the one-launch rollout (LDS)");
+        if (E2 == 0) return fail(PW_EINVAL, "observation too long for the one-launch rollout (LDS)");
     }
     if (E2 > 0) {
         a.E = E2;
@@ -324,26 +346,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         h->last_kernel = use_v3 ? (a.bf16x3 ? "pw_policy_rollout3_kernel<bf16x3>" : "pw_policy_rollout3_kernel") : "pw_policy_rollout2_kernel";
         return PW_OK;
     }
-    const unsigned grid = (unsigned)((kp.B + a.E - 1) / a.E);
-#define PW_PR3(C, NT, SK)                                                                                                \
-    do {                                                                                                                 \
-        static unsigned long long attr_set = 0; /* bit = device */                                            \
-        PW_LDS_OPTIN(&attr_set, (pw_policy_rollout_kernel<C, NT, SK>)); \
-        hipLaunchKernelGGL((pw_policy_rollout_kernel<C, NT, SK>), dim3(grid), dim3(512), shm, st, P);                    \
-    } while (0)
-#define PW_PR2(C, NT) do { if (sink) PW_PR3(C, NT, true); else PW_PR3(C, NT, false); } while (0)
-#define PW_PR(C) case C: PW_PR2(C, 0); break;
-    if (kp.N == 6 && kp.L == 6) PW_PR2(2, 6);        // BASELINE configs[1]: D = 16
-    else if (kp.N == 3 && kp.L == 3) PW_PR2(2, 3);   // configs[0]: D = 10
-    else switch (S1C) {
-        PW_PR(1) PW_PR(2) PW_PR(3) PW_PR(4) PW_PR(5) PW_PR(6) PW_PR(7) PW_PR(8)
-    }
-#undef PW_PR3
-#undef PW_PR2
-#undef PW_PR
-    PW_HIP_CHECK(hipGetLastError());
-    h->last_kernel = "pw_policy_rollout_kernel";
-    return PW_OK;
+    return fail(PW_EINVAL, "observation too long for the one-launch rollout (LDS)");
 }
 
 int pw_rollout_tail(const float *rew_shared, const uint8_t *terminal, int32_t B, float *episode_return,

@@ -1,7 +1,7 @@
 """GPU: the one-launch policy rollouts (pw_policy_rollout: actor + Gumbel sampling + env step for a whole chunk in
 ONE kernel) anchored DIRECTLY on the CPU oracle.
 
-Every rollout kernel (forms 1 / 2 / 3 of simple_spread, the simple_tag and the simple_reference kernels) carries its
+Every rollout kernel (forms 2 / 3 / 3j of simple_spread, the simple_tag and the simple_reference kernels) carries its
 own copy of the environment step.  tests/test_gpu_engine.py compares them with the FusedActor() + env.step() loop --
 HIP against HIP.  Here the actions a launch sampled (``out['act']``, an output) are replayed through the float32 C
 oracle from the same Philox reset, and every environment output of the launch -- observations, per-agent rewards,
@@ -19,8 +19,9 @@ torch = pytest.importorskip('torch')
 from oracle import c_oracle as co  # noqa: E402  (checker only)
 from tests.test_gpu_parity import _assert_same_bits, _np  # noqa: E402
 
-FORMS = dict(default=0, v1=1, v2=2, v3=3)
-KERNEL_OF_FORM = {1: 'pw_policy_rollout_kernel', 2: 'pw_policy_rollout2_kernel', 3: 'pw_policy_rollout3_kernel'}
+FORMS = dict(default=0, v2=2, v3=3, v3j=4)
+KERNEL_OF_FORM = {2: 'pw_policy_rollout2_kernel', 3: 'pw_policy_rollout3_kernel',
+                  4: 'pw_policy_rollout3j_kernel'}
 
 
 def _replay_through_oracle(o32, got, T, two_head=False):
@@ -57,15 +58,13 @@ def _assert_final_state(env, o32, extra=()):
         _assert_same_bits(_np(st[k]), getattr(o32, k), k)
 
 
-@pytest.mark.parametrize('form', ['default', 'v1', 'v2', 'v3'])
-@pytest.mark.parametrize('B,N,T', [(4096, 6, 53), (100, 3, 60), (37, 7, 27), (9, 12, 26), (33, 16, 26), (7, 24, 5)],
-                         ids=['C2', 'N3', 'N7', 'N12', 'N16', 'N24'])
+@pytest.mark.parametrize('form', ['default', 'v2', 'v3', 'v3j'])
+@pytest.mark.parametrize('B,N,T', [(4096, 6, 53), (100, 3, 60), (37, 7, 27), (9, 12, 26), (33, 16, 26), (7, 24, 5), (520, 24, 53),
+                                   (19, 30, 27)], ids=['C2', 'N3', 'N7', 'N12', 'N16', 'N24', 'N24-B520', 'N30'])
 def test_spread_policy_rollout_outputs_equal_the_oracle_on_its_own_actions(B, N, T, form):
     """simple_spread, every kernel form (C2 at full size: B = 4096, N = 6, 53 steps across two auto-resets)."""
     from multiagent_rl_amd import make_batched_env
     from multiagent_rl_amd.policy import ActorNetwork, FusedActor
-    if form == 'v1' and N > 16:
-        pytest.skip('the phase-by-phase kernel holds observation rows of D <= 36 (N <= 16)')
     torch.manual_seed(4)
     env = make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=25, seed=21)
     env.set_dispatch(policy_form=FORMS[form])
@@ -74,8 +73,8 @@ def test_spread_policy_rollout_outputs_equal_the_oracle_on_its_own_actions(B, N,
     actor = FusedActor(ActorNetwork(env.obs_dim, 5).cuda().eval(), seed=9)
     _assert_same_bits(_np(env.reset()), o32.reset(), 'reset obs')
     got = actor.rollout(env, T)
-    if form == 'default':                 # automatic choice: form 3 wherever 8+ environments per workgroup fit its LDS
-        assert env.last_kernel() == KERNEL_OF_FORM[3 if N <= 16 else 2], env.last_kernel()
+    if form == 'default':                 # automatic choice: form 3 wherever 16 environments per workgroup fit its LDS,
+        assert env.last_kernel() == KERNEL_OF_FORM[3 if N <= 12 else 4], env.last_kernel()   # its just-in-time variant beyond
     elif not (form == 'v3' and N > 16):
         assert env.last_kernel() == KERNEL_OF_FORM[FORMS[form]], env.last_kernel()
     a = _np(got['act'])
