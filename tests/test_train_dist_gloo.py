@@ -1,0 +1,131 @@
+"""CPU, gloo, world_size 2: the multi-rank form of multiagent_rl_amd.train.train_batched -- every rank rolls out its shard into
+the full gather's wire block, rank 0 owns the ring and the learner, the actor goes back to every rank as one flat broadcast after
+each batch of updates.  The HIP pieces (rollout launch, wire finalize / ingest) are the torch stand-ins of tests/dist_standins.py
+and a stub rollout; what is under test is the control flow of train.py over torch.distributed."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.test_dist_gloo import B, N, T, _SpreadEnv, _free_port, episode_number, landmarks_of, spread_chunk, spread_start
+
+
+class _Cfg(object):
+    max_episode_len, num_episodes, is_training = 3, 40, True
+    batch_size, warmup_steps, update_rate, save_rate, display = 8, 0, 20, 16, False
+
+
+class _Space(object):
+    n, shape = 5, (10,)
+
+
+class _Trainer(object):
+    """Trainer surface of experiments/run.py:21,81,102; `optimize` nudges one weight on the learner rank."""
+    last = None
+
+    def __init__(self, actor, critic, memory, action_type='Discrete'):
+        self.actor, self.memory, self.calls, self.saved = actor, memory, [], []
+        _Trainer.last = self
+
+    def optimize(self):
+        self.calls.append(len(self.memory))
+        with torch.no_grad():
+            self.actor.dense2.module.bias += 1.0
+
+    def save_models(self, name):
+        self.saved.append(name)
+
+
+class _Fused(object):
+    """FusedActor's surface as train_batched uses it with a gather: rollout(env, T, out, stats=...) and refresh()."""
+
+    def __init__(self, env, rank):
+        self.env, self.rank, self.k, self.refreshed = env, rank, 0, 0
+        env.start = spread_start(rank)
+
+    def rollout(self, env, chunk, out, stats=None):
+        src = spread_chunk(self.rank, self.k, self.k * T)
+        for name in ('obs', 'rew_shared', 'terminal', 'act', 'final_obs'):
+            out[name].copy_(src[name])
+        stats[2].add_(int(src['terminal'].sum()))                       # finished episodes of this rank
+        self.k += 1
+        e = torch.arange(B)
+        ep = episode_number(e, self.k * T)
+        env.start = (src['obs'][T - 1][..., :4].clone(), landmarks_of(self.rank, e, ep), ep)    # the next chunk's start
+
+    def refresh(self):
+        self.refreshed += 1
+
+
+class _Rollout(object):
+    def __init__(self, env):
+        self.obs = torch.zeros(B, N, 10)
+        self.env_steps = 0
+        self.episode_return = torch.zeros(B)
+        self.finished_return_sum = torch.zeros((), dtype=torch.float64)
+        self.finished_episodes = torch.zeros((), dtype=torch.int64)
+
+    def stats(self):
+        n = int(self.finished_episodes)
+        return dict(env_steps=self.env_steps, episodes=n, mean_episode_reward=0.0)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from multiagent_rl_amd.policy import ActorNetwork
+    from multiagent_rl_amd.train import train_batched
+    from tests.dist_standins import CpuFullGather
+    env = _SpreadEnv(rank)
+    env.observation_space, env.action_space = [_Space()] * N, [_Space()] * N
+    torch.manual_seed(100 + rank)                                       # the ranks start from DIFFERENT weights
+    actor = ActorNetwork(10, 5)
+    gather = CpuFullGather(env, T, rank, world, 'cpu')
+    fused = _Fused(env, rank)
+    hist = train_batched(env, actor, None, _Trainer, 'simple_spread', 'Discrete', cnt=0, arglist=_Cfg(), out_dir=None,
+                         log=lambda *a: None, chunk=T, gather=gather, rank=rank, world=world,
+                         make_rollout=lambda e, a, m, s: (fused, _Rollout(e)))
+    tr = _Trainer.last
+    q.put(dict(rank=rank, chunks=fused.k, optimize=tr.calls, refreshed=fused.refreshed, saved=tr.saved,
+               bias=actor.dense2.module.bias.detach().clone().numpy(), w1=actor.dense1.module.weight.detach().clone().numpy(),
+               ring=None if rank else sum(t['rew'].shape[0] for t in gather.memory.transitions),
+               stats=hist['stats'], memory_is_ring=tr.memory is gather.memory))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_train_batched_over_two_ranks():
+    if torch.cuda.device_count() > 0:
+        pytest.skip('CPU-container test: it spawns worker processes')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r['rank'])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    r0, r1 = res
+    # both ranks ran the same number of chunks (their shards end episodes in the same steps) and stopped together
+    assert r0['chunks'] == r1['chunks'] >= 3 and r0['stats']['episodes'] >= 40
+    chunks = r0['chunks']
+    # the learner lives on rank 0 only: 2 ranks x 5 steps x 8 envs = 80 env-steps per chunk -> 4 gate openings per chunk; after the
+    # FIRST chunk the ring is still empty (the gather completes one chunk late), so those four are skipped, not run on nothing
+    updates = 4 * (chunks - 1)
+    assert r1['optimize'] == [] and len(r0['optimize']) == updates and r0['stats']['updates'] == updates
+    assert r0['memory_is_ring'] and r0['saved'] == ['simple_spread_fin_0'] and r1['saved'] == []
+    # the ring the learner samples holds every transition of BOTH ranks up to the previous chunk
+    assert r0['optimize'][0] == 2 * T * B and r0['optimize'][4] == 2 * 2 * T * B and r0['ring'] == 2 * chunks * T * B
+    # after every batch of updates the learner rank's actor went to every rank: rank 1 ends with rank 0's weights
+    assert (r0['bias'] == r1['bias']).all() and (r0['w1'] == r1['w1']).all()
+    torch.manual_seed(100)
+    from multiagent_rl_amd.policy import ActorNetwork
+    want = ActorNetwork(10, 5)
+    assert (r0['w1'] == want.dense1.module.weight.detach().numpy()).all()
+    assert abs(float(r0['bias'][0]) - (float(want.dense2.module.bias[0].detach()) + updates)) < 1e-4
+    assert r0['refreshed'] == r1['refreshed'] == chunks                 # broadcast_actor(..., fused=...) refreshes the snapshot
