@@ -672,7 +672,8 @@ def _compact_summary(other, policy):
     if isinstance(policy, dict) and policy.get('value'):
         parts = []
         rf = policy.get('roofline') or {}
-        parts.append('C2 %.3g mfma %.2f' % (policy['value'], rf.get('frac', float('nan'))) if rf else 'C2 %.3g' % policy['value'])
+        lab = policy.get('label', 'C2')
+        parts.append('%s %.3g mfma %.2f' % (lab, policy['value'], rf.get('frac', float('nan'))) if rf else '%s %.3g' % (lab, policy['value']))
         for o in policy.get('other_scenarios') or []:
             if 'value' in o:
                 parts.append('%s %.3g %.2f' % (short(o['config']), o['value'], (o.get('roofline') or {}).get('frac', float('nan'))))
@@ -815,7 +816,8 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
         ro = BatchedRollout(penv, actor, ReplayBuffer(1e6, N, penv.obs_dim))
         tp, tp_ev = timed_collect(ro, n_chunks)
         line = dict(value=B * n_chunks * Tp / tp, unit='env-steps/s', us_per_step=tp / (n_chunks * Tp) * 1e6,
-                    steps=n_chunks * Tp, policy=label, actor_precision=penv.get_actor_precision(),
+                    steps=n_chunks * Tp, policy=label, label='C2' if (N, B) == (6, 4096) else 'N%d B%d' % (N, B),
+                    actor_precision=penv.get_actor_precision(),
                     exact=penv.get_actor_precision() == 'f32',
                     loop='%d-step chunks, one launch each: pw_policy_rollout (actor + sampling + env step + device '
                          'replay append + episode stats)' % Tp,

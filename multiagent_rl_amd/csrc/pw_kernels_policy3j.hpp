@@ -1,5 +1,5 @@
 // pw_kernels_policy3j.hpp -- part of libpworld.so (translation unit csrc/pworld_policy.hip includes it).
-// Policy-in-the-loop rollout, third form for LONG agent axes (N = 13 .. 32): the BiLSTM of pw_kernels_policy3.hpp with
+// Policy-in-the-loop rollout, third form for LONG agent axes (N = 13 .. 50): the BiLSTM of pw_kernels_policy3.hpp with
 // dense1 computed JUST IN TIME, one timestep per direction per loop iteration, and no observation rows in LDS.
 #pragma once
 
@@ -28,7 +28,9 @@ namespace {
 // The environment step runs undeferred here (every wave has environment duty at these N, and its work is a few per cent of a
 // pass of 2 x N x 62 matrix instructions per wave).
 // LDS (N = 24, L = 24, E = 16): 16 KB x1 ring + 8 KB h exchange + 96 KB head input + 6 KB states + 7.7 KB noise + 3 KB
-// landmarks + small = 143 KB.  Serves simple_spread with the local observation (D = 4 + 2 L <= 64), N <= 32.
+// landmarks + small = 143 KB.  Serves simple_spread with the local observation, D = 4 + 2 L <= 104 (W1's fragments: up to 26
+// VGPRs), at most 8 environment waves of whole environments: 16 environments per workgroup up to N = 24, 13 at N = 30, 8 at
+// N = 33 .. 50 (BASELINE's C5 point N = L = 48: D = 100, the only form that holds such rows).
 // ------------------------------------------------------------------------------------------
 struct Roll3jLds {
     float4 *s_xf;    // [2 buffers][2 dir][4 j][64 lane]: x1 fragments of one timestep per (buffer, direction)
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
     const int epw_max = E < kWave / N ? E : kWave / N;
     const int waves_full = (E + epw_max - 1) / epw_max;
     const int epw = (E + waves_full - 1) / waves_full;
-    const int n_env_waves = (envs_here + epw - 1) / epw;  // <= 8 (N <= 32)
+    const int n_env_waves = (envs_here + epw - 1) / epw;  // <= 8 (the host caps E at 8 * (64 / N))
     const int ew = wave - (8 - n_env_waves);
     const bool env_wave = ew >= 0;
     int e_loc = lane / N, a = lane - e_loc * N;

@@ -173,7 +173,9 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     if (!h->fast && !tag)
         return fail(PW_EINVAL, "pw_policy_rollout serves the simple_spread fast-path configurations (local observation, "
                                "homogeneous agents, L <= N) and simple_tag with homogeneous roles");
-    if (kp.N > 64 || kp.D > 64) return fail(PW_EINVAL, "N and the observation length must be <= 64");
+    // observation rows longer than 64 numbers (simple_spread N = L > 30) are served by the just-in-time form alone (D <= 104)
+    const bool wide = kp.D > 64;
+    if (kp.N > 64 || kp.D > 104) return fail(PW_EINVAL, "N must be <= 64 and the observation length <= 104");
     if (io->act_idx || io->act_vec || io->act_comm || io->coll)
         return fail(PW_EINVAL, "pw_policy_rollout produces the actions itself (act_out) and has no coll output");
     const bool have_sink = sink && sink->ring;
@@ -280,12 +282,17 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     // N = 30: 494 / - / 194.  Automatic wherever the plain third form does not keep its 16 columns busy; policy_form 4 forces it
     // (tests run it at small N too).
     int E3j = 0;
-    if (kp.N <= 32 && kp.D == 4 + 2 * kp.L && kp.L <= kp.N && !a.bf16x3 && (form == 4 || (form == 0 && !use_v3)))
-        for (int e = kp.B < 16 ? kp.B : 16; e >= 1; --e)
+    if (!tag && kp.D == 4 + 2 * kp.L && kp.L <= kp.N && !a.bf16x3 && (form == 4 || (form == 0 && !use_v3))) {
+        const int ecap = 8 * (kWave / kp.N) < 16 ? 8 * (kWave / kp.N) : 16;   // at most 8 environment waves of whole environments
+        for (int e = kp.B < ecap ? kp.B : ecap; e >= 1; --e)
             if (roll3j_lds_bytes(e, kp.N, kp.L) <= 160 * 1024) { E3j = e; break; }
-    if (form == 4 && E3j == 0) return fail(PW_EINVAL, "policy_form 4 (just-in-time dense1) serves N <= 32 with the local observation");
+    }
+    if (form == 4 && E3j == 0) return fail(PW_EINVAL, "policy_form 4 (just-in-time dense1) serves the local observation with L <= N");
+    if (wide && (E3j == 0 || (form != 0 && form != 4)))
+        return fail(PW_EINVAL, "observation rows longer than 64 numbers are served by the just-in-time rollout form only (policy_form 0 or 4)");
+    if (wide) use_v3 = false;
     if (form == 0 && !use_v3 && E3j < (kp.B < 8 ? kp.B : 8) && E3 >= (kp.B < 8 ? kp.B : 8)) use_v3 = true;  // the round-3 rule
-    if (!use_v3 && E3j > 0 && (form == 4 || E3j >= (kp.B < 8 ? kp.B : 8))) {
+    if (!use_v3 && E3j > 0 && (form == 4 || wide || E3j >= (kp.B < 8 ? kp.B : 8))) {
         a.E = E3j;
         const size_t shmj = roll3j_lds_bytes(E3j, kp.N, kp.L);
         const unsigned gridj = (unsigned)((kp.B + E3j - 1) / E3j);
@@ -296,7 +303,10 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         hipLaunchKernelGGL((pw_policy_rollout3j_kernel<C, SK>), dim3(gridj), dim3(512), shmj, st, P);                    \
     } while (0)
 #define PW_R3J(C) case C: if (sink) PW_R3J2(C, true); else PW_R3J2(C, false); break;
-        switch (S1C) { PW_R3J(1) PW_R3J(2) PW_R3J(3) PW_R3J(4) PW_R3J(5) PW_R3J(6) PW_R3J(7) PW_R3J(8) }
+        switch (S1C) {
+            PW_R3J(1) PW_R3J(2) PW_R3J(3) PW_R3J(4) PW_R3J(5) PW_R3J(6) PW_R3J(7) PW_R3J(8)
+            PW_R3J(9) PW_R3J(10) PW_R3J(11) PW_R3J(12) PW_R3J(13)     // D = 65 .. 104 (N = L = 31 .. 50)
+        }
 #undef PW_R3J2
 #undef PW_R3J
         PW_HIP_CHECK(hipGetLastError());
@@ -418,10 +428,14 @@ size_t pw_actor_front_pack_floats(int32_t in_dim) { return actor_frag16_offset((
 int pw_actor_front_pack(const float *w1, const float *w_ih, int32_t in_dim, float *frag, void *stream)
 {
     if (!w1 || !w_ih || !frag) return fail(PW_EINVAL, "null argument");
-    if (in_dim < 1 || in_dim > 64) return fail(PW_EINVAL, "in_dim must be in [1, 64]");
+    // in_dim <= 64: every consumer; 65 .. 104: the W1 image is wider (S1 = 4 * ceil(in_dim / 8) k steps) and only the just-in-time
+    // rollout form (pw_policy_rollout3j_kernel: simple_spread up to N = L = 50) reads it
+    if (in_dim < 1 || in_dim > 104) return fail(PW_EINVAL, "in_dim must be in [1, 104]");
     if ((reinterpret_cast<uintptr_t>(w_ih) | reinterpret_cast<uintptr_t>(frag)) & 15)
         return fail(PW_EINVAL, "w_ih and frag must be 16-byte aligned");
-    hipLaunchKernelGGL(pw_actor_front_pack_kernel, dim3(16), dim3(256), 0, static_cast<hipStream_t>(stream), w1, w_ih, in_dim, frag);
+    const unsigned w1_threads = 2u * (unsigned)(((in_dim + 7) >> 3) * 4) * 64u;   // the W1 section; the other two take 4096 threads
+    const unsigned pack_blocks = w1_threads > 4096u ? (w1_threads + 255u) / 256u : 16u;
+    hipLaunchKernelGGL(pw_actor_front_pack_kernel, dim3(pack_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w1, w_ih, in_dim, frag);
     PW_HIP_CHECK(hipGetLastError());
     return PW_OK;
 }

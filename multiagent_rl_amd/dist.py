@@ -269,6 +269,9 @@ class FullTransitionGather(object):
         self.max_episode_len = int(env.cfg.max_episode_len) if hasattr(env, 'cfg') else int(env.max_episode_len)
         if wire not in ('auto', 'state', 'rows'):
             raise ValueError("wire must be 'auto', 'state' or 'rows'")
+        if hasattr(env, 'cfg') and self.max_episode_len > 0 and not env.cfg.auto_reset:
+            raise ValueError('FullTransitionGather needs an auto-resetting env: the blocks carry the pre-reset observation (state) of '
+                             'every episode end, which only the in-kernel reset writes')
         fits = self._state_wire_applies(env)
         if wire == 'state' and not fits:
             raise ValueError('state-only wire blocks serve simple_spread with the local observation (D = 4 + 2L)')

@@ -89,6 +89,44 @@ def test_spread_policy_rollout_outputs_equal_the_oracle_on_its_own_actions(B, N,
     _assert_final_state(env, o32)
 
 
+@pytest.mark.parametrize('B,N,T', [(24, 48, 27), (11, 33, 26), (70, 40, 4)], ids=['N48', 'N33', 'N40'])
+def test_spread_policy_rollout_with_rows_longer_than_64_numbers(B, N, T):
+    """BASELINE configs[4]'s largest point with the policy in the loop: N = L = 48 (D = 100).  Only the just-in-time form holds
+    such rows (8 environments per workgroup); its outputs equal the oracle's on its own actions bit for bit, and -- with a
+    sharpened head, so that the Gumbel noise cannot decide -- its actions are the arg-max of PyTorch's float32 logits on the
+    oracle's observation rows (the per-step FusedActor does not serve D > 64, so this is the actor's own check here)."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    torch.manual_seed(8)
+    env = make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=25, seed=33)
+    cfg = co.make_config('simple_spread', N, max_episode_len=25, auto_reset=True, seed=33)
+    o32 = co.COracle(cfg, B, np.float32)
+    net = ActorNetwork(env.obs_dim, 5).cuda().eval()
+    with torch.no_grad():
+        net.dense2.module.weight *= 2e5
+        net.dense2.module.bias *= 2e5
+    actor = FusedActor(net, seed=9)
+    obs0 = o32.reset()
+    _assert_same_bits(_np(env.reset()), obs0, 'reset obs')
+    got = actor.rollout(env, T)
+    assert env.last_kernel() == 'pw_policy_rollout3j_kernel', env.last_kernel()
+    assert _replay_through_oracle(o32, got, T) == T // 25
+    _assert_final_state(env, o32)
+    # the actor: logits of the stock PyTorch network on the rows the oracle produced
+    rows = torch.from_numpy(np.concatenate([obs0[None], _np(got['obs'][:-1])], 0)).cuda()        # what the policy saw at step t
+    with torch.no_grad():
+        lg = net(rows.reshape(T * B, N, env.obs_dim)).reshape(T, B, N, 5)
+    top2 = lg.topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 200.0                  # Gumbel noise lives in [-17, 3]; float32 logits of ~1e5 carry ~1e-1 of error
+    want = lg.argmax(-1).to(torch.int32)
+    assert clear.float().mean().item() > 0.8
+    assert torch.equal(got['act'][clear], want[clear])
+    for form in (2, 3):                                            # the other forms refuse such rows instead of running something else
+        env.set_dispatch(policy_form=form)
+        with pytest.raises(Exception, match='longer than 64'):
+            actor.rollout(env, 2)
+
+
 @pytest.mark.parametrize('B,adv,good,T', [(8192, 4, 2, 53), (100, 3, 1, 55), (37, 2, 3, 30)], ids=['C3', '3+1', '2+3'])
 def test_tag_policy_rollout_outputs_equal_the_oracle_on_its_own_actions(B, adv, good, T):
     """simple_tag (BASELINE configs[2]: 4 adversaries + 2 good agents, B = 8192; ragged rows zero-padded)."""
