@@ -20,7 +20,8 @@ time; ``ms_per_step`` is per launch; ``config`` states T, K and the env-steps pe
 N > 1 (weak scaling, B per GPU fixed): envs are sharded by env_id_base.  Headline: the only exchange is the RCCL
 gather of replay rows sampled from each rank's chunk (``SampledTransitionGather``); the policy-in-the-loop extra
 measures north_star's collective, the FULL gather of every transition to the root's ring
-(``FullTransitionGather``), and reports bytes per env-step and GB/s per xGMI link.
+(``FullTransitionGather``: state-only wire blocks, 114 B per env-step at C2 -- the root rebuilds the observation
+rows), and reports bytes per env-step and GB/s per xGMI link.
 
 Exit code: 0 only if every rank finished every part it started.  A run whose policy-in-the-loop extra timed out, whose
 peer died, or whose closing barrier never completed still prints the (already measured) headline line, then exits 3; a
@@ -926,9 +927,11 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
     return dict(value=total / tp, unit='env-steps/s', us_per_step=tp / (n_chunks * Tp) * 1e6, steps=n_chunks * Tp,
                 policy=label,
                 loop='%d-step chunks, one pw_policy_rollout launch each per rank, outputs written into the wire block' % Tp,
-                gather=dict(kind='FULL gather: every transition of every rank to the root replay ring '
-                                 '(pw_chunk_wire_finalize -> grouped RCCL send/recv peer->root -> pw_replay_add_wire), '
-                                 'double-buffered, one chunk late',
+                gather=dict(kind='FULL gather: every transition of every rank to the root replay ring (%s -> grouped RCCL send/recv '
+                                 'peer->root -> %s), double-buffered, one chunk late'
+                                 % (('STATE-ONLY wire blocks: pw_state_wire_begin / _finalize', 'pw_replay_add_state_wire rebuilds the rows')
+                                    if getattr(full, 'state_wire', False) else ('row blocks: pw_chunk_wire_finalize', 'pw_replay_add_wire')),
+                            wire='state' if getattr(full, 'state_wire', False) else 'rows',
                             bytes_per_env_step=full.bytes_per_env_step, bytes_per_chunk_per_rank=full.lay.total_bytes,
                             GBps_per_link=per_link, GBps_root_ingest=None if per_link is None else per_link * (world - 1),
                             exchanges=full.exchanges, transitions_ingested_root=full.rows_ingested,
