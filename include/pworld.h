@@ -192,7 +192,7 @@ typedef struct pw_dispatch {
     int32_t trio;          /* -1 auto; 0 / 1: the three-wave variants of the duo kernels (spread: block-store forms, N >= 6) */
     int32_t p_prio;        /* -1 auto; >= 0: issue-priority bits of the duo kernels' waves (2 bits per wave; simple_tag: 0 / 1) */
     int32_t envs_per_wave; /* 0 auto; n >= 1: envs per wave, clamped to 64 / N */
-    int32_t policy_form;   /* 0 auto; 2 / 3: pw_policy_rollout2_kernel / pw_policy_rollout3_kernel; 4: pw_policy_rollout3j_kernel; 1: retired (PW_EINVAL)
+    int32_t policy_form;   /* 0 auto; 3: pw_policy_rollout3_kernel; 4: pw_policy_rollout3j_kernel; 1, 2: retired (PW_EINVAL)
                             * (the third form with dense1 just in time: long agent axes, N <= 32) */
 } pw_dispatch;
 int pw_dispatch_default(pw_dispatch *d);                    /* every choice automatic */

@@ -261,15 +261,14 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     }
     const int S1C = (kp.D + 7) / 8, S1 = 4 * S1C;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // Kernel forms.  pw_policy_rollout2_kernel (pw_kernels_policy2.hpp): role-specialised waves, weights resident in registers, as
-    // many environments per workgroup as fit 160 KB of LDS (D <= 64: N <= 30).  pw_policy_rollout3_kernel
-    // (pw_kernels_policy3.hpp): the whole BiLSTM on v_mfma_f32_16x16x4_f32, one timestep per barrier, 16 environments per
-    // workgroup at any N; its dense1 output takes 4 KB of LDS per agent, so the environments per workgroup shrink past N = 12.
-    // pw_policy_rollout3j_kernel (pw_kernels_policy3j.hpp): the same with dense1 just in time.  (A first, phase-by-phase form --
-    // policy_form 1 -- was retired in 0.1.5: nothing selected it.)  pw_dispatch.policy_form overrides the choice.
+    // Kernel forms.  pw_policy_rollout3_kernel (pw_kernels_policy3.hpp): the whole BiLSTM on v_mfma_f32_16x16x4_f32, one timestep
+    // per barrier, 16 environments per workgroup at any N; its dense1 output takes 4 KB of LDS per agent, so the environments per
+    // workgroup shrink past N = 12.  pw_policy_rollout3j_kernel (pw_kernels_policy3j.hpp): the same with dense1 just in time.
+    // (The first, phase-by-phase form and the second, role-specialised-waves form -- policy_form 1 / 2 -- were retired in 0.1.5:
+    // nothing selected them.)  pw_dispatch.policy_form overrides the choice.
     const int form = h->disp.policy_form;
-    if (form == 1)
-        return fail(PW_EINVAL, "policy_form 1 (the phase-by-phase rollout kernel) was retired in 0.1.5; use 0 (automatic), 2, 3 or 4");
+    if (form == 1 || form == 2)
+        return fail(PW_EINVAL, "policy_form 1 / 2 (the first two rollout kernels) were retired in 0.1.5; use 0 (automatic), 3 or 4");
     int E3 = 0;
     for (int e = kp.B < 16 ? kp.B : 16; e >= 1; --e)  // 16 MFMA columns = 16 environments whatever N is (no 96-row limit here)
         if (roll3_lds_bytes(e, kp.N, kp.L, kp.D, S1) <= 160 * 1024) { E3 = e; break; }
@@ -313,35 +312,20 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         h->last_kernel = "pw_policy_rollout3j_kernel";
         return PW_OK;
     }
-    const bool use_v2 = !use_v3;
-    if (a.bf16x3 && !use_v3)
-        return fail(PW_EINVAL, "PW_ACTOR_BF16X3 needs the third kernel form (policy_form 0 or 3, N <= 16 with 8+ environments per workgroup)");
-    int E2 = use_v3 ? E3 : 0;
-    if (use_v2) {
-        for (int e = a.E; e >= 1; --e)
-            if (roll2_lds_bytes(e, kp.N, kp.L, kp.D, S1) <= 160 * 1024) { E2 = e; break; }
-        if (E2 == 0) return fail(PW_EINVAL, "observation too long for the one-launch rollout (LDS)");
-    }
-    if (E2 > 0) {
-        a.E = E2;
-        const size_t shm2 = use_v3 ? roll3_lds_bytes(E2, kp.N, kp.L, kp.D, S1) : roll2_lds_bytes(E2, kp.N, kp.L, kp.D, S1);
-        const unsigned grid2 = (unsigned)((kp.B + E2 - 1) / E2);
+    if (!use_v3)
+        return fail(PW_EINVAL, a.bf16x3 ? "PW_ACTOR_BF16X3 needs the third kernel form (policy_form 0 or 3, N <= 16 with 8+ environments per workgroup)"
+                                        : "the selected rollout form does not fit this configuration's observation rows in LDS (policy_form 0 chooses)");
+    {
+        a.E = E3;
+        const size_t shm2 = roll3_lds_bytes(E3, kp.N, kp.L, kp.D, S1);
+        const unsigned grid2 = (unsigned)((kp.B + E3 - 1) / E3);
 #define PW_R24(C, NT, SK, BF)                                                                                            \
     do {                                                                                                                 \
         static unsigned long long attr_set3 = 0; /* bit = device */                                                      \
-        PW_LDS_OPTIN(&attr_set3, (pw_policy_rollout3_kernel<C, NT, SK, BF>)); \
+        PW_LDS_OPTIN(&attr_set3, (pw_policy_rollout3_kernel<C, NT, SK, BF>));                                            \
         hipLaunchKernelGGL((pw_policy_rollout3_kernel<C, NT, SK, BF>), dim3(grid2), dim3(512), shm2, st, P);             \
     } while (0)
-#define PW_R23(C, NT, SK)                                                                                                \
-    do {                                                                                                                 \
-        if (use_v3) {                                                                                                    \
-            if (a.bf16x3) PW_R24(C, NT, SK, true); else PW_R24(C, NT, SK, false);                                        \
-            break;                                                                                                       \
-        }                                                                                                                \
-        static unsigned long long attr_set = 0; /* bit = device */                                                       \
-        PW_LDS_OPTIN(&attr_set, (pw_policy_rollout2_kernel<C, NT, SK>)); \
-        hipLaunchKernelGGL((pw_policy_rollout2_kernel<C, NT, SK>), dim3(grid2), dim3(512), shm2, st, P);                 \
-    } while (0)
+#define PW_R23(C, NT, SK) do { if (a.bf16x3) PW_R24(C, NT, SK, true); else PW_R24(C, NT, SK, false); } while (0)
 #define PW_R22(C, NT) do { if (sink) PW_R23(C, NT, true); else PW_R23(C, NT, false); } while (0)
 #define PW_R2(C) case C: PW_R22(C, 0); break;
         if (kp.N == 6 && kp.L == 6) PW_R22(2, 6);        // BASELINE configs[1]: D = 16
@@ -353,10 +337,9 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
 #undef PW_R22
 #undef PW_R2
         PW_HIP_CHECK(hipGetLastError());
-        h->last_kernel = use_v3 ? (a.bf16x3 ? "pw_policy_rollout3_kernel<bf16x3>" : "pw_policy_rollout3_kernel") : "pw_policy_rollout2_kernel";
+        h->last_kernel = a.bf16x3 ? "pw_policy_rollout3_kernel<bf16x3>" : "pw_policy_rollout3_kernel";
         return PW_OK;
     }
-    return fail(PW_EINVAL, "observation too long for the one-launch rollout (LDS)");
 }
 
 int pw_rollout_tail(const float *rew_shared, const uint8_t *terminal, int32_t B, float *episode_return,

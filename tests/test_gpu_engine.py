@@ -464,22 +464,24 @@ def test_one_launch_actor_equals_three_launch_chain(monkeypatch):
     assert torch.equal(one(obs), three(obs))
 
 
-@pytest.mark.parametrize('form', ['default', 'v2', 'v3', 'v3j'])
+@pytest.mark.parametrize('form', ['default', 'v3', 'v3j'])
 @pytest.mark.parametrize('B,N,T', [(16, 6, 3), (4096, 6, 30), (512, 6, 300), (8192, 6, 130), (100, 3, 60), (37, 7, 27), (5, 10, 4), (70, 2, 26),
                                    (9, 12, 26), (33, 16, 26), (7, 24, 5), (4, 30, 3), (40, 24, 27), (21, 30, 4), (1, 1, 27)])
 def test_one_launch_policy_rollout_equals_the_step_loop(B, N, T, form):
     """pw_policy_rollout (T x (actor + sampling + env step) in ONE launch, everything resident on the CU) vs the
     loop of FusedActor() + env.step(): sampled actions, observations, rewards, terminals, pre-reset observations
     and the final world state must be IDENTICAL, across auto-resets, ragged batches and N that does not divide 96.
-    All kernel forms (role-specialised waves 'v2'; 'v3': the whole BiLSTM on v_mfma_f32_16x16x4_f32, one timestep per
-    barrier -- N = 30 exceeds its LDS and falls back to v2; 'v3j': the same with dense1 just in time and no observation rows
-    in LDS, which serves N up to 32 and is what long agent axes get by default) and the default choice between them."""
+    Both kernel forms ('v3': the whole BiLSTM on v_mfma_f32_16x16x4_f32, one timestep per barrier -- N = 30 exceeds its LDS:
+    skipped there; 'v3j': the same with dense1 just in time and no observation rows in LDS, which serves every N and is what
+    long agent axes get by default) and the default choice between them."""
     from multiagent_rl_amd import make_batched_env
     from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    if form == 'v3' and N >= 30:
+        pytest.skip('the plain third form does not hold 30 agents\' dense1 output and rows in LDS (the launch returns PW_EINVAL)')
     torch.manual_seed(4)
     mk = lambda: make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=25, seed=21)  # noqa: E731
     env_a, env_b = mk(), mk()
-    env_b.set_dispatch(policy_form=dict(default=0, v2=2, v3=3, v3j=4)[form])   # pw_dispatch: the handle carries the selection
+    env_b.set_dispatch(policy_form=dict(default=0, v3=3, v3j=4)[form])   # pw_dispatch: the handle carries the selection
     actor = ActorNetwork(env_a.obs_dim, 5).cuda().eval()
     loop, one = FusedActor(actor, seed=9), FusedActor(actor, seed=9)
     obs = env_a.reset()
@@ -509,15 +511,23 @@ def test_one_launch_policy_rollout_equals_the_step_loop(B, N, T, form):
     assert torch.equal(got2['act'][0], act) and torch.equal(got2['obs'][0], obs2)
 
 
-def test_retired_policy_form_is_refused():
-    """policy_form 1 (the first, phase-by-phase rollout kernel) was retired in 0.1.5: PW_EINVAL, not a silent other form."""
+def test_retired_policy_forms_are_refused():
+    """policy_form 1 / 2 (the phase-by-phase and the role-specialised-waves rollout kernels) were retired in 0.1.5: PW_EINVAL, not a
+    silent other form; and a forced form that cannot hold the rows says so."""
     from multiagent_rl_amd import make_batched_env
     from multiagent_rl_amd.policy import ActorNetwork, FusedActor
     env = make_batched_env('simple_spread', 32, n=6, auto_reset=True, seed=1)
     env.reset()
-    env.set_dispatch(policy_form=1)
-    with pytest.raises(Exception, match='retired'):
-        FusedActor(ActorNetwork(env.obs_dim, 5).cuda().eval(), seed=1).rollout(env, 3)
+    actor = FusedActor(ActorNetwork(env.obs_dim, 5).cuda().eval(), seed=1)
+    for form in (1, 2):
+        env.set_dispatch(policy_form=form)
+        with pytest.raises(Exception, match='retired'):
+            actor.rollout(env, 3)
+    big = make_batched_env('simple_spread', 8, n=30, auto_reset=True, seed=1)
+    big.reset()
+    big.set_dispatch(policy_form=3)
+    with pytest.raises(Exception, match='does not fit'):
+        FusedActor(ActorNetwork(big.obs_dim, 5).cuda().eval(), seed=1).rollout(big, 2)
 
 
 def test_collect_one_launch_fills_the_ring_like_the_step_loop():

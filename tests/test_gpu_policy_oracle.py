@@ -1,7 +1,7 @@
 """GPU: the one-launch policy rollouts (pw_policy_rollout: actor + Gumbel sampling + env step for a whole chunk in
 ONE kernel) anchored DIRECTLY on the CPU oracle.
 
-Every rollout kernel (forms 2 / 3 / 3j of simple_spread, the simple_tag and the simple_reference kernels) carries its
+Every rollout kernel (forms 3 / 3j of simple_spread, the simple_tag and the simple_reference kernels) carries its
 own copy of the environment step.  tests/test_gpu_engine.py compares them with the FusedActor() + env.step() loop --
 HIP against HIP.  Here the actions a launch sampled (``out['act']``, an output) are replayed through the float32 C
 oracle from the same Philox reset, and every environment output of the launch -- observations, per-agent rewards,
@@ -19,8 +19,8 @@ torch = pytest.importorskip('torch')
 from oracle import c_oracle as co  # noqa: E402  (checker only)
 from tests.test_gpu_parity import _assert_same_bits, _np  # noqa: E402
 
-FORMS = dict(default=0, v2=2, v3=3, v3j=4)
-KERNEL_OF_FORM = {2: 'pw_policy_rollout2_kernel', 3: 'pw_policy_rollout3_kernel',
+FORMS = dict(default=0, v3=3, v3j=4)
+KERNEL_OF_FORM = {3: 'pw_policy_rollout3_kernel',
                   4: 'pw_policy_rollout3j_kernel'}
 
 
@@ -58,13 +58,15 @@ def _assert_final_state(env, o32, extra=()):
         _assert_same_bits(_np(st[k]), getattr(o32, k), k)
 
 
-@pytest.mark.parametrize('form', ['default', 'v2', 'v3', 'v3j'])
+@pytest.mark.parametrize('form', ['default', 'v3', 'v3j'])
 @pytest.mark.parametrize('B,N,T', [(4096, 6, 53), (100, 3, 60), (37, 7, 27), (9, 12, 26), (33, 16, 26), (7, 24, 5), (520, 24, 53),
                                    (19, 30, 27)], ids=['C2', 'N3', 'N7', 'N12', 'N16', 'N24', 'N24-B520', 'N30'])
 def test_spread_policy_rollout_outputs_equal_the_oracle_on_its_own_actions(B, N, T, form):
     """simple_spread, every kernel form (C2 at full size: B = 4096, N = 6, 53 steps across two auto-resets)."""
     from multiagent_rl_amd import make_batched_env
     from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    if form == 'v3' and N >= 30:
+        pytest.skip('the plain third form does not hold 30 agents\' dense1 output and rows in LDS')
     torch.manual_seed(4)
     env = make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=25, seed=21)
     env.set_dispatch(policy_form=FORMS[form])
@@ -75,7 +77,7 @@ def test_spread_policy_rollout_outputs_equal_the_oracle_on_its_own_actions(B, N,
     got = actor.rollout(env, T)
     if form == 'default':                 # automatic choice: form 3 wherever 16 environments per workgroup fit its LDS,
         assert env.last_kernel() == KERNEL_OF_FORM[3 if N <= 12 else 4], env.last_kernel()   # its just-in-time variant beyond
-    elif not (form == 'v3' and N > 16):
+    else:
         assert env.last_kernel() == KERNEL_OF_FORM[FORMS[form]], env.last_kernel()
     a = _np(got['act'])
     assert a.shape == (T, B, N) and a.min() >= 0 and a.max() <= 4
@@ -121,10 +123,9 @@ def test_spread_policy_rollout_with_rows_longer_than_64_numbers(B, N, T):
     want = lg.argmax(-1).to(torch.int32)
     assert clear.float().mean().item() > 0.8
     assert torch.equal(got['act'][clear], want[clear])
-    for form in (2, 3):                                            # the other forms refuse such rows instead of running something else
-        env.set_dispatch(policy_form=form)
-        with pytest.raises(Exception, match='longer than 64'):
-            actor.rollout(env, 2)
+    env.set_dispatch(policy_form=3)                                # the plain third form refuses such rows instead of running something else
+    with pytest.raises(Exception, match='longer than 64'):
+        actor.rollout(env, 2)
 
 
 @pytest.mark.parametrize('B,adv,good,T', [(8192, 4, 2, 53), (100, 3, 1, 55), (37, 2, 3, 30)], ids=['C3', '3+1', '2+3'])

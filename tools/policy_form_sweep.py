@@ -14,12 +14,12 @@ Ns = [int(x) for x in sys.argv[1:]] or [6, 12, 14, 16, 20, 24, 30]
 B, T = 4096, 100
 for N in Ns:
     row = []
-    for form in (0, 2, 3, 4):
+    for form in (0, 3, 4):
         try:
             env = BatchedParticleEnv('simple_spread', B, num_agents=N, max_episode_len=25, auto_reset=True, seed=1)
             env.set_dispatch(policy_form=form)
             ro = BatchedRollout(env, FusedActor(ActorNetwork(env.obs_dim, 5).cuda().eval(), seed=2), ReplayBuffer(int(1e6), N, env.obs_dim))
-            K = 3 if N >= 20 and form in (2, 3) else 6
+            K = 3 if N >= 20 and form == 3 else 6
             ro.collect_one_launch(T, chunk=T)
             torch.cuda.synchronize()
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
