@@ -617,7 +617,7 @@ def main():
                     GBps_per_link=g['GBps_per_link'], GBps_root_ingest=g['GBps_root_ingest'], peers=world - 1,
                     bytes_per_env_step=g['bytes_per_env_step'], transitions_ingested_root=g['transitions_ingested_root'],
                     expected_transitions=g['expected_transitions'], complete=g['transitions_ingested_root'] == g['expected_transitions'],
-                    root_receive_bytes=2 * (world - 1) * g['bytes_per_chunk_per_rank'],
+                    root_receive_bytes=3 * (world - 1) * g['bytes_per_chunk_per_rank'],   # three slots of one block per peer
                     env_steps_per_s=policy_line.get('value'), error=g['error']),
                 sampled_exchange=dict(value_with_exchange=line['value'],
                                       value_without_exchange=world * B * T * K / elapsed_plain,

@@ -260,7 +260,9 @@ class FullTransitionGather(object):
     ``wire='rows'`` keeps the row block (any scenario).
     """
 
-    def __init__(self, env, T, rank, world, device, memory=None, group=None, capacity=int(1e6), wire='auto'):
+    SLOTS = 3
+
+    def __init__(self, env, T, rank, world, device, memory=None, group=None, capacity=int(1e6), wire='auto', overlap_ingest=True):
         from ._lib import PwChunkWire, PwStateWire
         self.rank, self.world, self.device, self.group = rank, world, torch.device(device), group
         self.B, self.N, self.D, self.T = env.num_envs, env.n, env.obs_dim, int(T)
@@ -279,11 +281,19 @@ class FullTransitionGather(object):
         self.lay = self._layout(PwStateWire if self.state_wire else PwChunkWire)
         nbytes = self.lay.total_bytes
         dev = self.device
-        self.wire = [torch.zeros(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        # THREE slots: chunk k's blocks travel (and, at the root, are appended) while chunk k + 1 rolls out into the next slot and
+        # chunk k + 2 may already start in the third -- the root's ring append runs on its own stream beside the NEXT rollout
+        # launch instead of in front of it (profiles/r4_root_ingest.txt: at 8 blocks per chunk 22-23 -> 19-19.6 us per step)
+        self.wire = [torch.zeros(nbytes, dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
         self.recv = None
         if rank == 0:
             self.recv = [[None] + [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(1, world)]
-                         for _ in range(2)]
+                         for _ in range(self.SLOTS)]
+        # root: ring appends on a high-priority side stream (its own hardware queue); _slot_free[s]: slot s's blocks have been
+        # appended (they may be overwritten), _finalized[s]: this rank's own block of slot s is complete on the main stream
+        self._ingest_stream = torch.cuda.Stream(dev, priority=-1) if (dev.type == 'cuda' and rank == 0 and overlap_ingest) else None
+        self._slot_free = [None] * self.SLOTS
+        self._finalized = [None] * self.SLOTS
         B, N, D = self.B, self.N, self.D
         # the rollout's outputs that do NOT travel as they are (finalize condenses them into the block)
         self.side = dict(final_obs=torch.empty(self.T, B, N, D, dtype=torch.float32, device=dev) if self.lay.F else None,
@@ -346,7 +356,10 @@ class FullTransitionGather(object):
     def outputs(self, slot=None):
         """The [T, ...] output dict for this chunk's rollout launch (``FusedActor.rollout(env, T, out)`` /
         ``BatchedParticleEnv.rollout``): obs and rew_shared are views INTO the wire block."""
-        slot = self.exchanges & 1 if slot is None else slot
+        slot = self.exchanges % self.SLOTS if slot is None else slot
+        if self._slot_free[slot] is not None:       # the side stream's appends of this slot's previous blocks have been issued:
+            torch.cuda.current_stream(self.device).wait_event(self._slot_free[slot])   # nothing overwrites them before they ran
+            self._slot_free[slot] = None
         v = self.views(self.wire[slot])
         if self.state_wire:
             self._begin(self.wire[slot])
@@ -360,10 +373,10 @@ class FullTransitionGather(object):
     def bytes_per_env_step(self):
         return self.lay.total_bytes / float(self.T * self.B)
 
-    @staticmethod
-    def root_receive_bytes(world, block_bytes):
-        """HBM the learner rank holds for incoming blocks: two slots (double buffer) x one block per peer."""
-        return 2 * (int(world) - 1) * int(block_bytes)
+    @classmethod
+    def root_receive_bytes(cls, world, block_bytes):
+        """HBM the learner rank holds for incoming blocks: SLOTS slots x one block per peer."""
+        return cls.SLOTS * (int(world) - 1) * int(block_bytes)
 
     # -- overridable pieces (the CPU gloo test substitutes torch stand-ins for the two HIP launches)
     def _make_memory(self):
@@ -411,20 +424,45 @@ class FullTransitionGather(object):
         if self._pending is None:
             return
         works, slot = self._pending
-        for w in works:
-            if not w.is_completed():
-                w.wait()  # NCCL: orders the current stream after the transfer; does not block the host
-        if self.rank == 0:
-            for r in range(self.world):  # rank order => deterministic ring layout
+        self._pending = None
+        side = self._ingest_stream
+        if side is None:
+            for w in works:
+                if not w.is_completed():
+                    w.wait()  # NCCL: orders the current stream after the transfer; does not block the host
+            if self.rank == 0:
+                for r in range(self.world):  # rank order => deterministic ring layout
+                    self._ingest(self.wire[slot] if r == 0 else self.recv[slot][r])
+                    self.rows_ingested += self.T * self.B
+            return
+        # root, on the device: the appends of the PREVIOUS chunk's blocks run on the side stream, behind the transfers and behind
+        # this rank's own finalize, while the main stream goes on with the next rollout launch
+        with torch.cuda.stream(side):
+            for w in works:
+                if not w.is_completed():
+                    w.wait()
+            if self._finalized[slot] is not None:
+                side.wait_event(self._finalized[slot])
+            for r in range(self.world):
                 self._ingest(self.wire[slot] if r == 0 else self.recv[slot][r])
                 self.rows_ingested += self.T * self.B
-        self._pending = None
+            ev = torch.cuda.Event()
+            ev.record(side)
+            self._slot_free[slot] = ev
+
+    def wait_ingested(self):
+        """Order the current stream behind every append issued so far (call before the learner samples the ring)."""
+        if self._ingest_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._ingest_stream)
 
     def __call__(self, obs0):
         """After the chunk's rollout launch (same stream): condense, complete the PREVIOUS chunk's transfer and
         append it at the root, then start this chunk's transfer."""
-        slot = self.exchanges & 1
+        slot = self.exchanges % self.SLOTS
         self._finalize(self.wire[slot], obs0)
+        if self._ingest_stream is not None:
+            self._finalized[slot] = torch.cuda.Event()
+            self._finalized[slot].record(torch.cuda.current_stream(self.device))
         self._complete()
         self._pending = (self._post(slot), slot)
         self.exchanges += 1
@@ -441,3 +479,4 @@ class FullTransitionGather(object):
 
     def finish(self):
         self._complete()
+        self.wait_ingested()

@@ -134,6 +134,8 @@ def train_batched(env, actor, critic, Trainer, scenario_name, action_type='Discr
         if max_updates_per_chunk is not None:
             due = min(due, int(max_updates_per_chunk))
         if due and learns and len(memory) >= getattr(cfg, 'batch_size', 1):
+            if gather is not None:
+                gather.wait_ingested()          # the root appends on a side stream: order the learner's reads behind them
             for _ in range(due):
                 learner.optimize()
             updates += due

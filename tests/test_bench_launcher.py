@@ -68,7 +68,7 @@ def test_bench_gpus8_c4_shape_self_launch():
     mg = line['multi_gpu']
     assert mg['full_gather']['transitions_ingested_root'] == mg['full_gather']['expected_transitions'] == 8 * 4 * 100
     assert mg['full_gather']['GBps_per_link'] == g['GBps_per_link'] and mg['full_gather']['peers'] == 7
-    assert mg['full_gather']['root_receive_bytes'] == 2 * 7 * g['bytes_per_chunk_per_rank']
+    assert mg['full_gather']['root_receive_bytes'] == 3 * 7 * g['bytes_per_chunk_per_rank']      # three slots of one block per peer
     assert mg['sampled_exchange']['value_without_exchange'] > 0 and mg['sampled_exchange']['launches_timed'] == 6
     assert abs(mg['sampled_exchange']['value_with_exchange'] - line['value']) < 1e-6 * line['value']
 

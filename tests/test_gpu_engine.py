@@ -673,7 +673,7 @@ def test_chunk_wire_finalize_and_add_wire_equal_add_rollout(B, N, T, ep):
         out = full.outputs()
         out['act'].copy_(acts)
         env.rollout(acts, out={n_: v for n_, v in out.items() if n_ != 'act'})
-        block = full.wire[full.exchanges & 1]
+        block = full.wire[full.exchanges % full.SLOTS]
         dense = {n_: v.clone() for n_, v in out.items()}
         full(obs0)
         # the block equals the CPU restatement of finalize
@@ -763,7 +763,7 @@ def test_state_wire_ring_equals_add_rollout_bitwise(B, N, L, T, ep):
         out = full.outputs()                                   # also: pw_state_wire_begin on this chunk's block
         out['act'].copy_(acts)
         env.rollout(acts, out={n_: v for n_, v in out.items() if n_ != 'act'})
-        block = full.wire[full.exchanges & 1]
+        block = full.wire[full.exchanges % full.SLOTS]
         dense = {n_: v.clone() for n_, v in out.items()}
         full(obs0)
         # the block equals the CPU restatement of begin + finalize
