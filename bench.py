@@ -928,7 +928,7 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
                 policy=label,
                 loop='%d-step chunks, one pw_policy_rollout launch each per rank, outputs written into the wire block' % Tp,
                 gather=dict(kind='FULL gather: every transition of every rank to the root replay ring (%s -> grouped RCCL send/recv '
-                                 'peer->root -> %s), double-buffered, one chunk late'
+                                 'peer->root -> %s), triple-buffered, one chunk late'
                                  % (('STATE-ONLY wire blocks: pw_state_wire_begin / _finalize', 'pw_replay_add_state_wire rebuilds the rows')
                                     if getattr(full, 'state_wire', False) else ('row blocks: pw_chunk_wire_finalize', 'pw_replay_add_wire')),
                             wire='state' if getattr(full, 'state_wire', False) else 'rows',

@@ -243,7 +243,7 @@ class FullTransitionGather(object):
     straight into the block (``outputs(slot)``: zero-copy), ``pw_chunk_wire_finalize`` (one launch) adds the
     observation acted on at step 0, the pre-reset rows of the steps that ended an episode, the byte-wide actions and
     the episode-end map; the blocks travel as direct peer -> root sends (grouped isend/irecv = RCCL send/recv in one
-    group: all seven inbound xGMI links of the root at once, not a ring), double-buffered, completed one chunk late
+    group: all seven inbound xGMI links of the root at once, not a ring), triple-buffered (the root appends on a side stream beside the next rollout), completed one chunk late
     so the transfer overlaps the next chunk's rollout; the root appends block after block IN RANK ORDER with
     ``pw_replay_add_wire`` (one launch per block): exchange x, rank r, step t, env e -> ring slot
     ``(x*world + r)*T*B + t*B + e``.
