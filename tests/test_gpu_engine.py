@@ -858,6 +858,50 @@ def test_wire_functions_reject_foreign_layouts():
     torch.cuda.synchronize()
 
 
+def test_state_wire_functions_reject_foreign_layouts_and_scenarios():
+    """pw_state_wire_*: a layout not produced by pw_state_wire_layout, a misaligned block, a handle of another scenario / another
+    shape / the full observation are refused with PW_EINVAL (and dist.FullTransitionGather falls back to row blocks there)."""
+    import ctypes as C
+    from multiagent_rl_amd import _lib, make_batched_env
+    from multiagent_rl_amd.dist import FullTransitionGather
+    lib = _lib.load()
+    env = make_batched_env('simple_spread', 8, n=3, auto_reset=True, max_episode_len=25, seed=1)
+    env.reset()
+    lay = _lib.PwStateWire()
+    assert lib.pw_state_wire_layout(10, 8, 3, 3, 25, C.byref(lay)) == 0 and lay.F == 1 and lay.D == 10
+    assert lib.pw_state_wire_layout(1000, 8, 3, 3, 2, C.byref(lay)) < 0 and b'126' in lib.pw_last_error()
+    assert lib.pw_state_wire_layout(10, 8, 3, 3, 25, C.byref(lay)) == 0
+    block = torch.zeros(lay.total_bytes, dtype=torch.uint8, device='cuda')
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    obs = torch.zeros(10, 8, 3, 10, device='cuda')
+    term, act = torch.zeros(10, 8, dtype=torch.uint8, device='cuda'), torch.zeros(10, 8, 3, dtype=torch.int32, device='cuda')
+    bad = _lib.PwStateWire.from_buffer_copy(lay)
+    bad.state = lay.state + 256
+    assert lib.pw_state_wire_begin(env._h, C.byref(bad), p(block), None) < 0 and b'pw_state_wire_layout' in lib.pw_last_error()
+    assert lib.pw_state_wire_begin(env._h, C.byref(lay), C.c_void_p(block.data_ptr() + 4), None) < 0
+    assert lib.pw_state_wire_begin(env._h, C.byref(lay), p(block), None) == 0
+    assert lib.pw_state_wire_finalize(env._h, C.byref(lay), p(block), p(obs), p(obs), p(term), p(act), None) == 0
+    other = make_batched_env('simple_spread', 8, n=6, auto_reset=True, seed=1)          # another shape
+    other.reset()
+    assert lib.pw_state_wire_begin(other._h, C.byref(lay), p(block), None) < 0 and b'shape mismatch' in lib.pw_last_error()
+    tag = make_batched_env('simple_tag', 8, num_adversaries=3, num_good=1, auto_reset=True, seed=1)
+    tag.reset()
+    assert lib.pw_state_wire_begin(tag._h, C.byref(lay), p(block), None) < 0 and b'simple_spread' in lib.pw_last_error()
+    full_obs = make_batched_env('simple_spread', 8, n=3, local_observation=False, auto_reset=True, seed=1)
+    full_obs.reset()
+    assert lib.pw_state_wire_begin(full_obs._h, C.byref(lay), p(block), None) < 0
+    ring = _lib.PwReplayStore()
+    torch.cuda.synchronize()
+    # the host side picks the block kind by the same rule
+    dev = torch.device('cuda', 0)
+    assert FullTransitionGather(env, 10, 0, 1, dev).state_wire
+    assert not FullTransitionGather(tag, 10, 0, 1, dev).state_wire and not FullTransitionGather(full_obs, 10, 0, 1, dev).state_wire
+    with pytest.raises(ValueError, match='state-only'):
+        FullTransitionGather(tag, 10, 0, 1, dev, wire='state')
+    with pytest.raises(ValueError, match='auto-resetting'):
+        FullTransitionGather(make_batched_env('simple_spread', 8, n=3, auto_reset=False, seed=1), 10, 0, 1, dev)
+
+
 def test_run_test_on_hip_env_with_device_ring_pickles_history(tmp_path):
     """rollout.run_test (experiments/run.py:106-200) on the HIP MultiAgentEnv with the DEFAULT memory -- the device
     ReplayBuffer -- reproduces the reference's evaluation call trace (event kinds, shapes, dtypes; values to float32
