@@ -45,6 +45,13 @@ __device__ __forceinline__ void quad_pair_of(const int q, int &i, int &j)
 // bit-identical to the plain form (tests: the `quad+coll` path, and the bench-path test at C2 full size).
 // K1: the division by the contact margin inside the force runs as ONE Newton correction (pw_common.hpp div_chain1); the
 // host sets it only for margins whose refined reciprocal is the correctly rounded one (pworld.hip margin_one_correction).
+#if defined(PW_EXP_BARRIER2)   // timing experiments only (tools/step_time.hip builds; results are WRONG): the workgroup meets every
+#define PW_QUAD_BARRIER(t) do { if (!((t) & 1)) duo_barrier(); else wave_lds_sync(); } while (0)   // SECOND step only
+#elif defined(PW_EXP_BARRIER0)  // ... or never (the waves run free: the floor of the physics chain without any meeting)
+#define PW_QUAD_BARRIER(t) wave_lds_sync()
+#else
+#define PW_QUAD_BARRIER(t) duo_barrier()
+#endif
 template <bool UNIT_MASS, bool COLL = false, bool K1 = false>
 __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamParams A, const int T)
 {
@@ -105,7 +112,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         const int e0 = wave * EPP;
         const int nv = envs_here - e0 < 0 ? 0 : envs_here - e0 < EPP ? envs_here - e0 : EPP;  // envs of this wave
         if (nv == 0) {  // nothing to advance: keep the workgroup's barriers company
-            for (int t = 0; t < T; ++t) duo_barrier();
+            for (int t = 0; t < T; ++t) PW_QUAD_BARRIER(t);
             return;
         }
         // agent lanes (lane < nv * 6; the others shadow lane 0)
@@ -217,7 +224,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
             qi = *reinterpret_cast<const float2 *>(s_ring + cur * kWave + ri);
             qj = *reinterpret_cast<const float2 *>(s_ring + cur * kWave + rj);
             PW_STAMP(1);
-            duo_barrier();
+            PW_QUAD_BARRIER(t);
             PW_STAMP(2);
         }
         act_fetch_drain();  // the tail's fetches have landed before the wave ends
@@ -334,7 +341,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         // prologue: A(0)
         {
             PW_STAMP_START;
-            duo_barrier();
+            PW_QUAD_BARRIER(0);
             PW_STAMP(0);
             const int nxt = (cur + 1) & 3;
             a_reads(nxt);
@@ -345,7 +352,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         }
         for (int t = 1; t < T; ++t) {  // A(t) interleaved with B(t - 1): no branch but the (rare) reset step's
             PW_STAMP_START;
-            duo_barrier();
+            PW_QUAD_BARRIER(t);
             PW_STAMP(0);
             const int nxt = (cur + 1) & 3;
             a_reads(nxt);
@@ -401,7 +408,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         const size_t tBN = (size_t)t * BN;
         PW_STAMP_START;
         nt_store(A.done + tBN + g, (uint8_t)0);
-        duo_barrier();
+        PW_QUAD_BARRIER(t);
         PW_STAMP(0);
         int nxt = (cur + 1) & 3;
         nt_store(A.terminal + (size_t)t * A.B + env, (uint8_t)(A.max_episode_len > 0 && t + 1 + ep_off >= A.max_episode_len ? 1 : 0));
