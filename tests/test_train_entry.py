@@ -196,3 +196,42 @@ def test_entry_script_two_chunks_on_the_gpu(tmp_path):
     assert len(hist['reward_episodes']) == 1024 and len(hist['reward_episodes_by_agents']) == 3
     assert abs(np.mean(hist['reward_episodes']) - st['mean_episode_reward']) < 1e-3 * abs(st['mean_episode_reward'])
     assert os.path.exists(tmp_path / 'Models' / 'simple_spread_fin_0_actor.pt')
+
+
+@pytest.mark.gpu
+def test_train_batched_through_the_full_gather_on_one_rank(tmp_path):
+    """The multi-rank form of train_batched with world = 1 on cuda:0 (no process group needed: a one-rank gather posts no transfer):
+    the rollout writes into the gather's wire block (state-only), the ring the learner samples is the gather's, filled one chunk
+    late on the side stream -- and holds exactly the transitions the same rollout's own ring sink stores."""
+    sys.path.insert(0, os.path.join(ROOT, 'examples'))
+    from madr_learner import CriticNetwork, Trainer
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.dist import FullTransitionGather
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+
+    class Cfg(_Args):
+        num_episodes, batch_size, warmup_steps, update_rate, save_rate = 512, 256, 10 ** 9, 100, 10 ** 9   # never learns: weights fixed
+
+    torch.manual_seed(3)
+    B, N, T = 128, 3, 50
+    dev = torch.device('cuda', 0)
+    mk = lambda: make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=25, seed=12345678)  # noqa: E731
+    env = mk()
+    actor = ActorNetwork(env.obs_dim, 5)
+    gather = FullTransitionGather(env, T, 0, 1, dev, capacity=4 * T * B)
+    assert gather.state_wire
+    hist = train_batched(env, actor, CriticNetwork(env.obs_dim + 5), Trainer, 'simple_spread', 'Discrete', cnt=0, arglist=Cfg(),
+                         out_dir=str(tmp_path), log=lambda *a: None, chunk=T, gather=gather, rank=0, world=1)
+    assert hist['stats']['episodes'] == 512 and hist['stats']['env_steps'] == 2 * T * B and hist['stats']['updates'] == 0
+    assert len(gather.memory) == 2 * T * B
+    # the same rollout with the kernel's own ring sink: same seeds, same weights -> the same ring
+    env2 = mk()
+    want = ReplayBuffer(4 * T * B, N, env2.obs_dim)
+    env2.reset()
+    fused = FusedActor(actor.to(dev), seed=12345678)
+    for _ in range(2):
+        fused.rollout(env2, T, False, memory=want)
+    torch.cuda.synchronize()
+    for name in ('obs', 'next_obs', 'act', 'rew', 'done'):
+        assert torch.equal(getattr(gather.memory, name)[:2 * T * B], getattr(want, name)[:2 * T * B]), name
