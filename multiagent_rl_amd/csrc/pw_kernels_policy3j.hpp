@@ -27,9 +27,9 @@ namespace {
 // stores.  Everything downstream (input projection, recurrence, head, sampling, environment step) is pw_policy_rollout3_kernel's.
 // The environment step runs undeferred here (every wave has environment duty at these N, and its work is a few per cent of a
 // pass of 2 x N x 62 matrix instructions per wave).
-// LDS (N = 24, L = 24, E = 16): 16 KB x1 ring + 8 KB h exchange + 96 KB head input + 6 KB states + 7.7 KB noise + 3 KB
-// landmarks + small = 143 KB.  Serves simple_spread with the local observation, D = 4 + 2 L <= 104 (W1's fragments: up to 26
-// VGPRs), at most 8 environment waves of whole environments: 16 environments per workgroup up to N = 24, 13 at N = 30, 8 at
+// LDS (N = 24, L = 24, E = 16): 16 KB x1 ring (the sampled actions alias it) + 8 KB h exchange + 96 KB head input + 6 KB states + 3 KB
+// landmarks + small = 134 KB; N = 30: 159.6 KB -- 16 environments per workgroup still fit (the Gumbel noise is drawn in the head's lanes).  Serves simple_spread with the local observation, D = 4 + 2 L <= 104 (W1's fragments: up to 26
+// VGPRs), at most 8 environment waves of whole environments: 16 environments per workgroup up to N = 30, 8 at
 // N = 33 .. 50 (BASELINE's C5 point N = L = 48: D = 100, the only form that holds such rows).
 // ------------------------------------------------------------------------------------------
 struct Roll3jLds {
@@ -37,9 +37,8 @@ struct Roll3jLds {
     float4 *s_hx;    // [2 buffers][2 dir][2 j][64 lane]
     float4 *s_hf;    // [rows / 16 tiles][4 j][64 lane]
     float *s_b2;     // [16]
-    float *s_noise;  // [rows * 5]
     float4 *s_st;    // [rows] {vx, vy, px, py} of the agents as the policy sees them (row = env * N + agent)
-    int32_t *s_act;  // [rows]
+    int32_t *s_act;  // [rows]: aliases the x1 ring (written by the head, read by the environment lanes: the ring is idle in between)
     float2 *s_posb;  // [8 env waves][64]
     float2 *s_lmb;   // [E * L]
     double *s_fs;    // [16]
@@ -48,7 +47,7 @@ struct Roll3jLds {
 __host__ __device__ inline size_t roll3j_lds_bytes(int E, int N, int L)
 {
     const size_t rows = (size_t)E * N;
-    const size_t fl = 2 * 2 * 4 * 64 * 4 + 2 * 2 * 2 * 64 * 4 + ((rows + 15) / 16) * 1024 + 16 + rows * 5 + 3 + rows * 4 + rows + 1;
+    const size_t fl = 2 * 2 * 4 * 64 * 4 + 2 * 2 * 2 * 64 * 4 + ((rows + 15) / 16) * 1024 + 16 + 3 + rows * 4 + 1;
     return fl * 4 + 8 * kWave * sizeof(float2) + (size_t)E * L * sizeof(float2) + 16 * (sizeof(double) + sizeof(int)) + 64;
 }
 __device__ __forceinline__ Roll3jLds roll3j_carve(unsigned char *raw, int E, int N, int L)
@@ -61,10 +60,9 @@ __device__ __forceinline__ Roll3jLds roll3j_carve(unsigned char *raw, int E, int
     S.s_hx = reinterpret_cast<float4 *>(base + o); o += 2 * 2 * 2 * 64 * 4;
     S.s_hf = reinterpret_cast<float4 *>(base + o); o += ((rows + 15) / 16) * 1024;
     S.s_b2 = base + o; o += 16;
-    S.s_noise = base + o; o += rows * 5;
     o = (o + 3) & ~3;
     S.s_st = reinterpret_cast<float4 *>(base + o); o += rows * 4;
-    S.s_act = reinterpret_cast<int32_t *>(base + o); o += rows;
+    S.s_act = reinterpret_cast<int32_t *>(S.s_xf);   // rows <= 512 ints of the ring's 4096 floats
     o = (o + 1) & ~1;
     S.s_posb = reinterpret_cast<float2 *>(base + o); o += 8 * kWave * 2;
     S.s_lmb = reinterpret_cast<float2 *>(base + o); o += E * L * 2;
@@ -95,27 +93,6 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
     constexpr int OUT = 5;  // one 5-logit head (checked on the host)
 
     if (tid < OUT) S.s_b2[tid] = A.b2[tid];
-
-    // Gumbel noise of one head evaluation (pw_policy_rollout3_kernel's draw_noise: same Philox keying)
-    auto draw_noise = [&](const uint64_t step, const int t0, const int nthr) {
-        constexpr int NB = (OUT + 3) / 4;
-        for (int idx = t0; idx < rows_here * NB; idx += nthr) {
-            const int rr = idx / NB;
-            const uint32_t blk = (uint32_t)(idx - rr * NB), tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
-            const long grow = row_base + rr;
-            uint32_t u[4];
-            pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | tag, (uint32_t)step, (uint32_t)(step >> 32),
-                             (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
-#pragma unroll
-            for (int wq = 0; wq < 4; ++wq) {
-                const int o = 4 * (int)blk + wq;
-                if (o < OUT) {
-                    const float uo = ((float)(u[wq] >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
-                    S.s_noise[rr * OUT + o] = __logf(-__logf(uo));
-                }
-            }
-        }
-    };
 
     // ---- environment lanes: wave w >= 8 - n_env_waves owns local envs [ew * epw, ...), lane = (env, agent)
     const int epw_max = E < kWave / N ? E : kWave / N;
@@ -197,13 +174,13 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
     }
     const bool seq_ok = n16 < envs_here;
     const int nseq = seq_ok ? n16 : 0;   // columns past the environments of this workgroup read env 0; nobody uses their results
-    const int noise_thr = n_env_waves == 2 ? 256 : n_env_waves < 8 ? (8 - n_env_waves) * 64 : 512;
-    const int noise_t0 = n_env_waves == 2 ? ((wave & 2) ? 512 : (wave >> 2) * 128 + (wave & 1) * 64 + lane) : tid;
     wg_lds_barrier();  // constants, first states and landmarks in LDS
-    if (noise_t0 < noise_thr) draw_noise(step0, noise_t0, noise_thr);
-    wg_lds_barrier();
 
-    auto head = [&]() {
+    // The head on the matrix cores (pw_policy_rollout3_kernel's), with the Gumbel noise drawn IN the lanes that subtract it: value
+    // (row, logit o) = log(-log(u)), u = word (o & 3) of Philox block (o >> 2) keyed (seed; step, global row) -- the keying of every
+    // other form -- so row group 0 (logits 0..3) needs block 0 and row group 1 (logit 4) block 1 of its row: no noise plane in LDS
+    // (9.6 KB at N = 30: with it, 16 environments per workgroup would not fit).
+    auto head = [&](const uint64_t step) {
         const int ntile = (rows_here + 15) >> 4;
         for (int tile = wave; tile < ntile; tile += 8) {
             f32x4 lg;
@@ -219,9 +196,21 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
                 lg = __builtin_amdgcn_mfma_f32_16x16x4f32(aw2[4 * jx + 3], b.w, lg, 0, 0, 0);
             }
             const int rr = tile * 16 + n16;
-            const float *nz = S.s_noise + (rr < rows_here ? rr : 0) * OUT;
-            const float p0 = lg[0] - nz[kq == 1 ? 4 : 0], p1 = lg[1] - nz[1], p2 = lg[2] - nz[2], p3 = lg[3] - nz[3];
-            const float p4 = __shfl(p0, n16 + 16, kWave);
+            float nz[4] = {0.f, 0.f, 0.f, 0.f};
+            if (kq < 2) {  // wave-divergent only by row group
+                const long grow = row_base + (rr < rows_here ? rr : 0);
+                const uint32_t blk = (uint32_t)kq, tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
+                uint32_t u[4];
+                pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | tag, (uint32_t)step, (uint32_t)(step >> 32),
+                                 (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float uo = ((float)(u[i] >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
+                    nz[i] = __logf(-__logf(uo));
+                }
+            }
+            const float p0 = lg[0] - nz[0], p1 = lg[1] - nz[1], p2 = lg[2] - nz[2], p3 = lg[3] - nz[3];
+            const float p4 = __shfl(p0, n16 + 16, kWave);  // logit 4 lives in register 0 of row group 1
             int bi = 0;
             float bv = p0;
             if (p1 > bv) { bv = p1; bi = 1; }
@@ -369,10 +358,9 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
                 if (s2 + 1 < N) { acc[0] = accn[0]; acc[1] = accn[1]; }
             }
         }
-        head();  // one barrier inside
+        head(step0 + (uint64_t)t);  // one barrier inside
 
         // ---- environment step (pw_spread_stream_kernel's arithmetic)
-        if (t + 1 < P.T && noise_t0 < noise_thr) draw_noise(step0 + (uint64_t)(t + 1), noise_t0, noise_thr);
         if (env_wave) {
             ai = S.s_act[r];
             if (SINK && P.has_ring) {  // the observation the policy acted on: rebuilt from the (still pre-step) registers

@@ -275,10 +275,10 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     const int full = kp.B < 16 ? kp.B : 16;     // environments per workgroup that fill the 16 MFMA columns
     bool use_v3 = form == 3 ? E3 > 0 : form == 0 && E3 >= full;
     // Long agent axes: the third form with dense1 just in time and no observation rows in LDS (pw_kernels_policy3j.hpp) keeps 16
-    // environments per workgroup up to N = 24 and >= 12 up to N = 30, where the plain third form has to drop columns (N >= 13)
+    // environments per workgroup up to N = 30 (8 beyond: rows up to 104 numbers), where the plain third form has to drop columns (N >= 13)
     // and the second form costs 400 us per step (N = 24).  us per step at B = 4096, forms 2 / 3 / 3j (profiles/r4_policy_forms.txt):
-    // N = 12: 67 / 33.0 / 34.1; N = 14: 111 / 77 / 39.8; N = 16: 170 / 89 / 48.1; N = 20: 270 / 211 / 59.7; N = 24: 414 / 495 / 76.7;
-    // N = 30: 494 / - / 194.  Automatic wherever the plain third form does not keep its 16 columns busy; policy_form 4 forces it
+    // N = 12: 67 / 33.0 / 34.1; N = 14: 111 / 77 / 41.5; N = 16: 170 / 89 / 49.0; N = 20: 270 / 211 / 60; N = 24: 414 / 495 / 77.1;
+    // N = 30: 494 / - / 100; N = 48: - / - / 342.  Automatic wherever the plain third form does not keep its 16 columns busy; policy_form 4 forces it
     // (tests run it at small N too).
     int E3j = 0;
     if (!tag && kp.D == 4 + 2 * kp.L && kp.L <= kp.N && !a.bf16x3 && (form == 4 || (form == 0 && !use_v3))) {
