@@ -43,4 +43,52 @@ __device__ int g_pw_debug;  // probe builds only: bit 0 skips the MFMAs (tiles s
 #define PW_R2_FLUSH(base)
 #endif
 
+// Finished-episode statistics of a rollout launch (run.py:55-65 bookkeeping summed over all envs): every workgroup leaves its
+// partial (sum, count) in `scratch` ([gridDim.x] doubles, [gridDim.x] counts, one ticket word); the workgroup that takes the last
+// ticket adds the partials up -- with ALL its threads: 512 partials per round through LDS and a fixed binary tree (deterministic:
+// the pairing depends on gridDim.x alone).  (Until round 4 one thread walked the partials one global load after the other: ~40 us at
+// the end of every launch with 256 workgroups -- 3 % of a 100-step C2 chunk.)  Call with the per-env partials in s_fs / s_fc
+// (LDS, complete: a barrier has passed); `red` = 8 KB of LDS that nothing else uses any more (the start of the block).
+__device__ __forceinline__ void rollout_finish_stats(const int envs_here, double *s_fs, int *s_fc, unsigned long long *scratch,
+                                                     double *finished_sum, int64_t *finished_count, unsigned char *red)
+{
+    const int tid = threadIdx.x;
+    double *part_sum = reinterpret_cast<double *>(scratch);
+    long long *part_cnt = reinterpret_cast<long long *>(scratch + gridDim.x);
+    unsigned long long *ticket = scratch + 2 * gridDim.x;
+    if (tid == 0) {
+        double ws = 0.0;
+        long long wc = 0;
+        for (int i = 0; i < envs_here; ++i) { ws += s_fs[i]; wc += s_fc[i]; }
+        part_sum[blockIdx.x] = ws;
+        part_cnt[blockIdx.x] = wc;
+        __threadfence();
+        s_fc[0] = atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1 ? 1 : 0;  // the per-env partials are consumed: reuse a slot
+    }
+    wg_lds_barrier();
+    if (!s_fc[0]) return;   // workgroup-uniform
+    __threadfence();
+    double *red_s = reinterpret_cast<double *>(red);             // [512]
+    long long *red_c = reinterpret_cast<long long *>(red) + 512;  // [512]
+    double ssum = 0.0;
+    long long scnt = 0;
+    for (unsigned base = 0; base < gridDim.x; base += 512) {
+        const unsigned i = base + (unsigned)tid;
+        red_s[tid] = i < gridDim.x ? __builtin_nontemporal_load(part_sum + i) : 0.0;
+        red_c[tid] = i < gridDim.x ? __builtin_nontemporal_load(part_cnt + i) : 0ll;
+        wg_lds_barrier();
+        for (int stride = 256; stride >= 1; stride >>= 1) {
+            if (tid < stride) { red_s[tid] += red_s[tid + stride]; red_c[tid] += red_c[tid + stride]; }
+            wg_lds_barrier();
+        }
+        if (tid == 0) { ssum += red_s[0]; scnt += red_c[0]; }
+        wg_lds_barrier();
+    }
+    if (tid == 0) {
+        *finished_sum += ssum;
+        *finished_count += scnt;
+        *ticket = 0;
+    }
+}
+
 }  // namespace

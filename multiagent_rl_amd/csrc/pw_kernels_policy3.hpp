@@ -480,29 +480,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
         wg_lds_barrier();
         if (live && a == 0) { S.s_fs[el] = fin_sum; S.s_fc[el] = fin_cnt; }
         wg_lds_barrier();
-        if (tid == 0) {
-            double ws = 0.0;
-            long long wc = 0;
-            for (int i = 0; i < envs_here; ++i) { ws += S.s_fs[i]; wc += S.s_fc[i]; }
-            double *part_sum = reinterpret_cast<double *>(P.scratch);
-            long long *part_cnt = reinterpret_cast<long long *>(P.scratch + gridDim.x);
-            unsigned long long *ticket = P.scratch + 2 * gridDim.x;
-            part_sum[blockIdx.x] = ws;
-            part_cnt[blockIdx.x] = wc;
-            __threadfence();
-            if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1) {
-                __threadfence();
-                double ssum = 0.0;
-                long long scnt = 0;
-                for (unsigned i = 0; i < gridDim.x; ++i) {
-                    ssum += __builtin_nontemporal_load(part_sum + i);
-                    scnt += __builtin_nontemporal_load(part_cnt + i);
-                }
-                *P.finished_sum += ssum;
-                *P.finished_count += scnt;
-                *ticket = 0;
-            }
-        }
+        rollout_finish_stats(envs_here, S.s_fs, S.s_fc, P.scratch, P.finished_sum, P.finished_count, smem_raw);
     }
 }
 

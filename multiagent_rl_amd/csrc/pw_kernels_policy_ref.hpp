@@ -22,9 +22,18 @@ struct PolicyRolloutRefArgs {
     int32_t *act_out;   // [T,B,N,2] (or NULL)
     float *obs, *final_obs, *rew, *rew_shared;
     uint8_t *done, *terminal;
+    // optional direct sink (round 4, as the simple_spread / simple_tag rollouts): the transitions go straight into the TWO-HEAD replay
+    // ring (act [cap,N,2] u8; slot (ring_start + t*B + env) % capacity) and the episode returns are kept here -- no second launch
+    pw_replay_store ring;
+    int has_ring;
+    int64_t ring_start;
+    float *episode_return;
+    double *finished_sum;
+    int64_t *finished_count;
+    unsigned long long *scratch;
 };
 
-template <int S1C>
+template <int S1C, bool SINK = false>
 __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const PolicyRolloutRefArgs P)
 {
     constexpr int DC = kDimC, N = 2;
@@ -35,8 +44,12 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
     const int D = A.D;
     Actor16W W;  // the actor's weights: registers for the whole launch (pw_kernels_actor16.hpp)
     actor16_load<S1C>(A, S, W);
-    float *s_obs = reinterpret_cast<float *>(S.end);                       // [96][D] observation rows
-    int32_t *s_act = reinterpret_cast<int32_t *>(s_obs + kFusedRows * D);  // [96][2] (movement, symbol)
+    // observation rows, TWO buffers of [96][D]: the policy reads buffer `cur`, the environment lanes publish the next rows into the other
+    // one -- so that, with a ring sink, the IDLE waves can copy the rows the policy acted on into ring.obs during the environment step
+    float *s_obs2 = reinterpret_cast<float *>(S.end);
+    int32_t *s_act = reinterpret_cast<int32_t *>(s_obs2 + 2 * kFusedRows * D);  // [96][2] (movement, symbol)
+    double *s_fs = reinterpret_cast<double *>(s_act + 2 * kFusedRows);     // [16] (+ [16] ints): finished-episode sums / counts (SINK)
+    int *s_fc = reinterpret_cast<int *>(s_fs + 16);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,14 +72,19 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
     RefLane<DC> s;
     int ep_step = 0;
     uint32_t ep_count = 0;
+    float ep_ret = 0.f;
+    double fin_sum = 0.0;
+    int fin_cnt = 0;
+    size_t slot = 0;
     if (env_wave) {
+        if (SINK && P.episode_return && live && a == 0) ep_ret = P.episode_return[env];
         ref_load<DC>(V, env, a, s);
         ep_step = V.ep_step[env];
         ep_count = V.ep_count[env];
         float co[DC];
 #pragma unroll
         for (int q = 0; q < DC; ++q) co[q] = __shfl_xor(s.c[q], 1, kWave);
-        if (live) ref_write_obs<DC, false>(V, s, co, a, s_obs + r * D);
+        if (live) ref_write_obs<DC, false>(V, s, co, a, s_obs2 + r * D);
     }
     const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
     wg_lds_barrier();
@@ -89,6 +107,11 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
         t_acc = (0.0f + (a == 0 ? rw : r_other)) + (a == 0 ? r_other : rw);  // agent order
         ep_step += 1;
         t_term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
+        if (SINK && live && a == 0 && P.episode_return) {  // run.py:55-65, per env
+            const float rsum = ep_ret + t_acc;
+            if (t_term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
+            else ep_ret = rsum;
+        }
     };
     auto tail_stores = [&](const int t, const bool with_obs) {
         const size_t row = (size_t)t * BN + g;
@@ -101,19 +124,40 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
                 if (P.terminal) P.terminal[(size_t)t * A.B + env] = t_term ? 1 : 0;
             }
             if (with_obs && P.obs) ref_write_obs<DC, false>(V, s, co, a, P.obs + row * D);
+            if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
+                ref_write_obs<DC, false>(V, s, co, a, P.ring.next_obs + (slot * N + a) * D);
+                if (a == 0) { P.ring.rew[slot] = t_acc; P.ring.done[slot] = 0.0f; }
+            }
         }
     };
     auto pre_hook = [&]() { if (tail_stage == 1) { tail_compute(); tail_stage = 2; } };
     auto mid_hook = [&]() { if (tail_stage == 2) { tail_stores(tail_t, true); tail_stage = 0; } };
 
     for (int t = 0; t < P.T; ++t) {
+        float *s_obs = s_obs2 + (t & 1) * (kFusedRows * D);          // what the policy acts on in this step
+        float *s_next = s_obs2 + ((t + 1) & 1) * (kFusedRows * D);   // where the environment lanes publish the next rows
         // ---- policy: observation rows (LDS) -> one sampled index per head and row (LDS)
         actor16_forward<S1C, false>(A, S, W, s_obs, D, rows_here, envs_here, row_base, step0 + (uint64_t)t, nullptr, s_act, pre_hook,
                                     mid_hook);  // a barrier at its end
+        if (SINK && P.has_ring && !env_wave) {
+            // the observations the policy acted on -> ring.obs, by the seven waves that would otherwise wait for the environment wave
+            for (int idx = tid; idx < rows_here * D; idx += 448) {
+                const int rr = idx / D, c = idx - rr * D;
+                const size_t sl = (size_t)((P.ring_start + (int64_t)t * A.B + env0 + (rr >> 1)) % P.ring.capacity);
+                P.ring.obs[(sl * N + (rr & 1)) * D + c] = s_obs[idx];
+            }
+        }
         // ---- environment step (pw_reference_rollout_kernel's arithmetic, index actions)
         if (env_wave) {
             const size_t row = (size_t)t * BN + g;
             ai = s_act[2 * r]; ci = s_act[2 * r + 1];
+            if (SINK && P.has_ring) {  // the pair the policy sampled -> ring.act (the observation rows: the idle waves, above)
+                slot = (size_t)((P.ring_start + (int64_t)t * A.B + env) % P.ring.capacity);
+                if (live) {
+                    P.ring.act[(slot * N + a) * 2] = (uint8_t)ai;
+                    P.ring.act[(slot * N + a) * 2 + 1] = (uint8_t)ci;
+                }
+            }
             const float a1 = ai == 1, a2 = ai == 2, a3 = ai == 3, a4 = ai == 4;
             float cn[DC];
 #pragma unroll
@@ -146,10 +190,10 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
                 }
                 if (live) {
                     if (P.obs) ref_write_obs<DC, false>(V, s, co, a, P.obs + row * D);
-                    ref_write_obs<DC, false>(V, s, co, a, s_obs + r * D);
+                    ref_write_obs<DC, false>(V, s, co, a, s_next + r * D);
                 }
             } else {
-                if (live) ref_write_obs<DC, false>(V, s, co, a, s_obs + r * D);
+                if (live) ref_write_obs<DC, false>(V, s, co, a, s_next + r * D);
                 tail_stage = 1;
                 tail_t = t;
             }
@@ -160,7 +204,16 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
     if (tail_stage != 0) tail_stores(tail_t, true);
     if (live) {
         ref_store<DC>(V, env, a, s);
-        if (a == 0) { V.ep_step[env] = ep_step; V.ep_count[env] = ep_count; }
+        if (a == 0) {
+            V.ep_step[env] = ep_step; V.ep_count[env] = ep_count;
+            if (SINK && P.episode_return) P.episode_return[env] = ep_ret;
+        }
+    }
+    if (SINK && P.episode_return) {  // finished-episode statistics: per-workgroup partials, the last workgroup adds them up in order
+        wg_lds_barrier();
+        if (live && a == 0) { s_fs[el] = fin_sum; s_fc[el] = fin_cnt; }
+        wg_lds_barrier();
+        rollout_finish_stats(envs_here, s_fs, s_fc, P.scratch, P.finished_sum, P.finished_count, smem_raw);
     }
 }
 

@@ -137,12 +137,21 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     const KParams &kp = h->kp;
     if (h->cfg.scenario == PW_SIMPLE_REFERENCE) {
         // the MultiDiscrete scenario: two-head actor [5 | PW_DIM_C] (w2 [15,64], b2 [15]), act_out [T,B,N,2]
-        if (sink) return fail(PW_EINVAL, "pw_policy_rollout on simple_reference has no ring sink (the two-head ring is filled by "
-                                         "pw_replay_add_rollout from the chunk's outputs)");
+        const bool rsink = sink && sink->ring;
+        if (sink) {
+            if (sink->ring && (sink->ring->act_heads != 2 || sink->ring->per_agent || sink->ring->head_width[1] != PW_DIM_C ||
+                               (sink->ring->head_width[0] != 0 && sink->ring->head_width[0] != 5)))
+                return fail(PW_EINVAL, "pw_policy_rollout sink on simple_reference: the ring must be the two-head ring (act_heads = 2, widths 5 | dim_c)");
+            if (sink->ring && (sink->ring->num_agents != 2 || sink->ring->obs_dim != kp.D || sink->ring->capacity < 1 ||
+                               sink->ring_start < 0 || (int64_t)num_steps * kp.B > sink->ring->capacity))
+                return fail(PW_EINVAL, "ring sink: shape mismatch or the chunk does not fit the ring");
+            if (sink->episode_return && (!sink->finished_sum || !sink->finished_count || !sink->scratch))
+                return fail(PW_EINVAL, "bookkeeping needs episode_return, finished_sum, finished_count and scratch");
+        }
         if (io->act_idx || io->act_vec || io->act_comm || io->coll)
             return fail(PW_EINVAL, "pw_policy_rollout produces the actions itself (act_out) and has no coll output");
-        if (!act_out || !io->obs || !io->rew || !io->rew_shared || !io->done || !io->terminal)
-            return fail(PW_EINVAL, "act_out and the obs, rew, rew_shared, done, terminal outputs are required");
+        if (!rsink && (!act_out || !io->obs || !io->rew || !io->rew_shared || !io->done || !io->terminal))
+            return fail(PW_EINVAL, "without a ring sink, act_out and the obs, rew, rew_shared, done, terminal outputs are required");
         if ((reinterpret_cast<uintptr_t>(io->obs) | reinterpret_cast<uintptr_t>(io->final_obs) | reinterpret_cast<uintptr_t>(frag) |
              reinterpret_cast<uintptr_t>(w_hh_fw) | reinterpret_cast<uintptr_t>(w_hh_bw)) & 15)
             return fail(PW_EINVAL, "obs, final_obs, frag and w_hh must be 16-byte aligned");
@@ -160,11 +169,24 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         R.done = io->done; R.terminal = io->terminal;
         const int rS1C = (kp.D + 7) / 8;
         if (rS1C != 3) return fail(PW_EINVAL, "simple_reference one-launch rollout: the observation is 21 numbers (3 landmarks)");
-        const size_t rshm = actor16_lds_floats(2, 32, 4 * rS1C) * sizeof(float) + (size_t)kFusedRows * kp.D * sizeof(float) + 2 * kFusedRows * sizeof(int32_t);
-        static unsigned long long attr_set = 0; /* bit = device */
-        PW_LDS_OPTIN(&attr_set, (pw_policy_rollout_ref_kernel<3>));
-        hipLaunchKernelGGL((pw_policy_rollout_ref_kernel<3>), dim3((unsigned)((kp.B + 15) / 16)), dim3(512), rshm,
-                           static_cast<hipStream_t>(stream), R);
+        const size_t rshm = actor16_lds_floats(2, 32, 4 * rS1C) * sizeof(float) + (size_t)2 * kFusedRows * kp.D * sizeof(float) + 2 * kFusedRows * sizeof(int32_t) +
+                            16 * (sizeof(double) + sizeof(int));
+        if (rsink) { R.ring = *sink->ring; R.has_ring = 1; R.ring_start = sink->ring_start; }
+        if (sink && sink->episode_return) {
+            R.episode_return = sink->episode_return; R.finished_sum = sink->finished_sum;
+            R.finished_count = sink->finished_count; R.scratch = static_cast<unsigned long long *>(sink->scratch);
+        }
+        if (sink) {
+            static unsigned long long attr_sets = 0; /* bit = device */
+            PW_LDS_OPTIN(&attr_sets, (pw_policy_rollout_ref_kernel<3, true>));
+            hipLaunchKernelGGL((pw_policy_rollout_ref_kernel<3, true>), dim3((unsigned)((kp.B + 15) / 16)), dim3(512), rshm,
+                               static_cast<hipStream_t>(stream), R);
+        } else {
+            static unsigned long long attr_set = 0; /* bit = device */
+            PW_LDS_OPTIN(&attr_set, (pw_policy_rollout_ref_kernel<3>));
+            hipLaunchKernelGGL((pw_policy_rollout_ref_kernel<3>), dim3((unsigned)((kp.B + 15) / 16)), dim3(512), rshm,
+                               static_cast<hipStream_t>(stream), R);
+        }
         PW_HIP_CHECK(hipGetLastError());
         h->last_kernel = "pw_policy_rollout_ref_kernel<3>";
         return PW_OK;

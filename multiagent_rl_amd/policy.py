@@ -227,12 +227,12 @@ class FusedActor(object):
         sink, ``out=False`` skips the step outputs altogether (only the ring / statistics are written)."""
         from ._lib import PwRolloutSink, PwStepIO
         T, B, N = int(num_steps), env.num_envs, env.n
-        two = len(self.heads) == 2   # MultiDiscrete actor: simple_reference, act [T,B,N,2] = (movement, symbol), no ring sink
+        two = len(self.heads) == 2   # MultiDiscrete actor: simple_reference, act [T,B,N,2] = (movement, symbol); the sink is a two-head ring
         if two:
             assert env.scenario_name == 'simple_reference' and self.heads == (5, env.dim_c), \
                 'two-head rollouts serve simple_reference (heads 5 | dim_c)'
-            assert memory is None and stats is None and out is not False, \
-                'simple_reference: no ring sink in the launch; append the chunk with ReplayBuffer.add_rollout'
+            assert memory is None or tuple(memory.act_heads or ()) == self.heads, \
+                'simple_reference: the ring sink is a ReplayBuffer built with act_heads=(5, dim_c)'
         else:
             assert self.heads == (5,), 'single 5-logit head only' 
         if out is False:

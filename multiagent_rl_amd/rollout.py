@@ -329,27 +329,15 @@ class BatchedRollout(object):
         runs policy + sampling + env step for the whole chunk with observations / actions / world state resident on
         the CU, and writes the transitions straight into the replay ring and the episode statistics from the same
         kernel (``pw_rollout_sink``).  ``keep_outputs=True`` also materialises the chunk's [T, ...] step outputs
-        (``self.last_chunk``).  Needs a FusedActor and a simple_spread fast-path (or homogeneous-role simple_tag) env; stores exactly what ``collect``
+        (``self.last_chunk``).  Needs a FusedActor and a simple_spread fast-path, homogeneous-role simple_tag or simple_reference env (the latter
+        with a ring built with ``act_heads=(5, dim_c)``); stores exactly what ``collect``
         stores (statistics up to float64 summation order)."""
         assert self._graph is None and hasattr(self.policy, 'rollout')
         stats = (self.episode_return, self.finished_return_sum, self.finished_episodes)
         done_steps = 0
-        two_head = len(getattr(self.policy, 'heads', (5,))) == 2
         while done_steps < num_steps:
             T = min(chunk, num_steps - done_steps)
-            if two_head:
-                # MultiDiscrete (simple_reference): the launch has no ring sink; the chunk's outputs go into the two-head ring
-                # and the episode statistics with ONE more launch (pw_replay_add_rollout): 2 launches per chunk
-                obs0 = self.obs if done_steps == 0 else self.last_chunk['obs'][-1].clone()
-                if getattr(self, '_chunk_T', None) != T:
-                    self._chunk_T, self.last_chunk = T, None
-                self.last_chunk = self.policy.rollout(self.env, T, self.last_chunk)
-                if self.memory is not None:
-                    self.memory.add_rollout(obs0, self.last_chunk, *stats)
-                else:
-                    for t in range(T):
-                        self._bookkeeping(self.last_chunk['rew_shared'][t], self.last_chunk['terminal'][t])
-            elif keep_outputs:
+            if keep_outputs:
                 if getattr(self, '_chunk_T', None) != T:
                     self._chunk_T, self.last_chunk = T, None
                 self.last_chunk = self.policy.rollout(self.env, T, self.last_chunk, memory=self.memory, stats=stats)

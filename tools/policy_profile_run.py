@@ -67,7 +67,7 @@ def main():
     ach = fl * B * T / launch_s / 1e12
     print(json.dumps(dict(workload=a.workload, scenario=scen, B=B, N=env.n, D=env.obs_dim, n_out=n_out, chunk=T, steps=a.steps,
                           warmup=a.warmup, value=B * T * a.steps / sec, unit='env-steps/s', us_per_step=sec / (a.steps * T) * 1e6,
-                          launch_ms=launch_s * 1e3, kernel=env.last_kernel(), launches_per_chunk=2 if two else 1,
+                          launch_ms=launch_s * 1e3, kernel=env.last_kernel(), launches_per_chunk=1,
                           flops_per_env_step=fl,
                           roofline=dict(bound='mfma_f32', achieved=ach, peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                                         frac=ach / F32_MFMA_PEAK_TFLOPS))))
