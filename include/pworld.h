@@ -439,12 +439,13 @@ typedef struct pw_rollout_sink {
  * optional.  The Gumbel noise of step t is keyed (seed; step + t, row) exactly as pw_actor_fused / pw_actor_head, so
  * the results equal a loop of pw_actor_fused + pw_step (+ pw_replay_add_tail).
  * simple_spread fast-path configurations (local observation, homogeneous agents, L <= N; observation rows up to
- * D = 64, i.e. N <= 30) and simple_tag with homogeneous roles (9 <= D <= 48; good agents' rows zero-padded to D), one
+ * D = 104, i.e. N = L <= 50: rows longer than 64 numbers on the just-in-time kernel form only) and simple_tag with homogeneous roles (9 <= D <= 48; good agents' rows zero-padded to D), one
  * 5-logit head; weights as for pw_actor_fused.
  * simple_reference (the MultiDiscrete scenario of main.py:24,52-54; 3 landmarks, D = 21): the two-head actor -- w2 [5 + PW_DIM_C,
  * 64] / b2 = dense2_1 and dense2_2 concatenated, one Gumbel-argmax per head exactly as pw_actor_fused(n_out0 = 5, n_out1 =
- * PW_DIM_C) -- and act_out [num_steps,B,N,2] = (movement, symbol); no ring sink (sink must be NULL: the chunk goes into a
- * two-head ring with pw_replay_add_rollout); results equal a loop of pw_actor_fused + pw_step(act_idx, act_comm). */
+ * PW_DIM_C) -- and act_out [num_steps,B,N,2] = (movement, symbol); the ring sink must be the two-head ring (act_heads = 2, head widths
+ * 5 | PW_DIM_C; 0.1.5 -- before, the chunk went into it with a second launch, pw_replay_add_rollout); results equal a loop of
+ * pw_actor_fused + pw_step(act_idx, act_comm). */
 int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const float *b_ih, const float *w_hh_fw,
                       const float *w_hh_bw, const float *w2, const float *b2, int32_t relu_out, uint64_t seed,
                       uint64_t step, const int64_t *step_dev /* device, or NULL */, const pw_step_io *io,
