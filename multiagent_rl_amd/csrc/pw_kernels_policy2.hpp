@@ -43,6 +43,15 @@ __device__ int g_pw_debug;  // probe builds only: bit 0 skips the MFMAs (tiles s
 #define PW_R2_FLUSH(base)
 #endif
 
+// Ring slot of transition (t, env) of a chunk that starts at ring_start: (ring_start + t * B + env) mod capacity WITHOUT the 64-bit
+// division (~150 instructions on the environment waves' critical path, every step): the host guarantees 0 <= ring_start < capacity and
+// T * B <= capacity, so the sum is below 2 * capacity and one conditional subtraction is the modulo.
+__device__ __forceinline__ size_t ring_slot(const int64_t ring_start, const int t, const int B, const long env, const int64_t capacity)
+{
+    const int64_t x = ring_start + (int64_t)t * B + env;
+    return (size_t)(x >= capacity ? x - capacity : x);
+}
+
 // Finished-episode statistics of a rollout launch (run.py:55-65 bookkeeping summed over all envs): every workgroup leaves its
 // partial (sum, count) in `scratch` ([gridDim.x] doubles, [gridDim.x] counts, one ticket word); the workgroup that takes the last
 // ticket adds the partials up -- with ALL its threads: 512 partials per round through LDS and a fixed binary tree (deterministic:

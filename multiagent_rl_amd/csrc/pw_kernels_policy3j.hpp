@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
         if (env_wave) {
             ai = S.s_act[r];
             if (SINK && P.has_ring) {  // the observation the policy acted on: rebuilt from the (still pre-step) registers
-                slot = (size_t)((P.ring_start + (int64_t)t * A.B + env) % P.ring.capacity);
+                slot = ring_slot(P.ring_start, t, A.B, (long)env, P.ring.capacity);
                 if (live) {
                     stream_write_obs<0>(P.ring.obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
                     P.ring.act[slot * N + a] = (uint8_t)ai;

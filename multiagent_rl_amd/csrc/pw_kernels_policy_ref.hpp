@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
             // the observations the policy acted on -> ring.obs, by the seven waves that would otherwise wait for the environment wave
             for (int idx = tid; idx < rows_here * D; idx += 448) {
                 const int rr = idx / D, c = idx - rr * D;
-                const size_t sl = (size_t)((P.ring_start + (int64_t)t * A.B + env0 + (rr >> 1)) % P.ring.capacity);
+                const size_t sl = ring_slot(P.ring_start, t, A.B, env0 + (rr >> 1), P.ring.capacity);
                 P.ring.obs[(sl * N + (rr & 1)) * D + c] = s_obs[idx];
             }
         }
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
             const size_t row = (size_t)t * BN + g;
             ai = s_act[2 * r]; ci = s_act[2 * r + 1];
             if (SINK && P.has_ring) {  // the pair the policy sampled -> ring.act (the observation rows: the idle waves, above)
-                slot = (size_t)((P.ring_start + (int64_t)t * A.B + env) % P.ring.capacity);
+                slot = ring_slot(P.ring_start, t, A.B, (long)env, P.ring.capacity);
                 if (live) {
                     P.ring.act[(slot * N + a) * 2] = (uint8_t)ai;
                     P.ring.act[(slot * N + a) * 2 + 1] = (uint8_t)ci;

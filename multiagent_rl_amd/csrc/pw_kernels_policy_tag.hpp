@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
             const size_t tBN = (size_t)t * BN;
             ai = s_act[r];
             if (SINK && P.has_ring) {  // the observation the policy acted on (still in LDS) -> ring.obs
-                slot = (size_t)((P.ring_start + (int64_t)t * A.B + env) % P.ring.capacity);
+                slot = ring_slot(P.ring_start, t, A.B, (long)env, P.ring.capacity);
                 if (live) {
                     const float2 *src = reinterpret_cast<const float2 *>(s_obs + r * D);
                     float2 *dst = reinterpret_cast<float2 *>(P.ring.obs + (slot * N + a) * D);

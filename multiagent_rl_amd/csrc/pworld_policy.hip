@@ -143,7 +143,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
                                (sink->ring->head_width[0] != 0 && sink->ring->head_width[0] != 5)))
                 return fail(PW_EINVAL, "pw_policy_rollout sink on simple_reference: the ring must be the two-head ring (act_heads = 2, widths 5 | dim_c)");
             if (sink->ring && (sink->ring->num_agents != 2 || sink->ring->obs_dim != kp.D || sink->ring->capacity < 1 ||
-                               sink->ring_start < 0 || (int64_t)num_steps * kp.B > sink->ring->capacity))
+                               sink->ring_start < 0 || sink->ring_start >= sink->ring->capacity || (int64_t)num_steps * kp.B > sink->ring->capacity))
                 return fail(PW_EINVAL, "ring sink: shape mismatch or the chunk does not fit the ring");
             if (sink->episode_return && (!sink->finished_sum || !sink->finished_count || !sink->scratch))
                 return fail(PW_EINVAL, "bookkeeping needs episode_return, finished_sum, finished_count and scratch");
@@ -206,7 +206,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     if (sink) {
         if (int rc = plain_ring_only(sink->ring, "pw_policy_rollout sink")) return rc;
         if (sink->ring && (sink->ring->num_agents != kp.N || sink->ring->obs_dim != kp.D || sink->ring->capacity < 1 ||
-                           sink->ring_start < 0 || (int64_t)num_steps * kp.B > sink->ring->capacity))
+                           sink->ring_start < 0 || sink->ring_start >= sink->ring->capacity || (int64_t)num_steps * kp.B > sink->ring->capacity))
             return fail(PW_EINVAL, "ring sink: shape mismatch or the chunk does not fit the ring");
         if (sink->episode_return && (!sink->finished_sum || !sink->finished_count || !sink->scratch))
             return fail(PW_EINVAL, "bookkeeping needs episode_return, finished_sum, finished_count and scratch");
