@@ -151,6 +151,22 @@ __device__ __forceinline__ f32x2 div_chain2(f32x2 a, float b, float y)
 // Measured (tools/step_time.hip A/B, profiles/r2_nt_stores.txt): the block-wise observation stores with the hint: B = 65536,
 // N = 6: +6.5 %, N = 24 at B = 4096: +6 %, C2: +1 %.  The row-per-lane observation stores write a quarter line each and
 // stay plain.
+#if defined(PW_EXP_NO_NT_STORES)   // timing experiments only (results are WRONG): the outputs that leave through nt_store are computed
+template <typename T>            // (kept alive by an empty asm) but not stored -- what the write stream costs a kernel
+__device__ __forceinline__ void nt_store(T *p, const T v)
+{
+    if constexpr (sizeof(T) == 8) {
+        const unsigned long long u = (unsigned long long)v;
+        asm volatile("" :: "v"(p), "v"((unsigned)u), "v"((unsigned)(u >> 32)));
+    } else if constexpr (sizeof(T) < 4) {
+        asm volatile("" :: "v"(p), "v"((unsigned)v));
+    } else {
+        asm volatile("" :: "v"(p), "v"(v));
+    }
+}
+__device__ __forceinline__ void nt_store(float4 *p, const float4 v) { asm volatile("" :: "v"(p), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+__device__ __forceinline__ void nt_store(float2 *p, const float2 v) { asm volatile("" :: "v"(p), "v"(v.x), "v"(v.y)); }
+#else
 template <typename T>
 __device__ __forceinline__ void nt_store(T *p, const T v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void nt_store(float4 *p, const float4 v)
@@ -163,6 +179,7 @@ __device__ __forceinline__ void nt_store(float2 *p, const float2 v)
     typedef float nt2 __attribute__((ext_vector_type(2)));
     __builtin_nontemporal_store(nt2{v.x, v.y}, reinterpret_cast<nt2 *>(p));
 }
+#endif
 
 // The per-agent / per-env planes take the hint only at N <= 6 (kNtPlanes in the spread kernels): C2 +2 %, B = 65536 +4 % on
 // top of the block stores, but N = 12: -2 %, N = 24: -3 %.

@@ -52,6 +52,11 @@ __device__ __forceinline__ void quad_pair_of(const int q, int &i, int &j)
 #else
 #define PW_QUAD_BARRIER(t) duo_barrier()
 #endif
+#ifndef PW_QUAD_ACT_AHEAD
+#define PW_QUAD_ACT_AHEAD 4   // steps the physics waves' action indices are fetched ahead (a power of two; LDS ring slots per wave)
+#endif
+constexpr int kQuadActAhead = PW_QUAD_ACT_AHEAD;
+constexpr int kQuadActRingBytes = kQuadActAhead * kWave * (int)sizeof(int32_t);  // per physics wave
 template <bool UNIT_MASS, bool COLL = false, bool K1 = false>
 __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamParams A, const int T)
 {
@@ -63,7 +68,7 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
     float *s_rew = s_min + kWave;                                          // [64] OA
     float2 *s_lmB = reinterpret_cast<float2 *>(s_rew + kWave);             // [8 * 6] OB (16-byte aligned)
     int32_t *s_act = reinterpret_cast<int32_t *>(s_lmB + EPW * L);         // [2 P waves][4 steps][64] action indices
-    float2 *s_utab = reinterpret_cast<float2 *>(s_act + 2 * 4 * kWave);    // [2 P waves][8] action force per index
+    float2 *s_utab = reinterpret_cast<float2 *>(s_act + 2 * kQuadActAhead * kWave);    // [2 P waves][8] action force per index
 
     // Roles by wave index, swapped in every other batch of 256 workgroups: the hardware places a workgroup's waves 0..3 on
     // the CU's SIMDs in order, and with two workgroups per CU (B = 4096: 512 workgroups on 256 CUs, workgroup j and j + 256
@@ -155,15 +160,15 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         // Action indices: fetched four steps ahead by LDS-direct loads (pw_common.hpp, act_fetch_issue: under a full chip
         // a load issued one step ahead cost 385 cycles of every step)
         const int32_t *act_g = A.act + g;
-        int32_t *act_ring = s_act + wave * (4 * kWave);
+        int32_t *act_ring = s_act + wave * (kQuadActAhead * kWave);
         const uint32_t act_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(act_ring));
         auto fetch_act = [&](int t) {  // indices of step t (clamped: the tail re-fetches the last step) -> slot t & 3
-            act_fetch_issue(act_g + (size_t)(t < T ? t : T - 1) * BN, act_lds + (uint32_t)(t & 3) * (kWave * 4));
+            act_fetch_issue(act_g + (size_t)(t < T ? t : T - 1) * BN, act_lds + (uint32_t)(t & (kQuadActAhead - 1)) * (kWave * 4));
         };
         // every load the compiler counts is consumed before the first uncounted one is issued: a counted wait inside the
         // loop (for a value first used there) would be short by the fetches in flight, i.e. drain them
         asm volatile("" :: "v"(ep_off), "v"(ep_count), "v"(offs_all), "v"(px), "v"(py), "v"(vx), "v"(vy), "s"(t_reset));
-        fetch_act(0); fetch_act(1); fetch_act(2); fetch_act(3);
+        for (int t0 = 0; t0 < kQuadActAhead; ++t0) fetch_act(t0);
         // the pair lanes' operands of the coming step are fetched right after the publish, before the barrier (this
         // wave only reads its own envs' entries, and a wave's LDS operations execute in issue order): the read's latency
         // hides behind the barrier
@@ -172,10 +177,10 @@ __global__ void __launch_bounds__(4 * kWave) pw_spread_quad_kernel(const StreamP
         PW_STAMP_DECL;
         for (int t = 0; t < T; ++t) {
             PW_STAMP_START;
-            act_fetch_wait3();  // step t's indices are in LDS
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kQuadActAhead - 1) : "memory");  // step t's indices are in LDS (the later fetches stay in flight)
             PW_STAMP(3);
-            const uint32_t ai = (uint32_t)act_ring[(t & 3) * kWave + lane];
-            fetch_act(t + 4);  // into the slot just read (its wait for the read above is the one the table lookup needs anyway)
+            const uint32_t ai = (uint32_t)act_ring[(t & (kQuadActAhead - 1)) * kWave + lane];
+            fetch_act(t + kQuadActAhead);  // into the slot just read (its wait for the read above is the one the table lookup needs anyway)
             const float2 u0 = utab[ai < 5u ? ai : 5u];  // {u_x + 0, u_y + 0}: the accumulators' starting values
             const bool two_slots = t == t_reset;        // workgroup-uniform: some env of the workgroup resets in this step
             // ---- pair phase: every unordered pair of the wave's envs at once

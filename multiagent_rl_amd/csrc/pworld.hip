@@ -382,7 +382,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
             if (dp.quad >= 0) quad = quad_ok && dp.quad != 0;
             if (quad) {
                 const size_t qshm = 4 * kWave * sizeof(float4) + 2 * 4 * 6 * 6 * sizeof(float2) + 2 * kWave * sizeof(float) +
-                                    8 * 6 * sizeof(float2) + 2 * kActRingBytes + 2 * 8 * sizeof(float2);
+                                    8 * 6 * sizeof(float2) + 2 * kQuadActRingBytes + 2 * 8 * sizeof(float2);
                 const bool k1 = h->fc.k1 != 0;  // the canonical margin 1e-3 qualifies
                 if (wc && k1) PW_LAUNCH(h, (pw_spread_quad_kernel<true, true, true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
                 else if (wc) PW_LAUNCH(h, (pw_spread_quad_kernel<true, true>), dim3(qgrid), dim3(4 * kWave), qshm, st, A, T);
