@@ -235,3 +235,39 @@ def test_train_batched_through_the_full_gather_on_one_rank(tmp_path):
     torch.cuda.synchronize()
     for name in ('obs', 'next_obs', 'act', 'rew', 'done'):
         assert torch.equal(getattr(gather.memory, name)[:2 * T * B], getattr(want, name)[:2 * T * B]), name
+
+
+def test_learn_gate_and_ledger_properties():
+    """Property checks (hypothesis): chunked gate openings add up to the per-step gate whatever the chunking; the ledger's episode
+    returns do not depend on where the chunks are cut."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(warm=st.integers(0, 500), rate=st.integers(1, 97), cuts=st.lists(st.integers(1, 400), min_size=1, max_size=12))
+    def gate(warm, rate, cuts):
+        cfg = _Args()
+        cfg.warmup_steps, cfg.update_rate = warm, rate
+        g = LearnGate(cfg)
+        total, pos = 0, 0
+        for c in cuts:
+            total += g.due_between(pos, pos + c)
+            pos += c
+        assert total == sum(1 for s in range(1, pos + 1) if g.due(s))
+
+    @settings(max_examples=25, deadline=None)
+    @given(seed=st.integers(0, 10 ** 6), cut=st.integers(1, 59))
+    def ledger(seed, cut):
+        g = torch.Generator().manual_seed(seed)
+        T, B, N = 60, 4, 2
+        rew = torch.randn(T, B, N, generator=g)
+        term = torch.rand(T, B, generator=g) < 0.15
+        whole, parts = ChunkLedger(B, N, 'cpu'), ChunkLedger(B, N, 'cpu')
+        whole.absorb(rew, term)
+        parts.absorb(rew[:cut], term[:cut])
+        parts.absorb(rew[cut:], term[cut:])
+        assert len(whole.totals) == len(parts.totals) == int(term.sum())
+        np.testing.assert_allclose(sorted(whole.totals), sorted(parts.totals), rtol=0, atol=1e-9)   # the order inside a chunk is (episode index, env)
+        np.testing.assert_allclose(whole.carry.numpy(), parts.carry.numpy(), rtol=0, atol=1e-9)
+
+    gate()
+    ledger()
