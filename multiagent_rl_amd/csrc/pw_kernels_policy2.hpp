@@ -43,6 +43,32 @@ __device__ int g_pw_debug;  // probe builds only: bit 0 skips the MFMAs (tiles s
 #define PW_R2_FLUSH(base)
 #endif
 
+// Ordered per-env reductions by wave shuffle for a runtime agent count: acc (+/-)= shfl(v, base + i) for i = 0 .. n - 1 IN THAT ORDER
+// (the upstream summation order: the bits depend on it), with four shuffles in flight per round -- issued one at a time, each
+// ds_bpermute's ~120-cycle round trip is exposed: 36 of them per step at N = 12, 72 at N = 24, on the environment waves' critical path.
+__device__ __forceinline__ float shfl_sub_ordered(float acc, const float v, const int base, const int n)
+{
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const float a0 = __shfl(v, base + i, kWave), a1 = __shfl(v, base + i + 1, kWave);
+        const float a2 = __shfl(v, base + i + 2, kWave), a3 = __shfl(v, base + i + 3, kWave);
+        acc -= a0; acc -= a1; acc -= a2; acc -= a3;
+    }
+    for (; i < n; ++i) acc -= __shfl(v, base + i, kWave);
+    return acc;
+}
+__device__ __forceinline__ float shfl_add_ordered(float acc, const float v, const int base, const int n)
+{
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const float a0 = __shfl(v, base + i, kWave), a1 = __shfl(v, base + i + 1, kWave);
+        const float a2 = __shfl(v, base + i + 2, kWave), a3 = __shfl(v, base + i + 3, kWave);
+        acc += a0; acc += a1; acc += a2; acc += a3;
+    }
+    for (; i < n; ++i) acc += __shfl(v, base + i, kWave);
+    return acc;
+}
+
 // Ring slot of transition (t, env) of a chunk that starts at ring_start: (ring_start + t * B + env) mod capacity WITHOUT the 64-bit
 // division (~150 instructions on the environment waves' critical path, every step): the host guarantees 0 <= ring_start < capacity and
 // T * B <= capacity, so the sum is below 2 * capacity and one conditional subtraction is the modulo.

@@ -271,15 +271,20 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
         wave_lds_sync();
         stream_partner_pass<NT, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
         const float own = sqrtf(best);
-        float rw = 0.0f;
-#pragma unroll(LT > 0 ? LT : 1)
-        for (int l = 0; l < L; ++l) rw -= __shfl(own, base + l, kWave);
-#pragma unroll(NT > 0 ? NT : 1)
-        for (int j = 0; j < N; ++j)
-            if ((coll >> j) & 1) rw -= 1.0f;
-        float acc = 0.0f;
-#pragma unroll(NT > 0 ? NT : 1)
-        for (int i = 0; i < N; ++i) acc += __shfl(rw, base + i, kWave);
+        float rw = 0.0f, acc = 0.0f;
+        if (NT > 0) {
+#pragma unroll
+            for (int l = 0; l < LT; ++l) rw -= __shfl(own, base + l, kWave);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                if ((coll >> j) & 1) rw -= 1.0f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc += __shfl(rw, base + i, kWave);
+        } else {  // runtime N: shuffles four at a time; "-1 per colliding agent" as many times as the mask has bits (equal subtrahends)
+            rw = shfl_sub_ordered(rw, own, base, L);
+            for (int c = __builtin_popcountll(coll); c > 0; --c) rw -= 1.0f;
+            acc = shfl_add_ordered(acc, rw, base, N);
+        }
         ep_step += 1;
         t_term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
         t_rw = rw;

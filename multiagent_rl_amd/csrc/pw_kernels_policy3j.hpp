@@ -254,12 +254,9 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
         wave_lds_sync();
         stream_partner_pass<0, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
         const float own = sqrtf(best);
-        float rw = 0.0f;
-        for (int l = 0; l < L; ++l) rw -= __shfl(own, base + l, kWave);
-        for (int j = 0; j < N; ++j)
-            if ((coll >> j) & 1) rw -= 1.0f;
-        float acc = 0.0f;
-        for (int i = 0; i < N; ++i) acc += __shfl(rw, base + i, kWave);
+        float rw = shfl_sub_ordered(0.0f, own, base, L);   // shuffles four at a time, upstream's order
+        for (int c = __builtin_popcountll(coll); c > 0; --c) rw -= 1.0f;   // "-1 per colliding agent": equal subtrahends, only their number matters
+        const float acc = shfl_add_ordered(0.0f, rw, base, N);
         ep_step += 1;
         const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
         if (SINK && live && a == 0 && P.episode_return) {  // run.py:55-65, per env

@@ -439,9 +439,7 @@ __device__ __forceinline__ void stream_partner_pass(const int N, const int a, co
                                                     MaskT &coll, MaskT &near, float &best)
 {
     coll = 0; near = 0; best = 0.0f;
-#pragma unroll(NT > 0 ? NT : 1)
-    for (int j = 0; j < (NT ? NT : N); ++j) {
-        const float2 q = pp[j];
+    auto one = [&](const float2 q, const int j) {
         const float dx = q.x - px, dy = q.y - py;
         const float d2 = dx * dx + dy * dy;
         if (d2 < coll_thr2) coll |= (MaskT)1 << j;
@@ -450,6 +448,19 @@ __device__ __forceinline__ void stream_partner_pass(const int N, const int a, co
         const float ex = q.x - olx, ey = q.y - oly;
         const float e2 = ex * ex + ey * ey;
         best = (j == 0 || e2 < best) ? e2 : best;
+    };
+    if (NT > 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) one(pp[j], j);
+    } else {
+        // runtime N: four LDS reads in flight per round (one read, wait, compute per partner cost ~120 cycles each -- 3 k cycles of a
+        // step at N = 24 on waves nothing hides); the partners are still visited in ascending order: the same bits
+        int j = 0;
+        for (; j + 4 <= N; j += 4) {
+            const float2 q0 = pp[j], q1 = pp[j + 1], q2 = pp[j + 2], q3 = pp[j + 3];
+            one(q0, j); one(q1, j + 1); one(q2, j + 2); one(q3, j + 3);
+        }
+        for (; j < N; ++j) one(pp[j], j);
     }
 }
 

@@ -1,5 +1,5 @@
 // Diagnostic build (never shipped): pworld.hip compiled with PW_STAMPS; shader cycles of wave 0 / workgroup 0 per
-// phase of pw_policy_rollout_kernel.
+// phase of pw_policy_rollout3_kernel (forms 1 / 2 were retired in round 4).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -I include tools/policy_rollout_probe.hip -o tools/policy_rollout_probe.bin
 #define PW_STAMPS 1
 #include "../multiagent_rl_amd/csrc/pworld.hip"
@@ -8,7 +8,7 @@
 
 int main(int argc, char **argv)
 {
-    const int B = argc > 1 ? atoi(argv[1]) : 4096, N = 6, T = 100;
+    const int B = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 3 ? atoi(argv[3]) : 6, T = 100;   // argv: B, debug mask, N
     pw_config cfg;
     pw_config_default(&cfg, PW_SIMPLE_SPREAD, B, N, -1, 0);
     cfg.auto_reset = 1; cfg.max_episode_len = 25;
@@ -41,14 +41,7 @@ int main(int argc, char **argv)
     printf("B=%d: %.2f us per step (%s)\n", B, ms * 1000.f / (5 * T), pw_last_error());
     unsigned long long s[16];
     hipMemcpyFromSymbol(s, HIP_SYMBOL(g_pw_stamps), sizeof(s));
-    if (getenv("PWORLD_POLICY_V1")) {
-        const char *names[4] = {"actor pass", "barrier after actor", "env step (waves 0-1)", "barrier after env"};
-        double sum = 0; for (int i = 8; i < 12; ++i) sum += s[i];
-        for (int i = 0; i < 4; ++i) printf("  %-28s %9.0f cycles/step %5.1f%%\n", names[i], s[8 + i] / (double)T, 100.0 * s[8 + i] / sum);
-        printf("  total %.0f cycles/step\n", sum / T);
-        const char *an[8] = {"fill dir 0 + barrier", "stage 1", "fill dir 1 + barrier", "stage 2 MFMA", "barrier", "recurrence", "barrier", "head"};
-        for (int i = 0; i < 8; ++i) printf("    last actor pass: %-24s %8llu cycles\n", an[i], s[i]);
-    } else if (!getenv("PWORLD_POLICY_V2")) {
+    {
         const char *mn[8] = {"dense1 block", "  barrier", "  BiLSTM timestep loop (N barriers)", "  head (one barrier inside)", "  env step, part 1 (env waves) / noise", "  barrier", "  env step, tail (env waves)", "  -"};
         for (int wv = 0; wv < 2; ++wv) {
             double sm = 0; for (int i = 0; i < 8; ++i) sm += s[8 * wv + i];
@@ -56,15 +49,6 @@ int main(int argc, char **argv)
             for (int i = 0; i < 8; ++i) printf("  %-44s %9.0f cycles/step %5.1f%%\n", mn[i], s[8 * wv + i] / (double)T, 100.0 * s[8 * wv + i] / sm);
             printf("  total %.0f cycles/step\n", sm / T);
         }
-    } else {
-        const char *mn[8] = {"matrix wave 0: stage 1 of tiles 0, 2", "  stage 2 pair (fw 0, rev 2)", "  stage 1 of tile 1", "  stage 2 pair (fw 1, rev 1)", "  stage 2 pair (fw 2, rev 0)", "  wait B1 (recurrences done)", "  head (B2, B3 inside)", "  env step + wait B4"};
-        const char *ln[5] = {"LSTM wave 4: waiting for row tiles", "  recurrence", "  wait B1", "  head (B2, B3 inside)", "  wait B4 (env step of waves 0-1)"};
-        double sm = 0, sl = 0; for (int i = 0; i < 8; ++i) sm += s[i];
-        for (int i = 0; i < 5; ++i) sl += s[8 + i];
-        for (int i = 0; i < 8; ++i) printf("  %-44s %9.0f cycles/step %5.1f%%\n", mn[i], s[i] / (double)T, 100.0 * s[i] / sm);
-        printf("  total %.0f cycles/step\n", sm / T);
-        for (int i = 0; i < 5; ++i) printf("  %-44s %9.0f cycles/step %5.1f%%\n", ln[i], s[8 + i] / (double)T, 100.0 * s[8 + i] / sl);
-        printf("  total %.0f cycles/step\n", sl / T);
     }
     return 0;
 }
