@@ -341,11 +341,31 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
     };
     int tail_stage = 0;  // 0 nothing pending; 1: tail_compute of step t - 1 pending; 2: its tail_stores pending
 
+    // dense1 blocks of this wave (bit = block), dealt once per launch: the environment waves run the previous step's tail_compute in the
+    // same window -- ~2.4 blocks' worth of time, slowed by the matrix instructions their SIMD neighbours issue -- so a block goes to the
+    // wave with the least load, an environment wave counting 2.4 ahead (stamps at N = 9 / 12, profiles/r4_policy_forms.txt: the
+    // environment waves were the long pole of the window by 3-4 k cycles when every wave took block w, w + 8, ...)
+    uint64_t my_blocks = 0;
+    {
+        int load10[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) load10[w] = w >= 8 - n_env_waves ? 24 : 0;   // tenths of a block
+        for (int blk = 0; blk < nblk; ++blk) {
+            int best_w = 0;
+#pragma unroll
+            for (int w = 1; w < 8; ++w) best_w = load10[w] < load10[best_w] ? w : best_w;   // first minimum: waves from 0 up
+#pragma unroll
+            for (int w = 0; w < 8; ++w) load10[w] += w == best_w ? 10 : 0;
+            if (best_w == wave) my_blocks |= 1ull << blk;
+        }
+    }
+
     for (int t = 0; t < P.T; ++t) {
         PW_R2_START;
-        if (tail_stage == 1) { tail_compute(); tail_stage = 2; }  // step t - 1, beside the dense1 blocks of the first waves
+        if (tail_stage == 1) { tail_compute(); tail_stage = 2; }  // step t - 1, beside the dense1 blocks of the other waves
         // ---- dense1 + ReLU: 32 x 32 blocks of relu(W1 X^T + b1), column rho = 16 * timestep + sequence
-        for (int blk = wave; blk < nblk && !PW_DBG(1); blk += 8) {
+        for (uint64_t todo = PW_DBG(1) ? 0 : my_blocks; todo; todo &= todo - 1) {
+            const int blk = __builtin_ctzll(todo);
             const int rt = blk >> 1, m = blk & 1;
             // the observation row behind column rt * 32 + col: agent ts of local env n (slots past N or past the envs of
             // this workgroup read a valid row; nobody uses their results)
