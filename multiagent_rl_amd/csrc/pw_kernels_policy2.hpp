@@ -17,10 +17,25 @@ __device__ __forceinline__ void lds_write_obs_row(float *o, const int L, const f
     float2 *o2 = reinterpret_cast<float2 *>(o);
     o2[0] = make_float2(vx, vy);
     o2[1] = make_float2(px, py);
-#pragma unroll(LT > 0 ? LT : 1)
-    for (int l = 0; l < (LT ? LT : L); ++l) {
-        const float2 q = lm[l];
-        o2[2 + l] = make_float2(q.x - px, q.y - py);
+    if (LT > 0) {
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            const float2 q = lm[l];
+            o2[2 + l] = make_float2(q.x - px, q.y - py);
+        }
+    } else {  // runtime L: four landmark reads in flight per round (one LDS round trip per landmark otherwise: ~1.2 k cycles at L = 12)
+        int l = 0;
+        for (; l + 4 <= L; l += 4) {
+            const float2 q0 = lm[l], q1 = lm[l + 1], q2 = lm[l + 2], q3 = lm[l + 3];
+            o2[2 + l] = make_float2(q0.x - px, q0.y - py);
+            o2[3 + l] = make_float2(q1.x - px, q1.y - py);
+            o2[4 + l] = make_float2(q2.x - px, q2.y - py);
+            o2[5 + l] = make_float2(q3.x - px, q3.y - py);
+        }
+        for (; l < L; ++l) {
+            const float2 q = lm[l];
+            o2[2 + l] = make_float2(q.x - px, q.y - py);
+        }
     }
 }
 

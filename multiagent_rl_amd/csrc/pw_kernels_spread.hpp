@@ -286,10 +286,23 @@ __device__ __forceinline__ void stream_write_obs(float *__restrict__ o, const in
     if ((LT ? LT : L) % 2 == 0) {
         float4 *o4 = reinterpret_cast<float4 *>(o);
         o4[0] = make_float4(vx, vy, px, py);
-#pragma unroll(LT > 0 ? LT / 2 : 1)
-        for (int c = 0; c < (LT ? LT : L) / 2; ++c) {
-            const float2 l0 = lm[2 * c], l1 = lm[2 * c + 1];
-            o4[1 + c] = make_float4(l0.x - px, l0.y - py, l1.x - px, l1.y - py);
+        if (LT > 0) {
+#pragma unroll
+            for (int c = 0; c < LT / 2; ++c) {
+                const float2 l0 = lm[2 * c], l1 = lm[2 * c + 1];
+                o4[1 + c] = make_float4(l0.x - px, l0.y - py, l1.x - px, l1.y - py);
+            }
+        } else {  // runtime L: four landmark reads in flight per round
+            int c = 0;
+            for (; c + 2 <= L / 2; c += 2) {
+                const float2 l0 = lm[2 * c], l1 = lm[2 * c + 1], l2 = lm[2 * c + 2], l3 = lm[2 * c + 3];
+                o4[1 + c] = make_float4(l0.x - px, l0.y - py, l1.x - px, l1.y - py);
+                o4[2 + c] = make_float4(l2.x - px, l2.y - py, l3.x - px, l3.y - py);
+            }
+            for (; c < L / 2; ++c) {
+                const float2 l0 = lm[2 * c], l1 = lm[2 * c + 1];
+                o4[1 + c] = make_float4(l0.x - px, l0.y - py, l1.x - px, l1.y - py);
+            }
         }
     } else {
         float2 *o2 = reinterpret_cast<float2 *>(o);
