@@ -93,22 +93,35 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
     float ep_ret = 0.f;
     double fin_sum = 0.0;
     int fin_cnt = 0;
+    // BASELINE configs[2]'s roster (4 adversaries + 2 good agents, 2 landmarks) takes the unrolled row writer / partner loops: with
+    // runtime bounds every LDS read of a loop is a round trip of its own (~120 exposed cycles each, ~10 per row)
+    const bool c3 = N == 6 && NA == 4 && L == 2;
+    auto write_row = [&](float *dst) {
+        if (c3) tag_write_obs<6, 4, 2>(dst, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+        else tag_write_obs<0, -1, 0>(dst, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+    };
     auto partner_pass = [&]() {
         coll = 0; near_a = 0; near_l = 0;
-        for (int j = 0; j < N; ++j) {
-            const float2 q = pp[j];
+        auto agent = [&](const float2 q, const int j) {
             const float dx = q.x - px, dy = q.y - py;
             const float d2 = dx * dx + dy * dy;
             const bool jg = j >= NA;
             if (d2 < (jg ? cthr_good : cthr_adv)) coll |= 1ull << j;
             if (bits_near(d2, jg ? nthr_good : nthr_adv)) near_a |= 1ull << j;
-        }
-        near_a &= ~(1ull << a);
-        for (int l = 0; l < L; ++l) {
-            const float2 q = lmv[l];
+        };
+        auto landmark = [&](const float2 q, const int l) {
             const float dx = q.x - px, dy = q.y - py;
             if (bits_near(dx * dx + dy * dy, nthr_lm)) near_l |= 1ull << l;
+        };
+        if (c3) {  // all eight LDS reads in flight
+            const float2 q0 = pp[0], q1 = pp[1], q2 = pp[2], q3 = pp[3], q4 = pp[4], q5 = pp[5], l0 = lmv[0], l1 = lmv[1];
+            agent(q0, 0); agent(q1, 1); agent(q2, 2); agent(q3, 3); agent(q4, 4); agent(q5, 5);
+            landmark(l0, 0); landmark(l1, 1);
+        } else {
+            for (int j = 0; j < N; ++j) agent(pp[j], j);
+            for (int l = 0; l < L; ++l) landmark(lmv[l], l);
         }
+        near_a &= ~(1ull << a);
     };
     if (env_wave) {
         if (SINK && P.episode_return && live && a == 0) ep_ret = P.episode_return[env];
@@ -120,7 +133,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
         if (live) { s_pos[me] = make_float2(px, py); s_vel[me] = make_float2(vx, vy); }
         wave_lds_sync();
         partner_pass();
-        if (live) tag_write_obs<0, -1, 0>(s_obs + r * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+        if (live) write_row(s_obs + r * D);
     }
     const float k = V.contact_margin, cf = V.contact_force, dt = V.dt, damp = V.damp, mass = V.mass;
     const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
@@ -146,6 +159,10 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
                 if ((coll >> q) & 1) rw -= 10.0f;
             rw -= tag_bound(fabsf(px));
             rw -= tag_bound(fabsf(py));
+        } else if (c3) {  // both good agents' masks in flight (N = 6: the low words hold everything)
+            const uint32_t m4 = s_mlo[base + 4], m5 = s_mlo[base + 5];
+            rw += 10.0f * (float)__builtin_popcount(m4 & (uint32_t)adv_bits);
+            rw += 10.0f * (float)__builtin_popcount(m5 & (uint32_t)adv_bits);
         } else {
             for (int gj = NA; gj < N; ++gj) {
                 const uint64_t mg = ((uint64_t)s_mhi[base + gj] << 32) | s_mlo[base + gj];
@@ -155,7 +172,13 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
         if (live) s_rew[me] = rw;
         wave_lds_sync();
         float acc = 0.0f;
-        for (int i = 0; i < N; ++i) acc += s_rew[base + i];
+        if (c3) {  // the six rewards in flight, added in agent order
+            const float r0 = s_rew[base], r1 = s_rew[base + 1], r2 = s_rew[base + 2], r3 = s_rew[base + 3], r4 = s_rew[base + 4],
+                        r5 = s_rew[base + 5];
+            acc += r0; acc += r1; acc += r2; acc += r3; acc += r4; acc += r5;
+        } else {
+            for (int i = 0; i < N; ++i) acc += s_rew[base + i];
+        }
         ep_step += 1;
         t_term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
         t_rw = rw;
@@ -181,7 +204,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
             if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
                 float *dst = P.ring.next_obs + (slot * N + a) * D;
                 if (with_obs) for (int c = 0; c < D / 2; ++c) reinterpret_cast<float2 *>(dst)[c] = row[c];
-                else tag_write_obs<0, -1, 0>(dst, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                else write_row(dst);
                 if (a == 0) { P.ring.rew[slot] = t_acc; P.ring.done[slot] = 0.0f; }
             }
             if (with_obs && V.obs) {
@@ -246,7 +269,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
                 const bool term = t_term;
                 if (term && V.auto_reset) {  // same for every lane of an env
                     if (live && V.final_obs)
-                        tag_write_obs<0, -1, 0>(V.final_obs + (tBN + g) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                        write_row(V.final_obs + (tBN + g) * D);
                     wave_lds_sync();
                     ep_count += 1;
                     ep_step = 0;
@@ -263,11 +286,11 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
                 wave_lds_sync();
                 if (__any(term && V.auto_reset)) partner_pass();
                 if (live) {
-                    if (V.obs) tag_write_obs<0, -1, 0>(V.obs + (tBN + g) * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
-                    tag_write_obs<0, -1, 0>(s_obs + r * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                    if (V.obs) write_row(V.obs + (tBN + g) * D);
+                    write_row(s_obs + r * D);
                 }
             } else {
-                if (live) tag_write_obs<0, -1, 0>(s_obs + r * D, N, NA, L, D, a, lmv, pp, vv, px, py, vx, vy);
+                if (live) write_row(s_obs + r * D);
                 tail_stage = 1;
                 tail_t = t;
             }
