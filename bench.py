@@ -232,11 +232,19 @@ class _StubEnv(object):
             out['final_obs'].fill_(-float(1000 * self.rank + k))
 
 
-def _profile_lookup(scenario, N, B, kernel=None):
+_PROFILE_REFUSED = []   # (file, reason) of summaries that matched a workload but were collected from other kernel code
+
+
+def _profile_lookup(scenario, N, B, kernel=None, policy=False):
     """Counter-side figures of the dominant kernel from the committed rocprofv3 summaries (profiles/): HBM traffic
     per ENV-STEP (FETCH_SIZE + WRITE_SIZE passes, per the MI355X guide) and the VALU issue share (SQ counters).
-    PMC counters cannot be read from inside this process; bench scales the per-env-step figure to its launch."""
+    PMC counters cannot be read from inside this process; bench scales the per-env-step figure to its launch.
+    A summary is quoted only if it was collected from the kernel code this tree holds: it records the hash of the kernel
+    family's sources (tools/summarize_prof.py -> kernel_source_sha16; multiagent_rl_amd/build_native.py kernel_source_hash) and
+    one whose hash differs -- or that predates the hash (rounds 1-4) -- is REFUSED, never replayed (the r3 summaries
+    were quoted in the r4 line after the kernels had changed)."""
     import glob
+    from multiagent_rl_amd import build_native
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_summary.json')), reverse=True):
         try:
@@ -244,14 +252,28 @@ def _profile_lookup(scenario, N, B, kernel=None):
         except Exception:
             continue
         w = sm.get('workload', {})
-        if w.get('scenario') == scenario and w.get('N') == N and w.get('B') == B and 'traffic_bytes_per_env_step' in sm:
+        if w.get('scenario') == scenario and w.get('N') == N and w.get('B') == B and bool(w.get('policy')) == policy \
+                and 'traffic_bytes_per_env_step' in sm:
             # counters belong to a kernel: only a profile of the kernel that actually ran is quoted
             fam = (kernel or '').split('<')[0]
             if fam and fam not in sm.get('kernel', ''):
                 continue
-            best = dict(sm, _file=os.path.relpath(f, ROOT))
+            rel = os.path.relpath(f, ROOT)
+            have = sm.get('kernel_source_sha16')
+            want = build_native.kernel_source_hash(sm.get('kernel_family') or build_native.kernel_family(sm.get('kernel', '')))
+            if have != want:
+                _PROFILE_REFUSED.append((rel, 'no kernel-source hash recorded (collected before round 5)' if have is None else
+                                         'kernel sources changed since it was collected (%s then, %s now)' % (have, want)))
+                continue
+            best = dict(sm, _file=rel)
             break
     return best
+
+
+def _profile_refusals(prefix_filter=None):
+    """Why no counter traffic is quoted, if a summary exists but was refused."""
+    r = [x for x in _PROFILE_REFUSED if prefix_filter is None or prefix_filter in x[0]]
+    return None if not r else 'refused: %s -- %s' % r[0]
 
 
 def main():
@@ -560,10 +582,12 @@ def main():
                          'traffic': traffic, 'frac_by_traffic': frac_by_traffic,
                          'frac_vs_store_ceiling': None if traffic is None else traffic / (launch_ms * 1e-3) / 1e9 / STORE_CEILING_GBPS,
                          'store_ceiling_GBps': STORE_CEILING_GBPS,
-                         'traffic_source': None if prof is None else
-                         '%s: %.1f B/env-step (FETCH_SIZE + WRITE_SIZE passes of a %s-step launch) x %d env-steps'
+                         'traffic_source': _profile_refusals() if prof is None else
+                         '%s: %.1f B/env-step (FETCH_SIZE + WRITE_SIZE passes of a %s-step launch; kernel sources %s = this '
+                         'tree) x %d env-steps'
                          % (prof['_file'], prof['traffic_bytes_per_env_step'],
-                            prof.get('workload', {}).get('steps_per_launch'), env_steps_per_launch),
+                            prof.get('workload', {}).get('steps_per_launch'), prof.get('kernel_source_sha16'), env_steps_per_launch),
+                         'profile_launch_ms': None if prof is None else prof.get('timed_avg_ns', prof.get('avg_ns', 0.0)) * 1e-6,
                          'issue': issue,
                          'algorithmic_bytes_per_launch': bytes_per_launch, 'kernel': kernel, 'launch_ms': launch_ms,
                          'bytes_per_env_step': env.bytes_per_env_step, 'env_steps_per_launch': env_steps_per_launch,
@@ -627,6 +651,11 @@ def main():
                 note='value = sharded rollout + sampled exchange (a full gather at this rate would need TB/s per peer: '
                      'DESIGN.md 6); the full gather is measured with the policy in the loop')
         line['other_configs_summary'] = summ
+        # key order of the printed line: everything short first -- multi_gpu (the full gather's per-link rate and completeness)
+        # right behind roofline / cpu_baseline -- the long arrays (policy_in_loop, other_configs) after it, the compact summary last:
+        # a record that keeps only the head or only the tail of the line still carries the figures that matter
+        late = ('policy_in_loop', 'other_configs', 'other_configs_summary')
+        line = dict([(k, v) for k, v in line.items() if k not in late] + [(k, line[k]) for k in late if k in line])
         print(json.dumps(line, allow_nan=False), flush=True)
     if isinstance(policy_line, dict) and policy_line.get('fatal'):
         # the extra raised on THIS rank: its peers are inside collectives it will not join -- leave, loudly, once the root's
@@ -788,10 +817,17 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
     label = 'FusedActor (reference ActorNetwork: Linear-BiLSTM-Linear, random init) + Gumbel sampling'
 
     if not use_dist:
-        def timed_collect(ro, chunks):
-            """One warm-up chunk, then `chunks` chunks bracketed by a HIP-event pair on the launch stream (torch's current
-            stream is the one every launch of BatchedRollout goes to) and by the host clock."""
-            ro.collect_one_launch(Tp, chunk=Tp)
+        def timed_collect(ro, chunks, ramp_ms=60.0, warm=3):
+            """The headline's methodology (and tools/policy_profile_run.py's): the same chunk untimed for ramp_ms (clock ramp: a chip
+            that idled through the previous leg's set-up reaches its sustained clock only after tens of milliseconds of load -- one
+            warm-up chunk of 1.4 ms left the timed chunks 7 % slower than the profile run), `warm` more untimed chunks,
+            then `chunks` chunks bracketed by a HIP-event pair on the launch stream (torch's current stream is the one every launch
+            of BatchedRollout goes to) and by the host clock."""
+            t_r = time.perf_counter()
+            while (time.perf_counter() - t_r) * 1e3 < ramp_ms:
+                ro.collect_one_launch(Tp, chunk=Tp)
+                sync()
+            ro.collect_one_launch(warm * Tp, chunk=Tp)
             sync()
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             t = time.perf_counter()
@@ -808,8 +844,14 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
             per_launch = float(fl) * env.num_envs * steps / launches
             launch_s = seconds / launches
             ach = per_launch / launch_s / 1e12
+            # counter side (HBM traffic per launch, MFMA busy share) from the committed summary of THIS kernel code, if there is one
+            prof = _profile_lookup(env.scenario_name, env.n, env.num_envs, env.last_kernel(), policy=True)
             return dict(bound='mfma_f32', achieved=ach, peak=F32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F32_MFMA_PEAK_TFLOPS,
                         flops_per_env_step=fl, algorithmic_flops_per_launch=per_launch, launch_ms=launch_s * 1e3,
+                        traffic=None if prof is None else prof['traffic_bytes_per_env_step'] * env.num_envs * steps / launches,
+                        mfma_busy_share=None if prof is None else prof.get('mfma_busy_share'),
+                        traffic_source=_profile_refusals('policy') if prof is None else prof['_file'],
+                        profile_launch_ms=None if prof is None else prof.get('timed_avg_ns', 0.0) * 1e-6,
                         kernel=env.last_kernel(), env_steps_per_launch=env.num_envs * steps // launches,
                         note='2 N (64 D + 64x256 + 2x32x128 + 64 n_out) flop per env-step (rls/model/ac_network_multi_gumbel.py:52-67), '
                              'exact f32 on v_mfma_f32_16x16x4_f32; the environment step, sampling and ring append ride in the same launch')
@@ -821,7 +863,7 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
                     actor_precision=penv.get_actor_precision(),
                     exact=penv.get_actor_precision() == 'f32',
                     loop='%d-step chunks, one launch each: pw_policy_rollout (actor + sampling + env step + device '
-                         'replay append + episode stats)' % Tp,
+                         'replay append + episode stats); %d chunks timed after a 60 ms clock ramp + 3 warm-up chunks' % (Tp, n_chunks),
                     roofline=mfma_roofline(penv, 5, tp_ev, n_chunks * Tp, n_chunks))
         # every further figure is an extra of this extra: one that fails is recorded under its own key, the figure above stays
         # the per-step form: actor, env step, replay append + bookkeeping = 3 launches per step in a hipGraph
@@ -842,7 +884,12 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
                 ('simple_tag 4+2, B=8192',
                  lambda: BatchedParticleEnv('simple_tag', 8192, num_adversaries=4, num_good=2, max_episode_len=25, auto_reset=True, seed=1), 5, 1e6),
                 ('simple_reference (two-head actor [5|10]), B=%d' % B,
-                 lambda: BatchedParticleEnv('simple_reference', B, max_episode_len=25, auto_reset=True, seed=3), [5, 10], 8e6)):
+                 lambda: BatchedParticleEnv('simple_reference', B, max_episode_len=25, auto_reset=True, seed=3), [5, 10], 8e6),
+                # the reference's own scalability axis (main_scalability_1.py:30: n_agent in [6, 9, 12]) and BASELINE C5 beyond it
+                ('simple_spread N=12, B=4096 (the reference\'s largest scalability setting)',
+                 lambda: BatchedParticleEnv('simple_spread', 4096, num_agents=12, max_episode_len=25, auto_reset=True, seed=12345678), 5, 1e6),
+                ('simple_spread N=24, B=4096 (C5 point; just-in-time form)',
+                 lambda: BatchedParticleEnv('simple_spread', 4096, num_agents=24, max_episode_len=25, auto_reset=True, seed=12345678), 5, 1e6)):
             try:
                 o_env = mk_env()
                 o_env.set_actor_precision('f32')     # whatever the process environment says: these rollouts serve float32 only

@@ -180,7 +180,7 @@ int pw_rollout(pw_handle *h, const pw_step_io *io, int num_steps, void *stream);
  * pw_create initialises it from pw_dispatch_default() overlaid, once, with the PWORLD_* environment variables of the
  * creating process (for A/B runs of unmodified host programs: PWORLD_FORCE_GENERIC, PWORLD_NO_STREAM, PWORLD_NO_DUO,
  * PWORLD_FORCE_DUO, PWORLD_NO_QUAD, PWORLD_FORCE_QUAD, PWORLD_OBS_BLOCK, PWORLD_SPREAD_TRIO / PWORLD_TAG_TRIO,
- * PWORLD_P_PRIO, PWORLD_EPW, PWORLD_POLICY_V2 / PWORLD_POLICY_V3 / PWORLD_POLICY_V3J); pw_set_dispatch replaces it.  Results never depend
+ * PWORLD_P_PRIO, PWORLD_EPW, PWORLD_POLICY_V3 / PWORLD_POLICY_V3J); pw_set_dispatch replaces it.  Results never depend
  * on it: every form produces the same bits (tests/test_gpu_parity.py runs them all against the oracle). */
 typedef struct pw_dispatch {
     uint32_t struct_size;  /* = sizeof(pw_dispatch); checked */

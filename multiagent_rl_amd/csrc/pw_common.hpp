@@ -23,6 +23,17 @@ int fail(int code, const std::string &msg)
 
 constexpr int kWave = 64;
 
+}  // namespace
+// Timing-only overlays (wrong results by design) are NOT product source: tools/experiments/pw_experiments.hpp, reachable only from
+// a tools/ build that passes -DPW_EXPERIMENTS -I tools/experiments.  build_native.py never does; the product sees the defaults below.
+#ifdef PW_EXPERIMENTS
+#include "pw_experiments.hpp"
+#endif
+#ifndef PW_NEAR_MASK_HOOK
+#define PW_NEAR_MASK_HOOK(m) do { } while (0)
+#endif
+namespace {
+
 // Every workgroup is ONE wave, and a wave's LDS instructions execute in issue order, so the
 // only thing a write -> cross-lane read hand-off through LDS needs is (a) that the compiler
 // keeps the program order of the accesses and (b) that the data has landed before it is
@@ -151,22 +162,7 @@ __device__ __forceinline__ f32x2 div_chain2(f32x2 a, float b, float y)
 // Measured (tools/step_time.hip A/B, profiles/r2_nt_stores.txt): the block-wise observation stores with the hint: B = 65536,
 // N = 6: +6.5 %, N = 24 at B = 4096: +6 %, C2: +1 %.  The row-per-lane observation stores write a quarter line each and
 // stay plain.
-#if defined(PW_EXP_NO_NT_STORES)   // timing experiments only (results are WRONG): the outputs that leave through nt_store are computed
-template <typename T>            // (kept alive by an empty asm) but not stored -- what the write stream costs a kernel
-__device__ __forceinline__ void nt_store(T *p, const T v)
-{
-    if constexpr (sizeof(T) == 8) {
-        const unsigned long long u = (unsigned long long)v;
-        asm volatile("" :: "v"(p), "v"((unsigned)u), "v"((unsigned)(u >> 32)));
-    } else if constexpr (sizeof(T) < 4) {
-        asm volatile("" :: "v"(p), "v"((unsigned)v));
-    } else {
-        asm volatile("" :: "v"(p), "v"(v));
-    }
-}
-__device__ __forceinline__ void nt_store(float4 *p, const float4 v) { asm volatile("" :: "v"(p), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
-__device__ __forceinline__ void nt_store(float2 *p, const float2 v) { asm volatile("" :: "v"(p), "v"(v.x), "v"(v.y)); }
-#else
+#ifndef PW_HAVE_EXP_NT_STORE   // (a -DPW_EXPERIMENTS timing build may have replaced them: tools/experiments/pw_experiments.hpp)
 template <typename T>
 __device__ __forceinline__ void nt_store(T *p, const T v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void nt_store(float4 *p, const float4 v)

@@ -232,18 +232,25 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
         if (ts >= N) ts = N - 1;
         if (n >= envs_here) n = 0;  // slots past the environments of this workgroup read a valid row; nobody uses their results
         const float *xr = xrows + (size_t)(n * N + ts) * xstride;
-        float xb[S1];
-#pragma unroll
-        for (int sidx = 0; sidx < S1; ++sidx) {
-            const int kk = 2 * sidx + half;
-            xb[sidx] = kk < D ? xr[kk] : 0.0f;
-        }
+        // rows longer than 32 numbers: the B operands are read in two batches with a scheduling fence in between, so that at most
+        // S1 / 2 of them are live at a time (all S1 at once is what took the simple_tag rollout past the 256-register cap at D > 32)
+        constexpr int KC = S1 > 16 ? S1 / 2 : S1;
         f32x16 acc1;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc1[q] = 0.0f;
 #pragma unroll
-        for (int sidx = 0; sidx < S1; ++sidx)
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(S.f_w1[(m * S1 + sidx) * 64 + lane], xb[sidx], acc1, 0, 0, 0);
+        for (int k0 = 0; k0 < S1; k0 += KC) {
+            float xb[KC];
+#pragma unroll
+            for (int sidx = 0; sidx < KC; ++sidx) {
+                const int kk = 2 * (k0 + sidx) + half;
+                xb[sidx] = kk < D ? xr[kk] : 0.0f;
+            }
+#pragma unroll
+            for (int sidx = 0; sidx < KC; ++sidx)
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(S.f_w1[(m * S1 + k0 + sidx) * 64 + lane], xb[sidx], acc1, 0, 0, 0);
+            if (k0 + KC < S1) __builtin_amdgcn_sched_barrier(0);
+        }
         float v[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = fmaxf(acc1[q] + S.s_b1[m * 32 + mfma_row(q, half)], 0.0f);

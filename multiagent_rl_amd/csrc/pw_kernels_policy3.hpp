@@ -351,9 +351,10 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
 #pragma unroll
         for (int w = 0; w < 8; ++w) load10[w] = w >= 8 - n_env_waves ? 24 : 0;   // tenths of a block
         for (int blk = 0; blk < nblk; ++blk) {
-            int best_w = 0;
-#pragma unroll
-            for (int w = 1; w < 8; ++w) best_w = load10[w] < load10[best_w] ? w : best_w;   // first minimum: waves from 0 up
+            int best_w = 0, best_v = load10[0];   // (the minimum's VALUE is carried along: load10[best_w] would index the array with a
+#pragma unroll                            // run-time value and put it into scratch memory)
+            for (int w = 1; w < 8; ++w)
+                if (load10[w] < best_v) { best_v = load10[w]; best_w = w; }   // first minimum: waves from 0 up
 #pragma unroll
             for (int w = 0; w < 8; ++w) load10[w] += w == best_w ? 10 : 0;
             if (best_w == wave) my_blocks |= 1ull << blk;

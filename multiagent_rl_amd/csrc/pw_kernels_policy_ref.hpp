@@ -97,9 +97,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
     float co[DC];  // the other agent's symbol (this step's)
     auto tail_compute = [&]() {
         const float ox = __shfl_xor(s.px, 1, kWave), oy = __shfl_xor(s.py, 1, kWave);
-        float glx = s.lmx[0], gly = s.lmy[0];
-        if (s.goal == 1) { glx = s.lmx[1]; gly = s.lmy[1]; }
-        if (s.goal == 2) { glx = s.lmx[2]; gly = s.lmy[2]; }
+        float glx, gly;
+        ref_goal_landmark<DC>(s, s.goal, glx, gly);
         const float dx = ox - glx, dy = oy - gly;
         const float rw = -(dx * dx + dy * dy);
         const float r_other = __shfl_xor(rw, 1, kWave);

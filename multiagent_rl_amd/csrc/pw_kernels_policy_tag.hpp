@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
     float2 *s_velb = s_posb + 2 * kWave;                                   // [2][64]
     float2 *s_lmb = s_velb + 2 * kWave;                                    // [E * L]
     uint32_t *s_mlob = reinterpret_cast<uint32_t *>(s_lmb + A.E * L);      // [2][64] collision masks, low / high words
-    uint32_t *s_mhib = s_mlob + 2 * kWave;
+    uint32_t *s_mhib = s_mlob + 2 * kWave;                                 // (unused since the masks are 32 bits wide; keeps the carve-up)
     float *s_rewb = reinterpret_cast<float *>(s_mhib + 2 * kWave);         // [2][64]
     double *s_fs = reinterpret_cast<double *>(s_rewb + 2 * kWave);         // [16] (+ [16] ints)
     int *s_fc = reinterpret_cast<int *>(s_fs + 16);
@@ -69,18 +69,20 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
     int el = ewi * epw + e_loc;
     const bool live = env_wave && e_loc < epw && el < envs_here;
     if (!live) { e_loc = 0; a = 0; el = env_wave ? ewi * epw : 0; }  // idle lanes shadow lane 0, store nothing
-    const int base = e_loc * N, me = base + a, r = el * N + a;
+    const int base = e_loc * N, me = base + a, r_lane = el * N + a, r = r_lane;
     const long env = env0 + el;
-    const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
+    const uint32_t g_lane = (uint32_t)env * (uint32_t)N + (uint32_t)a, g = g_lane;
     const int ew = env_wave ? ewi : 0;
     float2 *s_pos = s_posb + ew * kWave, *s_vel = s_velb + ew * kWave;
-    uint32_t *s_mlo = s_mlob + ew * kWave, *s_mhi = s_mhib + ew * kWave;
+    uint32_t *s_mlo = s_mlob + ew * kWave;
     float *s_rew = s_rewb + ew * kWave;
     const float2 *pp = s_pos + base, *vv = s_vel + base;
     float2 *lmv = s_lmb + el * L;
     const int cls = a >= NA ? 1 : 0;
-    const uint64_t env_id = V.env_id_base + (uint64_t)env;
-    const uint64_t adv_bits = NA >= 64 ? ~0ull : ((1ull << NA) - 1ull);
+    // Register diet (this kernel sat at the 256-register cap of a 512-thread workgroup and spilled 4 .. 10 VGPRs to scratch): the
+    // masks are 32 bits wide (the host admits D = 4 + 2L + 2(N - 1) + 2G <= 48 here: N <= 22, L <= 21), the finished-episode sums live
+    // in LDS (touched once per episode), the ring slot and the Philox env id are recomputed where they are used.
+    const uint32_t adv_bits = (1u << NA) - 1u;
     const float my_sens = V.sens[cls], my_fscale = V.fscale[cls], my_maxspeed = V.max_speed[cls];
     const float dmin_adv = V.dist_min[cls][0], dmin_good = V.dist_min[cls][1], dmin_lm = V.dist_min_lm[cls];
     const float cthr_adv = V.coll_thr2[cls][0], cthr_good = V.coll_thr2[cls][1];
@@ -89,10 +91,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
     float px = 0.f, py = 0.f, vx = 0.f, vy = 0.f;
     int ep_step = 0;
     uint32_t ep_count = 0;
-    uint64_t coll = 0, near_a = 0, near_l = 0;
+    uint32_t coll = 0, near_a = 0, near_l = 0;
     float ep_ret = 0.f;
-    double fin_sum = 0.0;
-    int fin_cnt = 0;
     // BASELINE configs[2]'s roster (4 adversaries + 2 good agents, 2 landmarks) takes the unrolled row writer / partner loops: with
     // runtime bounds every LDS read of a loop is a round trip of its own (~120 exposed cycles each, ~10 per row)
     const bool c3 = N == 6 && NA == 4 && L == 2;
@@ -106,12 +106,12 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
             const float dx = q.x - px, dy = q.y - py;
             const float d2 = dx * dx + dy * dy;
             const bool jg = j >= NA;
-            if (d2 < (jg ? cthr_good : cthr_adv)) coll |= 1ull << j;
-            if (bits_near(d2, jg ? nthr_good : nthr_adv)) near_a |= 1ull << j;
+            if (d2 < (jg ? cthr_good : cthr_adv)) coll |= 1u << j;
+            if (bits_near(d2, jg ? nthr_good : nthr_adv)) near_a |= 1u << j;
         };
         auto landmark = [&](const float2 q, const int l) {
             const float dx = q.x - px, dy = q.y - py;
-            if (bits_near(dx * dx + dy * dy, nthr_lm)) near_l |= 1ull << l;
+            if (bits_near(dx * dx + dy * dy, nthr_lm)) near_l |= 1u << l;
         };
         if (c3) {  // all eight LDS reads in flight
             const float2 q0 = pp[0], q1 = pp[1], q2 = pp[2], q3 = pp[3], q4 = pp[4], q5 = pp[5], l0 = lmv[0], l1 = lmv[1];
@@ -121,8 +121,9 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
             for (int j = 0; j < N; ++j) agent(pp[j], j);
             for (int l = 0; l < L; ++l) landmark(lmv[l], l);
         }
-        near_a &= ~(1ull << a);
+        near_a &= ~(1u << a);
     };
+    if (SINK && tid < 16) { s_fs[tid] = 0.0; s_fc[tid] = 0; }   // per-env finished-episode (sum, count) of this launch
     if (env_wave) {
         if (SINK && P.episode_return && live && a == 0) ep_ret = P.episode_return[env];
         px = V.pos_x[g]; py = V.pos_y[g]; vx = V.vel_x[g]; vy = V.vel_y[g];
@@ -145,13 +146,12 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
     // run by the environment waves inside the NEXT actor pass (before its dense1 blocks / before its head tiles).  A wave with an
     // episode ending in this step runs both, the reset and the post-reset partner pass before it publishes the rows.
     int ai = 0, tail_t = 0, tail_stage = 0;  // tail_stage: 0 nothing pending, 1 tail_compute pending, 2 tail_stores pending
-    size_t slot = 0;
     float t_rw = 0.f, t_acc = 0.f;
     bool t_term = false;
     auto tail_compute = [&]() {
         partner_pass();
         // simple_tag.reward
-        if (live) { s_mlo[me] = (uint32_t)coll; s_mhi[me] = (uint32_t)(coll >> 32); }
+        if (live) s_mlo[me] = coll;
         wave_lds_sync();
         float rw = 0.0f;
         if (cls) {
@@ -161,13 +161,10 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
             rw -= tag_bound(fabsf(py));
         } else if (c3) {  // both good agents' masks in flight (N = 6: the low words hold everything)
             const uint32_t m4 = s_mlo[base + 4], m5 = s_mlo[base + 5];
-            rw += 10.0f * (float)__builtin_popcount(m4 & (uint32_t)adv_bits);
-            rw += 10.0f * (float)__builtin_popcount(m5 & (uint32_t)adv_bits);
+            rw += 10.0f * (float)__builtin_popcount(m4 & adv_bits);
+            rw += 10.0f * (float)__builtin_popcount(m5 & adv_bits);
         } else {
-            for (int gj = NA; gj < N; ++gj) {
-                const uint64_t mg = ((uint64_t)s_mhi[base + gj] << 32) | s_mlo[base + gj];
-                rw += 10.0f * (float)__builtin_popcountll(mg & adv_bits);
-            }
+            for (int gj = NA; gj < N; ++gj) rw += 10.0f * (float)__builtin_popcount(s_mlo[base + gj] & adv_bits);
         }
         if (live) s_rew[me] = rw;
         wave_lds_sync();
@@ -185,12 +182,19 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
         t_acc = acc;
         if (SINK && live && a == 0 && P.episode_return) {
             const float rsum = ep_ret + acc;
-            if (t_term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
+            if (t_term) { s_fs[el] += (double)rsum; s_fc[el] += 1; ep_ret = 0.0f; }   // once per episode: LDS, not registers
             else ep_ret = rsum;
         }
     };
+    // `opaque`: the lane's launch-invariant indices (g, r) pass through an empty asm wherever they feed an output address.  Without it
+    // the compiler computes every `pointer + g` of the step's stores once per launch and keeps the 64-bit results in registers for
+    // the whole kernel -- that is what pushed this kernel over the 256-register cap and into scratch memory; a few address
+    // additions per step are cheaper than three scratch reloads.
+    auto opaque = [](const uint32_t v) { uint32_t x = v; asm volatile("" : "+v"(x)); return x; };
     auto tail_stores = [&](const int t, const bool with_obs) {  // with_obs: V.obs too (no reset in between: the same row)
         const size_t tBN = (size_t)t * BN;
+        const uint32_t g = opaque(g_lane);
+        const int r = (int)opaque((uint32_t)r_lane);
         if (live) {
             if (P.act_out) P.act_out[tBN + g] = ai;
             if (V.rew) V.rew[tBN + g] = t_rw;
@@ -202,6 +206,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
             // with_obs: no reset in between, so next_obs and obs are both the row this lane published in LDS -- copied, not rebuilt
             const float2 *row = reinterpret_cast<const float2 *>(s_obs + r * D);
             if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
+                const size_t slot = ring_slot(P.ring_start, t, A.B, (long)env, P.ring.capacity);
                 float *dst = P.ring.next_obs + (slot * N + a) * D;
                 if (with_obs) for (int c = 0; c < D / 2; ++c) reinterpret_cast<float2 *>(dst)[c] = row[c];
                 else write_row(dst);
@@ -221,9 +226,11 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
                                     mid_hook);  // a barrier at its end
         if (env_wave) {
             const size_t tBN = (size_t)t * BN;
+            const uint32_t g = opaque(g_lane);
+            const int r = (int)opaque((uint32_t)r_lane);
             ai = s_act[r];
             if (SINK && P.has_ring) {  // the observation the policy acted on (still in LDS) -> ring.obs
-                slot = ring_slot(P.ring_start, t, A.B, (long)env, P.ring.capacity);
+                const size_t slot = ring_slot(P.ring_start, t, A.B, (long)env, P.ring.capacity);
                 if (live) {
                     const float2 *src = reinterpret_cast<const float2 *>(s_obs + r * D);
                     float2 *dst = reinterpret_cast<float2 *>(P.ring.obs + (slot * N + a) * D);
@@ -237,13 +244,13 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
             if (my_fscale != 1.0f) { ux = my_fscale * ux; uy = my_fscale * uy; }
             float fx = ux + 0.0f, fy = uy + 0.0f;
             // U5: near agents (ascending j), then near landmarks (ascending l): upstream's entity order
-            for (uint64_t m = live ? near_a : 0; m; m &= m - 1) {
-                const int j = __builtin_ctzll(m);
+            for (uint32_t m = live ? near_a : 0; m; m &= m - 1) {
+                const int j = __builtin_ctz(m);
                 const float2 q = pp[j];
                 collision_force<true>(px, py, q.x, q.y, j >= NA ? dmin_good : dmin_adv, k, cf, fx, fy);
             }
-            for (uint64_t m = live ? near_l : 0; m; m &= m - 1) {
-                const float2 q = lmv[__builtin_ctzll(m)];
+            for (uint32_t m = live ? near_l : 0; m; m &= m - 1) {
+                const float2 q = lmv[__builtin_ctz(m)];
                 collision_force<true>(px, py, q.x, q.y, dmin_lm, k, cf, fx, fy);
             }
             // U6 with the max_speed clamp
@@ -273,6 +280,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
                     wave_lds_sync();
                     ep_count += 1;
                     ep_step = 0;
+                    const uint64_t env_id = V.env_id_base + (uint64_t)env;
                     pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)a, -1.0f, 1.0f, &px, &py);
                     vx = 0.f; vy = 0.f;
                     if (live)
@@ -315,8 +323,6 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
         }
     }
     if (SINK && P.episode_return) {
-        wg_lds_barrier();
-        if (live && a == 0) { s_fs[el] = fin_sum; s_fc[el] = fin_cnt; }
         wg_lds_barrier();
         rollout_finish_stats(envs_here, s_fs, s_fc, P.scratch, P.finished_sum, P.finished_count, smem_raw);
     }

@@ -40,6 +40,17 @@ struct RefLane {
     int goal;
 };
 
+// The goal landmark of a lane.  All six coordinates are read first and the choice is made between VALUES: written as "start with
+// landmark 0, overwrite if goal == 1 / 2" the compiler turns the conditional loads into one load at a run-time index, and a struct
+// that is indexed at run time lives in scratch memory (88 B of private segment in every kernel that used it).
+template <int DC>
+__device__ __forceinline__ void ref_goal_landmark(const RefLane<DC> &s, const int gsel, float &glx, float &gly)
+{
+    const float x0 = s.lmx[0], x1 = s.lmx[1], x2 = s.lmx[2], y0 = s.lmy[0], y1 = s.lmy[1], y2 = s.lmy[2];
+    glx = gsel == 2 ? x2 : gsel == 1 ? x1 : x0;
+    gly = gsel == 2 ? y2 : gsel == 1 ? y1 : y0;
+}
+
 template <int DC, bool SL>
 __device__ __forceinline__ void ref_reset(const RefParams &P, uint64_t env_id, uint32_t episode, int a, RefLane<DC> &s)
 {
@@ -177,9 +188,8 @@ __global__ void __launch_bounds__(kWave) pw_reference_rollout_kernel(const RefPa
         // ---- reward: -|p_other - p_goal_b|^2 (speaker_listener: -|p_listener - p_goal_b(speaker)|^2 for both)
         const int og = __shfl_xor(s.goal, 1, kWave);
         const int gsel = (SL && a == 1) ? og : s.goal;
-        float glx = s.lmx[0], gly = s.lmy[0];
-        if (gsel == 1) { glx = s.lmx[1]; gly = s.lmy[1]; }
-        if (gsel == 2) { glx = s.lmx[2]; gly = s.lmy[2]; }
+        float glx, gly;
+        ref_goal_landmark<DC>(s, gsel, glx, gly);
         const float tx = (SL && a == 1) ? s.px : ox, ty = (SL && a == 1) ? s.py : oy;
         const float dx = tx - glx, dy = ty - gly;
         const float r = -(dx * dx + dy * dy);
@@ -232,9 +242,8 @@ __global__ void __launch_bounds__(kWave) pw_reference_aux_kernel(const RefParams
     const int og = __shfl_xor(s.goal, 1, kWave);
     if ((mode & 4) && valid && rew) {
         const int gsel = (SL && a == 1) ? og : s.goal;
-        float glx = s.lmx[0], gly = s.lmy[0];
-        if (gsel == 1) { glx = s.lmx[1]; gly = s.lmy[1]; }
-        if (gsel == 2) { glx = s.lmx[2]; gly = s.lmy[2]; }
+        float glx, gly;
+        ref_goal_landmark<DC>(s, gsel, glx, gly);
         const float tx = (SL && a == 1) ? s.px : ox, ty = (SL && a == 1) ? s.py : oy;
         const float dx = tx - glx, dy = ty - gly;
         rew[(size_t)env * 2 + a] = -(dx * dx + dy * dy);

@@ -229,11 +229,7 @@ template <typename MaskT, typename PosT>
 __device__ __forceinline__ void near_force_loop(MaskT m, const PosT *pp, float px, float py, float dist_min, float k,
                                                 float cf, float &fx, float &fy)
 {
-#if defined(PW_EXP_NO_FORCE)      // timing experiments only (tools/step_time.hip builds; results are WRONG): what a step costs
-    m = 0;                        // without any contact force ...
-#elif defined(PW_EXP_ONE_PARTNER)
-    m &= (MaskT)0 - m;            // ... and with at most ONE evaluation per lane (the bound of a pair-parallel form's gain)
-#endif
+    PW_NEAR_MASK_HOOK(m);
     if (!m) return;
     int j = sizeof(MaskT) == 4 ? __builtin_ctz((uint32_t)m) : __builtin_ctzll((uint64_t)m);
     float2 q = *reinterpret_cast<const float2 *>(pp + j);

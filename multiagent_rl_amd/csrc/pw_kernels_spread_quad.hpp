@@ -45,12 +45,8 @@ __device__ __forceinline__ void quad_pair_of(const int q, int &i, int &j)
 // bit-identical to the plain form (tests: the `quad+coll` path, and the bench-path test at C2 full size).
 // K1: the division by the contact margin inside the force runs as ONE Newton correction (pw_common.hpp div_chain1); the
 // host sets it only for margins whose refined reciprocal is the correctly rounded one (pworld.hip margin_one_correction).
-#if defined(PW_EXP_BARRIER2)   // timing experiments only (tools/step_time.hip builds; results are WRONG): the workgroup meets every
-#define PW_QUAD_BARRIER(t) do { if (!((t) & 1)) duo_barrier(); else wave_lds_sync(); } while (0)   // SECOND step only
-#elif defined(PW_EXP_BARRIER0)  // ... or never (the waves run free: the floor of the physics chain without any meeting)
-#define PW_QUAD_BARRIER(t) wave_lds_sync()
-#else
-#define PW_QUAD_BARRIER(t) duo_barrier()
+#ifndef PW_QUAD_BARRIER
+#define PW_QUAD_BARRIER(t) duo_barrier()   // one workgroup meeting per step
 #endif
 #ifndef PW_QUAD_ACT_AHEAD
 #define PW_QUAD_ACT_AHEAD 4   // steps the physics waves' action indices are fetched ahead (a power of two; LDS ring slots per wave)

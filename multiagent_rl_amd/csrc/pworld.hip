@@ -217,7 +217,6 @@ void dispatch_from_environment(pw_dispatch *d, int *actor_bf16x3)
     if (const char *e = std::getenv("PWORLD_EPW")) d->envs_per_wave = std::atoi(e) >= 1 ? std::atoi(e) : 0;
     if (std::getenv("PWORLD_POLICY_V3J")) d->policy_form = 4;
     if (std::getenv("PWORLD_POLICY_V3")) d->policy_form = 3;
-    if (std::getenv("PWORLD_POLICY_V2")) d->policy_form = 2;
 }
 
 // Everything the selection decides ahead of a launch: envs per wave and which specialised paths apply.

@@ -335,7 +335,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         return PW_OK;
     }
     if (!use_v3)
-        return fail(PW_EINVAL, a.bf16x3 ? "PW_ACTOR_BF16X3 needs the third kernel form (policy_form 0 or 3, N <= 16 with 8+ environments per workgroup)"
+        return fail(PW_EINVAL, a.bf16x3 ? "PW_ACTOR_BF16X3 needs the third kernel form (policy_form 0 or 3, N <= 12: 16 environments per workgroup with the observation rows in LDS)"
                                         : "the selected rollout form does not fit this configuration's observation rows in LDS (policy_form 0 chooses)");
     {
         a.E = E3;

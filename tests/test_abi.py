@@ -121,11 +121,12 @@ def test_dispatch_lives_in_the_handle(monkeypatch):
     assert lib.pw_get_dispatch(h, C.byref(got)) == 0 and {n: getattr(got, n) for n in names} == auto
     monkeypatch.setenv('PWORLD_NO_QUAD', '1')
     monkeypatch.setenv('PWORLD_OBS_BLOCK', '1')
-    monkeypatch.setenv('PWORLD_POLICY_V2', '1')
+    monkeypatch.setenv('PWORLD_POLICY_V3J', '1')
+    monkeypatch.setenv('PWORLD_POLICY_V2', '1')                    # retired with forms 1 / 2: no longer read
     assert lib.pw_create(C.byref(cfg), C.byref(h2)) == 0          # read once, here
     monkeypatch.delenv('PWORLD_NO_QUAD')
     lib.pw_get_dispatch(h2, C.byref(got))
-    assert {n: getattr(got, n) for n in names} == dict(auto, quad=0, obs_block=1, policy_form=2)
+    assert {n: getattr(got, n) for n in names} == dict(auto, quad=0, obs_block=1, policy_form=4)
     lib.pw_get_dispatch(h, C.byref(got))
     assert {n: getattr(got, n) for n in names} == auto          # the older handle is untouched
     got.duo, got.envs_per_wave = 0, 5

@@ -78,6 +78,13 @@ def main():
         summ['traffic_bytes_per_launch'] = (c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024.0
         summ['traffic_bytes_per_env_step'] = summ['traffic_bytes_per_launch'] / per_launch
         summ['hbm_GBps'] = summ['traffic_bytes_per_launch'] / (kern_ms * 1e-3) / 1e9
+    # which kernel code this was measured on: bench.py quotes the counters only while the tree still holds exactly these sources
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from multiagent_rl_amd import build_native
+    summ['kernel_family'] = build_native.kernel_family(summ['kernel'])
+    summ['kernel_source_sha16'] = build_native.kernel_source_hash(summ['kernel_family'])
+    summ['kernel_source_files'] = build_native.KERNEL_FAMILIES[summ['kernel_family']]
     json.dump(summ, open(os.path.join(a.out, '%s_summary.json' % a.tag), 'w'), indent=1)
     print(json.dumps(summ, indent=1)[:2500])
 

@@ -93,6 +93,13 @@ def main():
             # a wave64 VALU instruction occupies its SIMD's issue for 4 clocks
             summ['valu_issue_share'] = 4.0 * summ['valu_insts_per_wave_step'] / summ['clocks_per_wave_step']
             summ['sq_source'] = 'profiles/%s_summary.json (rocprofv3 --pmc SQ passes, mean over the launches of this kernel)' % a.tag
+    # which kernel code this was measured on: bench.py quotes the counters only while the tree still holds exactly these sources
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from multiagent_rl_amd import build_native
+    summ['kernel_family'] = build_native.kernel_family(summ['kernel'])
+    summ['kernel_source_sha16'] = build_native.kernel_source_hash(summ['kernel_family'])
+    summ['kernel_source_files'] = build_native.KERNEL_FAMILIES[summ['kernel_family']]
     json.dump(summ, open(os.path.join(a.out, '%s_summary.json' % a.tag), 'w'), indent=1)
     print(json.dumps(summ, indent=1)[:1500])
 
