@@ -925,7 +925,9 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
         from multiagent_rl_amd.dist import FullTransitionGather as Full
     else:
         from tests.dist_standins import CpuFullGather as Full
-    full = Full(penv, Tp, rank, world, dev)
+    # the learner rank keeps a STATE ring (round 5): it writes 32 N + 8 L bytes per gathered transition instead of 8 N D and rebuilds
+    # the rows when a batch is sampled -- the root's ring appends are what bounds the 8-GPU figure (profiles/r5_root_ingest.txt)
+    full = Full(penv, Tp, rank, world, dev, ring='state' if stub_env is None else 'rows')   # (the no-device stub env has no state wire)
     err = None
     obs0 = penv.reset()
 
@@ -978,7 +980,7 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
                                  'peer->root -> %s), triple-buffered, one chunk late'
                                  % (('STATE-ONLY wire blocks: pw_state_wire_begin / _finalize', 'pw_replay_add_state_wire rebuilds the rows')
                                     if getattr(full, 'state_wire', False) else ('row blocks: pw_chunk_wire_finalize', 'pw_replay_add_wire')),
-                            wire='state' if getattr(full, 'state_wire', False) else 'rows',
+                            wire='state' if getattr(full, 'state_wire', False) else 'rows', ring=getattr(full, 'ring_kind', 'rows'),
                             bytes_per_env_step=full.bytes_per_env_step, bytes_per_chunk_per_rank=full.lay.total_bytes,
                             GBps_per_link=per_link, GBps_root_ingest=None if per_link is None else per_link * (world - 1),
                             exchanges=full.exchanges, transitions_ingested_root=full.rows_ingested,

@@ -53,7 +53,9 @@
 extern "C" {
 #endif
 
-#define PW_VERSION 105 /* 0.1.5: + pw_state_wire_* / pw_replay_add_state_wire (state-only wire blocks); PW_ACTOR_BF16X3 environment switch removed; 0.1.4: + pw_set_actor_precision / pw_actor_set_bf16x3 (opt-in bf16x3 input projection); pw_actor_front_pack's
+#define PW_VERSION 106 /* 0.1.6: + STATE rings (pw_replay_store.state_rows: the ring keeps {vel, pos} + the episode's landmarks, pw_replay_gather rebuilds the rows);
+                          state-only wire blocks for simple_tag (pw_state_wire_layout_scn), compact-row wire blocks for simple_reference (pw_ref_wire_*); pw_replay_store and pw_state_wire grew (appended fields, zero = before);
+                          PWORLD_POLICY_V2 no longer read.  0.1.5: + pw_state_wire_* / pw_replay_add_state_wire (state-only wire blocks); PW_ACTOR_BF16X3 environment switch removed; 0.1.4: + pw_set_actor_precision / pw_actor_set_bf16x3 (opt-in bf16x3 input projection); pw_actor_front_pack's
                           image grew a third section.  0.1.3: + pw_dispatch (kernel selection frozen in the handle; no environment reads at launch)
                           (0.1.2: + pw_rollout_kernel; 0.1.1: pw_replay_store grew act_heads / per_agent / head_width; wire-block entry points) */
 #define PW_MAX_AGENTS 64
@@ -232,7 +234,15 @@ size_t pw_algorithmic_bytes_per_env_step(const pw_handle *h);
  *     (head_width[0] = 0 means 5);
  *   per_agent = 1: rew and done are [cap,N] f32 -- the BiCNet tuple of experiments/run_BIC.py:46,50.
  * pw_replay_add and pw_replay_gather serve every variant, pw_replay_add_rollout the plain and the two-head ring; the tail /
- * packed / wire entry points and the pw_policy_rollout sink take the plain ring only (PW_EINVAL otherwise). */
+ * packed / wire entry points and the pw_policy_rollout sink take the plain ring only (PW_EINVAL otherwise).
+ *   state_rows = 1 (0.1.6): a STATE ring.  obs / next_obs are [cap,N,4] f32 planes holding {vx, vy, px, py} of every agent (the
+ *     first four columns of its observation row) and lm [cap,L,2] the landmarks of the transition's episode: 32N + 8L bytes per
+ *     transition instead of 8ND (C2: 240 instead of 768) -- what the learner rank writes per gathered transition.  obs_dim stays D:
+ *     pw_replay_gather REBUILDS the rows it returns ([b,N,D]; every entry is the state itself or one float32 subtraction, so the
+ *     batch is bit-identical to the row ring's).  scenario / num_landmarks / num_adversaries name the row layout: PW_SIMPLE_SPREAD
+ *     with the local observation (D = 4 + 2L) or PW_SIMPLE_TAG (D = 4 + 2L + 2(N - 1) + 2(N - A), good agents' rows zero-padded).
+ *     Filled by pw_replay_add_state_wire only (a row cannot be turned back into the landmarks it was built from); every other
+ *     writer returns PW_EINVAL.  Plain single-head, shared-reward rings only. */
 typedef struct pw_replay_store {
     float *obs, *next_obs, *rew, *done;
     uint8_t *act;
@@ -240,6 +250,8 @@ typedef struct pw_replay_store {
     int32_t num_agents, obs_dim;
     int32_t act_heads, per_agent;
     int32_t head_width[2];
+    int32_t state_rows, num_landmarks, scenario, num_adversaries; /* 0.1.6; all zero = the row ring of before */
+    float *lm;                                                    /* state ring: [cap,L,2] */
 } pw_replay_store;
 
 /* add(): append B transitions at ring positions (start + i) % capacity.
@@ -353,17 +365,56 @@ typedef struct pw_state_wire {
     int32_t T, B, N, L, D, F;
     size_t state0, state, final_state, lm, ep0, rew_shared, act, epi; /* byte offsets into the block */
     size_t total_bytes;
+    int32_t scenario, num_adversaries; /* 0.1.6: PW_SIMPLE_SPREAD (0: as before) or PW_SIMPLE_TAG with A adversaries */
 } pw_state_wire;
-/* Host arithmetic only (as pw_chunk_wire_layout).  begin / finalize return PW_EINVAL unless h is a simple_spread handle with the
- * local observation (D = 4 + 2L) of the block's B, N, L. */
-int pw_state_wire_layout(int32_t T, int32_t B, int32_t N, int32_t L, int32_t max_episode_len, pw_state_wire *out);
+/* Host arithmetic only (as pw_chunk_wire_layout).  begin / finalize return PW_EINVAL unless h is a handle of the block's scenario,
+ * B, N, L (and A) whose rows are a function of the state: simple_spread with the local observation (D = 4 + 2L), or simple_tag
+ * (0.1.6; D = 4 + 2L + 2(N - 1) + 2(N - A): [vel, pos, landmark - pos .., other pos - pos .., other good agents' vel ..], rows of good
+ * agents zero-padded; landmarks drawn from U(-0.9, 0.9): C3's 4 + 2 roster ships 17N + 5 = 107 B per env-step + (1 + F) state /
+ * landmark batches per chunk instead of the row block's 4ND + N + 5 = 539). */
+int pw_state_wire_layout(int32_t T, int32_t B, int32_t N, int32_t L, int32_t max_episode_len, pw_state_wire *out); /* simple_spread */
+int pw_state_wire_layout_scn(int32_t scenario, int32_t T, int32_t B, int32_t N, int32_t L, int32_t num_adversaries,
+                             int32_t max_episode_len, pw_state_wire *out);
 int pw_state_wire_begin(const pw_handle *h, const pw_state_wire *w, void *wire, void *stream);
 /* obs [T,B,N,D] and final_obs [T,B,N,D] (may be NULL when F = 0) are the rollout's outputs, terminal [T,B], act [T,B,N]
  * int32.  One launch. */
 int pw_state_wire_finalize(const pw_handle *h, const pw_state_wire *w, void *wire, const float *obs, const float *final_obs,
                            const uint8_t *terminal, const int32_t *act, void *stream);
-/* Root; needs no handle: the rebuild is the observation's own arithmetic on the block's data.  One launch. */
+/* Root; needs no handle: the rebuild is the observation's own arithmetic on the block's data.  One launch.  st may be a row ring
+ * (rows rebuilt here) or a STATE ring of the same scenario / N / L / A (states and landmarks copied; rows rebuilt by
+ * pw_replay_gather when a batch is sampled). */
 int pw_replay_add_state_wire(const pw_replay_store *st, int64_t start, const pw_state_wire *w, const void *wire, void *stream);
+
+/* ---- the gather for simple_reference (the MultiDiscrete scenario of main.py:24,52-54; 0.1.6): COMPACT-ROW wire blocks ------------
+ * Its 21-number row is [p_vel (2), landmark - p_pos (3 x 2), goal_b colour (3), the other agent's communication state (10)]
+ * (experiments/scenarios.py:23-42).  The last 13 numbers are not arithmetic at all: the colour is a constant of the agent's goal
+ * landmark (fixed for an episode) and the communication state is the one-hot of the symbol the OTHER agent sampled in this step
+ * (zeros after a reset; upstream update_agent_state copies action.c for a speaking agent).  So a block carries the first EIGHT
+ * numbers of every row as they are (the position itself is not in the row, and landmark - pos cannot be turned back into it), one
+ * goal byte per agent and episode, and both action heads as bytes; the root rebuilds obs / next_obs bit for bit.  Planes, 256-B aligned:
+ *   head0 [B,2,8] f32         columns 0..7 of the rows the policy acted on at step 0
+ *   head [T,B,2,8] f32        columns 0..7 of the post-step (post-reset) rows
+ *   final_head [F,B,2,8] f32  columns 0..7 of the pre-reset rows of env e's k-th episode end inside the chunk
+ *   goal [(F+1),B,2] u8       goal landmark of each agent in the episode in progress at step 0 (k = 0) and after the k-th reset
+ *   comm0 [B,2] u8            the symbol visible in agent a's row at step 0 (0xFF: none, i.e. zeros)
+ *   rew_shared [T,B] f32      written in place by the rollout
+ *   act [T,B,2,2] u8          (movement, symbol) of every agent
+ *   epi [T,B] u8              as in pw_state_wire
+ * = 73 bytes per env-step + (1 + F) head / goal batches per chunk (T = 100: 77 B; the row block: 181).
+ * Sender: pw_ref_wire_finalize after the chunk's rollout (rew_shared pointing into the block); it reads the rollout's outputs only
+ * (no handle).  Root: pw_replay_add_ref_wire into the TWO-HEAD ring (act_heads = 2, head widths 5 | PW_DIM_C), bit-identical to
+ * pw_replay_add_rollout on the sender's buffers.  The rows must come from HARD symbol indices (pw_policy_rollout, or pw_rollout with
+ * act_idx / act_comm): a soft communication vector (act_vec) is not representable -- use pw_chunk_wire_* then. */
+typedef struct pw_ref_wire {
+    int32_t T, B, F, reserved;
+    size_t head0, head, final_head, goal, comm0, rew_shared, act, epi; /* byte offsets into the block */
+    size_t total_bytes;
+} pw_ref_wire;
+int pw_ref_wire_layout(int32_t T, int32_t B, int32_t max_episode_len, pw_ref_wire *out);
+/* obs0 [B,2,21], obs / final_obs [T,B,2,21] (final_obs may be NULL when F = 0), terminal [T,B], act [T,B,2,2] int32.  One launch. */
+int pw_ref_wire_finalize(const pw_ref_wire *w, void *wire, const float *obs0, const float *obs, const float *final_obs,
+                         const uint8_t *terminal, const int32_t *act, void *stream);
+int pw_replay_add_ref_wire(const pw_replay_store *st, int64_t start, const pw_ref_wire *w, const void *wire, void *stream);
 
 /* Episode bookkeeping of the rollout loop (experiments/run.py:55-65) over B envs in one launch:
  * episode_return[b] += rew_shared[b]; where terminal[b]: *finished_sum += return (double),

@@ -61,7 +61,10 @@ class PwRolloutSink(C.Structure):
 class PwReplayStore(C.Structure):
     _fields_ = [('obs', C.c_void_p), ('next_obs', C.c_void_p), ('rew', C.c_void_p), ('done', C.c_void_p),
                 ('act', C.c_void_p), ('capacity', C.c_int64), ('num_agents', C.c_int32), ('obs_dim', C.c_int32),
-                ('act_heads', C.c_int32), ('per_agent', C.c_int32), ('head_width', C.c_int32 * 2)]
+                ('act_heads', C.c_int32), ('per_agent', C.c_int32), ('head_width', C.c_int32 * 2),
+                # 0.1.6: STATE ring (obs / next_obs = [cap,N,4] states, lm = [cap,L,2]; pw_replay_gather rebuilds the rows)
+                ('state_rows', C.c_int32), ('num_landmarks', C.c_int32), ('scenario', C.c_int32), ('num_adversaries', C.c_int32),
+                ('lm', C.c_void_p)]
 
 
 class PwChunkWire(C.Structure):
@@ -71,7 +74,13 @@ class PwChunkWire(C.Structure):
 
 class PwStateWire(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('T', 'B', 'N', 'L', 'D', 'F')] + \
-               [(n, C.c_size_t) for n in ('state0', 'state', 'final_state', 'lm', 'ep0', 'rew_shared', 'act', 'epi', 'total_bytes')]
+               [(n, C.c_size_t) for n in ('state0', 'state', 'final_state', 'lm', 'ep0', 'rew_shared', 'act', 'epi', 'total_bytes')] + \
+               [('scenario', C.c_int32), ('num_adversaries', C.c_int32)]
+
+
+class PwRefWire(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('T', 'B', 'F', 'reserved')] + \
+               [(n, C.c_size_t) for n in ('head0', 'head', 'final_head', 'goal', 'comm0', 'rew_shared', 'act', 'epi', 'total_bytes')]
 
 
 # name -> (restype, argtypes): every symbol include/pworld.h declares
@@ -115,9 +124,13 @@ SIGNATURES = {
     'pw_chunk_wire_finalize': (C.c_int, [C.POINTER(PwChunkWire)] + [C.c_void_p] * 6),
     'pw_replay_add_wire': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.POINTER(PwChunkWire), C.c_void_p, C.c_void_p]),
     'pw_state_wire_layout': (C.c_int, [C.c_int32] * 5 + [C.POINTER(PwStateWire)]),
+    'pw_state_wire_layout_scn': (C.c_int, [C.c_int32] * 7 + [C.POINTER(PwStateWire)]),
     'pw_state_wire_begin': (C.c_int, [C.c_void_p, C.POINTER(PwStateWire), C.c_void_p, C.c_void_p]),
     'pw_state_wire_finalize': (C.c_int, [C.c_void_p, C.POINTER(PwStateWire)] + [C.c_void_p] * 6),
     'pw_replay_add_state_wire': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.POINTER(PwStateWire), C.c_void_p, C.c_void_p]),
+    'pw_ref_wire_layout': (C.c_int, [C.c_int32] * 3 + [C.POINTER(PwRefWire)]),
+    'pw_ref_wire_finalize': (C.c_int, [C.POINTER(PwRefWire)] + [C.c_void_p] * 7),
+    'pw_replay_add_ref_wire': (C.c_int, [C.POINTER(PwReplayStore), C.c_int64, C.POINTER(PwRefWire), C.c_void_p, C.c_void_p]),
     'pw_dense': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                           C.c_void_p]),
     'pw_actor_front_pack_floats': (C.c_size_t, [C.c_int32]),

@@ -73,6 +73,24 @@ int plain_ring_only(const pw_replay_store *st, const char *who)
 {
     if (st && (st->act_heads > 1 || st->per_agent))
         return fail(PW_EINVAL, std::string(who) + ": two-head / per-agent rings are served by pw_replay_add and pw_replay_gather only");
+    if (st && st->state_rows)
+        return fail(PW_EINVAL, std::string(who) + ": a STATE ring (pw_replay_store.state_rows) is filled by pw_replay_add_state_wire and read by "
+                                                  "pw_replay_gather only -- observation rows cannot be turned back into the landmarks they were built from");
+    return PW_OK;
+}
+
+// A state ring's own consistency (pw_replay_add_state_wire, pw_replay_gather).
+int state_ring_ok(const pw_replay_store *st, const char *who)
+{
+    if (st->act_heads > 1 || st->per_agent) return fail(PW_EINVAL, std::string(who) + ": a STATE ring is a plain single-head, shared-reward ring");
+    const int N = st->num_agents, L = st->num_landmarks, A = st->num_adversaries;
+    if (!st->lm && L > 0) return fail(PW_EINVAL, std::string(who) + ": STATE ring without a landmark plane");
+    if (N < 1 || L < 0 || A < 0 || A > N) return fail(PW_EINVAL, std::string(who) + ": bad STATE ring shape");
+    const int D = st->scenario == PW_SIMPLE_SPREAD ? 4 + 2 * L : st->scenario == PW_SIMPLE_TAG ? 4 + 2 * L + 2 * (N - 1) + 2 * (N - A) : -1;
+    if (D != st->obs_dim)
+        return fail(PW_EINVAL, std::string(who) + ": STATE rings serve simple_spread (local observation, D = 4 + 2L) and simple_tag (D = 4 + 2L + 2(N - 1) + 2(N - A))");
+    if ((reinterpret_cast<uintptr_t>(st->obs) | reinterpret_cast<uintptr_t>(st->next_obs)) & 15) return fail(PW_EINVAL, std::string(who) + ": STATE ring planes must be 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(st->lm) & 7) return fail(PW_EINVAL, std::string(who) + ": STATE ring landmark plane must be 8-byte aligned");
     return PW_OK;
 }
 }  // namespace

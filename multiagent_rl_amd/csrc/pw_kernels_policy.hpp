@@ -659,6 +659,7 @@ struct PolicyRolloutArgs {
     double *finished_sum;
     int64_t *finished_count;
     unsigned long long *scratch;    // [2 * gridDim.x + 1] words, zero before first use
+    int NP;                         // just-in-time form: row stride of an environment in LDS (>= N; odd: see pw_kernels_policy3j.hpp)
 };
 
 // (The first, phase-by-phase form of the rollout kernel -- pw_policy_rollout_kernel: actor_forward_wg per step, the environment

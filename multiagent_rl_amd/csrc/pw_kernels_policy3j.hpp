@@ -31,6 +31,13 @@ namespace {
 // landmarks + small = 134 KB; N = 30: 159.6 KB -- 16 environments per workgroup still fit (the Gumbel noise is drawn in the head's lanes).  Serves simple_spread with the local observation, D = 4 + 2 L <= 104 (W1's fragments: up to 26
 // VGPRs), at most 8 environment waves of whole environments: 16 environments per workgroup up to N = 30, 8 at
 // N = 33 .. 50 (BASELINE's C5 point N = L = 48: D = 100, the only form that holds such rows).
+// Row stride NP (round 5).  A workgroup's rows sit in LDS env-major: state row / head-input row rr = n * NP + ts for sequence (environment)
+// n and timestep (agent) ts.  With NP = N even, the sixteen sequences of an MFMA column set are a multiple of 8 rows apart: at N = 24 every
+// lane of the head-input write of a timestep (one 8-byte store per lane into slot (rr & 15) of its tile: 16 x rr bytes modulo the 128-byte
+// bank period) hit the SAME bank pair -- a 64-way conflict per wave and timestep -- and the sixteen state reads of dense1 (16 bytes x N apart)
+// the same four banks: profiles/r4_policy_n24_summary.json counted 0.67 of all LDS cycles as conflict cycles.  An ODD stride makes
+// n * NP + ts run through all residues modulo 16: the host passes NP = N | 1 wherever the 16 environments still fit (the padding
+// rows are never read; the Gumbel noise stays keyed by the TRUE global row env * N + agent).
 // ------------------------------------------------------------------------------------------
 struct Roll3jLds {
     float4 *s_xf;    // [2 buffers][2 dir][4 j][64 lane]: x1 fragments of one timestep per (buffer, direction)
@@ -44,15 +51,15 @@ struct Roll3jLds {
     double *s_fs;    // [16]
     int *s_fc;       // [16]
 };
-__host__ __device__ inline size_t roll3j_lds_bytes(int E, int N, int L)
+__host__ __device__ inline size_t roll3j_lds_bytes(int E, int NP, int L)   // NP: the row stride (>= N)
 {
-    const size_t rows = (size_t)E * N;
+    const size_t rows = (size_t)E * NP;
     const size_t fl = 2 * 2 * 4 * 64 * 4 + 2 * 2 * 2 * 64 * 4 + ((rows + 15) / 16) * 1024 + 16 + 3 + rows * 4 + 1;
     return fl * 4 + 8 * kWave * sizeof(float2) + (size_t)E * L * sizeof(float2) + 16 * (sizeof(double) + sizeof(int)) + 64;
 }
-__device__ __forceinline__ Roll3jLds roll3j_carve(unsigned char *raw, int E, int N, int L)
+__device__ __forceinline__ Roll3jLds roll3j_carve(unsigned char *raw, int E, int NP, int L)
 {
-    const int rows = E * N;
+    const int rows = E * NP;
     float *base = reinterpret_cast<float *>(raw);
     Roll3jLds S;
     int o = 0;
@@ -79,14 +86,14 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const ActorFusedArgs &A = P.A;
     const StreamParams &V = P.V;
-    const int N = A.N, L = V.L, D = A.D, E = A.E;
-    const Roll3jLds S = roll3j_carve(smem_raw, E, N, L);
+    const int N = A.N, L = V.L, D = A.D, E = A.E, NP = P.NP;
+    const Roll3jLds S = roll3j_carve(smem_raw, E, NP, L);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long env0 = (long)blockIdx.x * E;
     const int envs_here = (int)((long)A.B - env0 < (long)E ? (long)A.B - env0 : (long)E);
-    const int rows_here = envs_here * N;
+    const int rows_here = envs_here * NP;   // LDS rows incl. the padding rows (agent index >= N) of every environment
     const long row_base = env0 * N;
     const size_t BN = (size_t)A.B * N;
     const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
@@ -105,7 +112,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
     int el = ew * epw + e_loc;
     const bool live = env_wave && e_loc < epw && el < envs_here;
     if (!live) { e_loc = 0; a = 0; el = env_wave ? ew * epw : 0; }
-    const int base = e_loc * N, r = el * N + a;
+    const int base = e_loc * N, r = el * NP + a;   // r: this lane's row in LDS (stride NP)
     const long env = env0 + el;
     const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
     float2 *s_pos = S.s_posb + (env_wave ? ew : 0) * kWave;
@@ -198,7 +205,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
             const int rr = tile * 16 + n16;
             float nz[4] = {0.f, 0.f, 0.f, 0.f};
             if (kq < 2) {  // wave-divergent only by row group
-                const long grow = row_base + (rr < rows_here ? rr : 0);
+                const int rq = rr < rows_here ? rr : 0, re = rq / NP, ra = rq - re * NP;   // LDS row -> (environment, agent)
+                const long grow = row_base + (long)re * N + (ra < N ? ra : 0);            // the TRUE global row keys the noise
                 const uint32_t blk = (uint32_t)kq, tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
                 uint32_t u[4];
                 pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | tag, (uint32_t)step, (uint32_t)(step >> 32),
@@ -225,7 +233,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
     // dense1 of timestep ts (this wave's direction) into x1 ring buffer `buf`: rows 16 hq .. + 15, 16 sequences
     float lmk[KS > 1 ? KS - 1 : 1];  // landmark coordinate (kq & 1) of landmark 2 (s - 1) + kq / 2 of env n16: constant over the pass
     auto dense1 = [&](const int ts, const int buf) {
-        const float *st = reinterpret_cast<const float *>(S.s_st + nseq * N + ts);
+        const float *st = reinterpret_cast<const float *>(S.s_st + nseq * NP + ts);
         const float x0 = st[kq], pc = st[2 + (kq & 1)];
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], x0, acc, 0, 0, 0);
@@ -343,7 +351,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
                 lstm_cell(acc[1][0], acc[1][1], acc[1][2], acc[1][3], c1, h1v);
                 reinterpret_cast<float2 *>(S.s_hx + (((s2 & 1) * 2 + dir) * 2 + (hq >> 1)) * 64 + lane)[hq & 1] = make_float2(h0v, h1v);
                 if (seq_ok) {
-                    const int rr = n16 * N + ts;
+                    const int rr = n16 * NP + ts;
                     reinterpret_cast<float2 *>(S.s_hf + ((rr >> 4) * 4 + 2 * dir + (hq >> 1)) * 64 + kq * 16 + (rr & 15))[hq & 1] =
                         make_float2(A.relu_out ? fmaxf(h0v, 0.0f) : h0v, A.relu_out ? fmaxf(h1v, 0.0f) : h1v);
                 }

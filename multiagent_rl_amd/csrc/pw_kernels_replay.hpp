@@ -472,8 +472,8 @@ __global__ void __launch_bounds__(256) pw_state_wire_begin_kernel(const pw_state
 __global__ void __launch_bounds__(256) pw_state_wire_finalize_kernel(const pw_state_wire w, void *wire, const float *obs,
                                                                      const float *final_obs, const uint8_t *terminal,
                                                                      const int32_t *act, const uint64_t seed,
-                                                                     const uint64_t env_id_base, const unsigned copy_blocks,
-                                                                     const unsigned env_blocks)
+                                                                     const uint64_t env_id_base, const float lm_lo, const float lm_hi,
+                                                                     const unsigned copy_blocks, const unsigned env_blocks)
 {
     const StateWirePtrs p = state_wire_ptrs(w, wire);
     const size_t BN = (size_t)w.B * w.N;
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(256) pw_state_wire_finalize_kernel(const pw_st
                 p.final_state[(size_t)k * BN + i] = row_state(final_obs + ((size_t)t * BN + i) * D);
                 for (int l = a; l < w.L; l += w.N) {
                     float x, y;
-                    pw_reset_xy(seed, env_id_base + e, ep0 + (uint32_t)k + 1u, (uint32_t)(w.N + l), -1.0f, 1.0f, &x, &y);
+                    pw_reset_xy(seed, env_id_base + e, ep0 + (uint32_t)k + 1u, (uint32_t)(w.N + l), lm_lo, lm_hi, &x, &y);
                     p.lm[((size_t)(k + 1) * w.B + e) * w.L + l] = make_float2(x, y);
                 }
                 ++k;
@@ -566,6 +566,260 @@ __global__ void __launch_bounds__(256) pw_replay_add_state_wire_kernel(const pw_
                 st.rew[slot] = p.rew_shared[te];
                 st.done[slot] = 0.0f;
             }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Rows as a function of the state, in 8-byte units (every row of these scenarios is a sequence of float2 units; D is even):
+//   simple_spread, local observation (experiments/scenarios.py:6-20):  [vel] [pos] [lm_l - pos] x L
+//   simple_tag (tag_write_obs in pw_kernels_tag.hpp; upstream simple_tag.observation):
+//                                      [vel] [pos] [lm_l - pos] x L  [pos_j - pos] for j != a ascending  [vel_j] for the GOOD agents j != a
+//                                      ascending, zero-padded to D (the adversaries' width)
+// s = {vx, vy, px, py} of the env's N agents, lm = its L landmarks.  Each unit is the state itself or one float32 subtraction of two
+// numbers the caller holds -- the same operands in the same operation as the kernels that wrote the row, hence the same bits.
+// ------------------------------------------------------------------------------------------
+struct RowGeom {
+    int scenario, N, L, A;
+};
+__device__ __forceinline__ float2 state_row_unit(const RowGeom &G, const int a, const int k, const float4 *__restrict__ s,
+                                                 const float2 *__restrict__ lm)
+{
+    const float4 me = s[a];
+    if (k == 0) return make_float2(me.x, me.y);
+    if (k == 1) return make_float2(me.z, me.w);
+    int q = k - 2;
+    if (q < G.L) {
+        const float2 l = lm[q];
+        return make_float2(l.x - me.z, l.y - me.w);
+    }
+    if (G.scenario == PW_SIMPLE_TAG) {
+        q -= G.L;
+        if (q < G.N - 1) {
+            const float4 o = s[q < a ? q : q + 1];
+            return make_float2(o.z - me.z, o.w - me.w);
+        }
+        q -= G.N - 1;
+        int j = G.A + q;
+        if (a >= G.A && j >= a) ++j;
+        if (j < G.N) {
+            const float4 o = s[j];
+            return make_float2(o.x, o.y);
+        }
+    }
+    return make_float2(0.0f, 0.0f);
+}
+
+// Root side, any state-wire scenario into a ROW ring: thread = one unit of one agent's row pair (obs_t, next_obs_t).  (simple_spread
+// keeps its 16-byte form above where the alignment allows; this one serves simple_tag and is the reference for both.)
+__global__ void __launch_bounds__(256) pw_replay_add_state_wire_units_kernel(const pw_replay_store st, const int64_t start,
+                                                                             const pw_state_wire w, const void *wire)
+{
+    const StateWirePtrs p = state_wire_ptrs(w, const_cast<void *>(wire));
+    const RowGeom G = {w.scenario, w.N, w.L, w.num_adversaries};
+    const int N = w.N, U = w.D / 2;
+    const size_t BN = (size_t)w.B * N, per_step = BN * U, total = (size_t)w.T * per_step;
+    float2 *r_obs = reinterpret_cast<float2 *>(st.obs), *r_next = reinterpret_cast<float2 *>(st.next_obs);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / per_step, rem = i - t * per_step, ea = rem / U, e = ea / N;
+        const int k = (int)(rem - ea * U), a = (int)(ea - e * N);
+        const size_t te = t * w.B + e;
+        const unsigned epi = p.epi[te], ke = epi & 0x7fu;
+        const float4 *s_obs = (t == 0 ? p.state0 : p.state + (t - 1) * BN) + e * N;
+        const float4 *s_next = ((epi & 0x80u) ? p.final_state + (size_t)ke * BN : p.state + t * BN) + e * N;
+        const float2 *lm = p.lm + ((size_t)ke * w.B + e) * w.L;
+        const size_t slot = (size_t)((start + (int64_t)te) % st.capacity);
+        const size_t at = (slot * N + a) * U + k;
+        r_obs[at] = state_row_unit(G, a, k, s_obs, lm);
+        r_next[at] = state_row_unit(G, a, k, s_next, lm);
+        if (k == 0) {
+            st.act[slot * N + a] = p.act[te * N + a];
+            if (a == 0) {
+                st.rew[slot] = p.rew_shared[te];
+                st.done[slot] = 0.0f;
+            }
+        }
+    }
+}
+
+// Root side, into a STATE ring (pw_replay_store.state_rows): the transition keeps what the block carries -- {vel, pos} of every agent
+// before and after the step (pre-reset where the step ended an episode) and the episode's landmarks; nothing is rebuilt here.
+// Thread = (step, env, agent): 2 x 16 B of state, the byte action, its share of the L landmarks; agent 0 the reward / done words.
+__global__ void __launch_bounds__(256) pw_replay_add_state_wire_to_state_ring_kernel(const pw_replay_store st, const int64_t start,
+                                                                                     const pw_state_wire w, const void *wire)
+{
+    const StateWirePtrs p = state_wire_ptrs(w, const_cast<void *>(wire));
+    const int N = w.N, L = w.L;
+    const size_t BN = (size_t)w.B * N, total = (size_t)w.T * BN;
+    float4 *r_s = reinterpret_cast<float4 *>(st.obs), *r_n = reinterpret_cast<float4 *>(st.next_obs);
+    float2 *r_lm = reinterpret_cast<float2 *>(st.lm);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / BN, ea = i - t * BN, e = ea / N;
+        const int a = (int)(ea - e * N);
+        const size_t te = t * w.B + e;
+        const unsigned epi = p.epi[te], ke = epi & 0x7fu;
+        const size_t slot = (size_t)((start + (int64_t)te) % st.capacity);
+        r_s[slot * N + a] = t == 0 ? p.state0[ea] : p.state[(t - 1) * BN + ea];
+        r_n[slot * N + a] = (epi & 0x80u) ? p.final_state[(size_t)ke * BN + ea] : p.state[t * BN + ea];
+        const float2 *lm = p.lm + ((size_t)ke * w.B + e) * L;
+        for (int l = a; l < L; l += N) r_lm[slot * L + l] = lm[l];
+        st.act[slot * N + a] = p.act[te * N + a];
+        if (a == 0) {
+            st.rew[slot] = p.rew_shared[te];
+            st.done[slot] = 0.0f;
+        }
+    }
+}
+
+// sample_index() on a STATE ring: thread = one unit of one agent's row pair of one sampled transition, REBUILT from the slot's states
+// and landmarks (state_row_unit); unit 0 also writes the agent's one-hot action row, agent 0's unit 0 the reward / done words.
+__global__ void __launch_bounds__(256) pw_replay_gather_state_kernel(const pw_replay_store st, const int64_t *idx, const int b,
+                                                                     float *out_obs, float *out_act, float *out_rew,
+                                                                     float *out_next_obs, float *out_done)
+{
+    const RowGeom G = {st.scenario, st.num_agents, st.num_landmarks, st.num_adversaries};
+    const int N = st.num_agents, U = st.obs_dim / 2, W0 = st.head_width[0] > 0 ? st.head_width[0] : 5;
+    const size_t total = (size_t)b * N * U;
+    const float4 *r_s = reinterpret_cast<const float4 *>(st.obs), *r_n = reinterpret_cast<const float4 *>(st.next_obs);
+    const float2 *r_lm = reinterpret_cast<const float2 *>(st.lm);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t ea = i / U, e = ea / N;
+        const int k = (int)(i - ea * U), a = (int)(ea - e * N);
+        const size_t slot = (size_t)idx[e];
+        const float2 *lm = r_lm + slot * G.L;
+        if (out_obs) reinterpret_cast<float2 *>(out_obs)[i] = state_row_unit(G, a, k, r_s + slot * N, lm);
+        if (out_next_obs) reinterpret_cast<float2 *>(out_next_obs)[i] = state_row_unit(G, a, k, r_n + slot * N, lm);
+        if (k == 0) {
+            if (out_act) {
+                const int a0 = st.act[slot * N + a];
+                float *row = out_act + ea * W0;
+                for (int q = 0; q < W0; ++q) row[q] = a0 == q ? 1.0f : 0.0f;
+            }
+            if (a == 0) {
+                if (out_rew) out_rew[e] = st.rew[slot];
+                if (out_done) out_done[e] = st.done[slot];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Compact-row wire block of simple_reference (include/pworld.h, pw_ref_wire).  Row of agent a (ref_write_obs in pw_kernels_reference.hpp;
+// experiments/scenarios.py:23-42): [vel (2), landmark - pos (6)] = the "head", carried as it is; [goal colour (3)]: 0.75 on the goal
+// landmark's channel, 0.25 elsewhere; [the other agent's communication state (10)]: one-hot of its symbol, zeros after a reset.
+// ------------------------------------------------------------------------------------------
+constexpr int kRefN = 2, kRefD = 21, kRefHead = 8, kRefDimC = PW_DIM_C;
+struct RefWirePtrs {
+    float *head0, *head, *final_head, *rew_shared;
+    uint8_t *goal, *comm0, *act, *epi;
+};
+__host__ __device__ inline RefWirePtrs ref_wire_ptrs(const pw_ref_wire &w, void *wire)
+{
+    unsigned char *b = static_cast<unsigned char *>(wire);
+    RefWirePtrs p;
+    p.head0 = reinterpret_cast<float *>(b + w.head0);
+    p.head = reinterpret_cast<float *>(b + w.head);
+    p.final_head = reinterpret_cast<float *>(b + w.final_head);
+    p.rew_shared = reinterpret_cast<float *>(b + w.rew_shared);
+    p.goal = b + w.goal;
+    p.comm0 = b + w.comm0;
+    p.act = b + w.act;
+    p.epi = b + w.epi;
+    return p;
+}
+__device__ __forceinline__ uint8_t ref_row_goal(const float *row)   // the channel that carries 0.75 (first one if the row is foreign)
+{
+    return (uint8_t)(row[9] > row[8] ? (row[10] > row[9] ? 2 : 1) : (row[10] > row[8] ? 2 : 0));
+}
+__device__ __forceinline__ uint8_t ref_row_symbol(const float *row)  // the other agent's symbol in columns 11..20, 0xFF for zeros
+{
+    for (int q = 0; q < kRefDimC; ++q)
+        if (row[11 + q] != 0.0f) return (uint8_t)q;
+    return 0xFF;
+}
+
+// Sender.  Workgroups [0, copy_blocks): the heads of every post-step row (grid-stride, one float per thread).  Workgroups
+// [copy_blocks, copy_blocks + env_blocks): thread = (env, agent): head0 / goal[0] / comm0 from obs0, then the env's T terminal flags in
+// order -- the k-th episode end's pre-reset head, the goal the reset drew (read off the post-reset row), agent 0 the epi byte.
+// The rest narrow the two-head int32 actions to bytes.
+__global__ void __launch_bounds__(256) pw_ref_wire_finalize_kernel(const pw_ref_wire w, void *wire, const float *obs0, const float *obs,
+                                                                   const float *final_obs, const uint8_t *terminal, const int32_t *act,
+                                                                   const unsigned copy_blocks, const unsigned env_blocks)
+{
+    const RefWirePtrs p = ref_wire_ptrs(w, wire);
+    const size_t BN = (size_t)w.B * kRefN;
+    if (blockIdx.x < copy_blocks) {
+        const size_t total = (size_t)w.T * BN * kRefHead;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)copy_blocks * blockDim.x) {
+            const size_t row = i / kRefHead;
+            p.head[i] = obs[row * kRefD + (i - row * kRefHead)];
+        }
+        return;
+    }
+    if (blockIdx.x < copy_blocks + env_blocks) {
+        const size_t i = (size_t)(blockIdx.x - copy_blocks) * blockDim.x + threadIdx.x;
+        if (i >= BN) return;
+        const size_t e = i / kRefN;
+        const int a = (int)(i - e * kRefN);
+        const float *r0 = obs0 + i * kRefD;
+        for (int c = 0; c < kRefHead; ++c) p.head0[i * kRefHead + c] = r0[c];
+        p.goal[i] = ref_row_goal(r0);
+        p.comm0[i] = ref_row_symbol(r0);
+        int k = 0;
+        for (int t = 0; t < w.T; ++t) {
+            const size_t te = (size_t)t * w.B + e;
+            const bool term = terminal[te] != 0 && final_obs != nullptr && k < w.F;
+            if (a == 0) p.epi[te] = (uint8_t)(k | (term ? 0x80 : 0));
+            if (term) {
+                const float *fr = final_obs + ((size_t)t * BN + i) * kRefD;
+                for (int c = 0; c < kRefHead; ++c) p.final_head[((size_t)k * BN + i) * kRefHead + c] = fr[c];
+                p.goal[(size_t)(k + 1) * BN + i] = ref_row_goal(obs + ((size_t)t * BN + i) * kRefD);   // the post-reset row
+                ++k;
+            }
+        }
+        return;
+    }
+    const size_t total = (size_t)w.T * BN * 2;
+    const unsigned first = copy_blocks + env_blocks, nb = gridDim.x - first;
+    for (size_t i = (size_t)(blockIdx.x - first) * blockDim.x + threadIdx.x; i < total; i += (size_t)nb * blockDim.x)
+        p.act[i] = (uint8_t)act[i];
+}
+
+// Root: ReplayBuffer.add() of the block's T*B transitions into the two-head ring, rows rebuilt.  Thread = one column of one agent's
+// row pair (obs_t, next_obs_t).
+__global__ void __launch_bounds__(256) pw_replay_add_ref_wire_kernel(const pw_replay_store st, const int64_t start, const pw_ref_wire w,
+                                                                     const void *wire)
+{
+    const RefWirePtrs p = ref_wire_ptrs(w, const_cast<void *>(wire));
+    const size_t BN = (size_t)w.B * kRefN, per_step = BN * kRefD, total = (size_t)w.T * per_step;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / per_step, rem = i - t * per_step, ea = rem / kRefD, e = ea / kRefN;
+        const int c = (int)(rem - ea * kRefD), a = (int)(ea - e * kRefN);
+        const size_t te = t * w.B + e, other = e * kRefN + (1 - a);
+        const unsigned epi = p.epi[te], k = epi & 0x7fu;
+        const bool ended = (epi & 0x80u) != 0;
+        float o, n;
+        if (c < kRefHead) {
+            o = (t == 0 ? p.head0 : p.head + (t - 1) * BN * kRefHead)[ea * kRefHead + c];
+            n = (ended ? p.final_head + (size_t)k * BN * kRefHead : p.head + t * BN * kRefHead)[ea * kRefHead + c];
+        } else if (c < kRefHead + 3) {
+            o = n = (c - kRefHead) == (int)p.goal[(size_t)k * BN + ea] ? 0.75f : 0.25f;   // one episode: obs_t and next_obs_t share the goal
+        } else {
+            const int q = c - kRefHead - 3;
+            // what agent a sees of the other agent at step t: the symbol it sampled at step t - 1 (none right after a reset)
+            const unsigned prev = t == 0 ? p.comm0[ea] : ((p.epi[te - w.B] & 0x80u) ? 0xFFu : p.act[((t - 1) * BN + other) * 2 + 1]);
+            o = (unsigned)q == prev ? 1.0f : 0.0f;
+            n = q == (int)p.act[(t * BN + other) * 2 + 1] ? 1.0f : 0.0f;   // pre-reset or not: this step's symbol
+        }
+        const size_t slot = (size_t)((start + (int64_t)te) % st.capacity);
+        const size_t at = (slot * kRefN + a) * kRefD + c;
+        st.obs[at] = o;
+        st.next_obs[at] = n;
+        if (c < 2) st.act[(slot * kRefN + a) * 2 + c] = p.act[(t * BN + ea) * 2 + c];
+        if (c == 0 && a == 0) {
+            st.rew[slot] = p.rew_shared[te];
+            st.done[slot] = 0.0f;
         }
     }
 }

@@ -850,6 +850,7 @@ int pw_replay_add(const pw_replay_store *st, int64_t start, const int64_t *start
                   const uint8_t *terminal, const float *done, void *stream)
 {
     if (!st || !obs || !act_idx || !rew_shared || !next_obs) return fail(PW_EINVAL, "null argument");
+    if (st->state_rows) return fail(PW_EINVAL, "pw_replay_add: a STATE ring is filled by pw_replay_add_state_wire only (rows do not determine the landmarks)");
     if (st->capacity < 1 || B < 1 || B > st->capacity || start < 0) return fail(PW_EINVAL, "bad ring arguments");
     if (st->obs_dim < 2) return fail(PW_EINVAL, "obs_dim must be >= 2");
     if (st->act_heads < 0 || st->act_heads > 2 || (st->act_heads == 2 && (st->head_width[0] < 0 || st->head_width[1] < 1)))
@@ -895,6 +896,7 @@ int pw_replay_add_rollout(const pw_replay_store *st, int64_t start, int32_t B, i
 {
     if (!st || !obs0 || !io || !act || !io->obs || !io->rew_shared || !io->terminal) return fail(PW_EINVAL, "null argument");
     if (st->per_agent) return fail(PW_EINVAL, "pw_replay_add_rollout: per-agent rings are served by pw_replay_add and pw_replay_gather only");
+    if (st->state_rows) return fail(PW_EINVAL, "pw_replay_add_rollout: a STATE ring is filled by pw_replay_add_state_wire only");
     if (st->capacity < 1 || B < 1 || T < 1 || (int64_t)B * T > st->capacity || start < 0)
         return fail(PW_EINVAL, "bad ring arguments (the chunk must fit the ring)");
     if (st->obs_dim < 5) return fail(PW_EINVAL, "obs_dim must be >= 5");
@@ -931,6 +933,17 @@ int pw_replay_gather(const pw_replay_store *st, const int64_t *idx, int32_t b, f
     if (st->obs_dim < 2) return fail(PW_EINVAL, "obs_dim must be >= 2");
     if (st->act_heads < 0 || st->act_heads > 2 || (st->act_heads == 2 && (st->head_width[0] < 0 || st->head_width[1] < 1)))
         return fail(PW_EINVAL, "bad act_heads / head_width");
+    if (st->state_rows) {  // STATE ring: the rows are rebuilt from the slot's states and landmarks
+        if (int rc = state_ring_ok(st, "pw_replay_gather")) return rc;
+        if ((reinterpret_cast<uintptr_t>(out_obs) | reinterpret_cast<uintptr_t>(out_next_obs)) & 7)
+            return fail(PW_EINVAL, "pw_replay_gather (STATE ring): out_obs / out_next_obs must be 8-byte aligned");
+        size_t sblocks = ((size_t)b * st->num_agents * (st->obs_dim / 2) + 255) / 256;
+        if (sblocks > 8192) sblocks = 8192;
+        hipLaunchKernelGGL(pw_replay_gather_state_kernel, dim3((unsigned)sblocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           *st, idx, b, out_obs, out_act, out_rew, out_next_obs, out_done);
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
     const size_t total = (size_t)b * st->num_agents * st->obs_dim;
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -1076,10 +1089,18 @@ int pw_replay_add_wire(const pw_replay_store *st, int64_t start, const pw_chunk_
 }
 
 namespace {
-void fill_state_wire(int32_t T, int32_t B, int32_t N, int32_t L, int32_t F, pw_state_wire *out)
+int state_wire_row_dim(int scenario, int N, int L, int A)
+{
+    if (scenario == PW_SIMPLE_SPREAD) return 4 + 2 * L;
+    if (scenario == PW_SIMPLE_TAG) return 4 + 2 * L + 2 * (N - 1) + 2 * (N - A);
+    return -1;
+}
+
+void fill_state_wire(int32_t scenario, int32_t T, int32_t B, int32_t N, int32_t L, int32_t A, int32_t F, pw_state_wire *out)
 {
     std::memset(out, 0, sizeof(*out));
-    out->T = T; out->B = B; out->N = N; out->L = L; out->D = 4 + 2 * L; out->F = F;
+    out->T = T; out->B = B; out->N = N; out->L = L; out->D = state_wire_row_dim(scenario, N, L, A); out->F = F;
+    out->scenario = scenario; out->num_adversaries = A;
     const size_t st = (size_t)B * N * sizeof(float4);
     size_t off = 0;
     auto plane = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -1097,10 +1118,11 @@ void fill_state_wire(int32_t T, int32_t B, int32_t N, int32_t L, int32_t F, pw_s
 int check_state_wire(const pw_state_wire *w, const void *wire)
 {
     if (!w || !wire) return fail(PW_EINVAL, "null argument");
-    if (w->T < 1 || w->B < 1 || w->N < 1 || w->L < 0 || w->D != 4 + 2 * w->L || w->F < 0 || w->F > 126)
+    if (w->T < 1 || w->B < 1 || w->N < 1 || w->L < 0 || w->F < 0 || w->F > 126 || w->num_adversaries < 0 || w->num_adversaries > w->N ||
+        w->D < 4 || w->D != state_wire_row_dim(w->scenario, w->N, w->L, w->num_adversaries))
         return fail(PW_EINVAL, "bad state-wire layout");
     pw_state_wire ref;  // offsets must be the ones pw_state_wire_layout produces
-    fill_state_wire(w->T, w->B, w->N, w->L, w->F, &ref);
+    fill_state_wire(w->scenario, w->T, w->B, w->N, w->L, w->num_adversaries, w->F, &ref);
     if (std::memcmp(&ref, w, sizeof(ref)) != 0) return fail(PW_EINVAL, "wire layout was not produced by pw_state_wire_layout");
     if (reinterpret_cast<uintptr_t>(wire) & 255) return fail(PW_EINVAL, "wire block must be 256-byte aligned");
     return PW_OK;
@@ -1109,22 +1131,35 @@ int check_state_wire(const pw_state_wire *w, const void *wire)
 int state_wire_handle_ok(const pw_handle *h, const pw_state_wire *w)
 {
     if (!h) return fail(PW_EINVAL, "null handle");
-    if (h->cfg.scenario != PW_SIMPLE_SPREAD || h->cfg.obs_mode != PW_OBS_LOCAL || h->kp.D != 4 + 2 * h->kp.L)
-        return fail(PW_EINVAL, "state-only wire blocks serve simple_spread with the local observation (rows that are a function "
-                               "of {vel, pos} and the landmarks); use pw_chunk_wire_* elsewhere");
-    if (w && (w->B != h->kp.B || w->N != h->kp.N || w->L != h->kp.L)) return fail(PW_EINVAL, "wire / handle shape mismatch");
+    const bool spread = h->cfg.scenario == PW_SIMPLE_SPREAD && h->cfg.obs_mode == PW_OBS_LOCAL;
+    const bool tag = h->cfg.scenario == PW_SIMPLE_TAG;
+    if (!(spread || tag) || h->kp.D != state_wire_row_dim(h->cfg.scenario, h->kp.N, h->kp.L, h->kp.A))
+        return fail(PW_EINVAL, "state-only wire blocks serve simple_spread with the local observation and simple_tag (rows that are a "
+                               "function of {vel, pos} and the landmarks); use pw_chunk_wire_* elsewhere");
+    if (w && (w->scenario != h->cfg.scenario || w->B != h->kp.B || w->N != h->kp.N || w->L != h->kp.L ||
+              (tag && w->num_adversaries != h->kp.A)))
+        return fail(PW_EINVAL, "wire / handle shape mismatch");
     return PW_OK;
 }
 }  // namespace
 
-int pw_state_wire_layout(int32_t T, int32_t B, int32_t N, int32_t L, int32_t max_episode_len, pw_state_wire *out)
+int pw_state_wire_layout_scn(int32_t scenario, int32_t T, int32_t B, int32_t N, int32_t L, int32_t num_adversaries,
+                             int32_t max_episode_len, pw_state_wire *out)
 {
     if (!out) return fail(PW_EINVAL, "null argument");
-    if (T < 1 || B < 1 || N < 1 || L < 0 || max_episode_len < 0) return fail(PW_EINVAL, "bad sizes");
+    if (scenario != PW_SIMPLE_SPREAD && scenario != PW_SIMPLE_TAG)
+        return fail(PW_EINVAL, "state-only wire blocks serve simple_spread (local observation) and simple_tag");
+    if (scenario == PW_SIMPLE_SPREAD) num_adversaries = 0;
+    if (T < 1 || B < 1 || N < 1 || L < 0 || max_episode_len < 0 || num_adversaries < 0 || num_adversaries > N) return fail(PW_EINVAL, "bad sizes");
     const int64_t F = max_episode_len > 0 ? ((int64_t)T + max_episode_len - 1) / max_episode_len : 0;
     if (F > 126) return fail(PW_EINVAL, "more than 126 episode ends per env and chunk: use shorter chunks");
-    fill_state_wire(T, B, N, L, (int32_t)F, out);
+    fill_state_wire(scenario, T, B, N, L, num_adversaries, (int32_t)F, out);
     return PW_OK;
+}
+
+int pw_state_wire_layout(int32_t T, int32_t B, int32_t N, int32_t L, int32_t max_episode_len, pw_state_wire *out)
+{
+    return pw_state_wire_layout_scn(PW_SIMPLE_SPREAD, T, B, N, L, 0, max_episode_len, out);
 }
 
 int pw_state_wire_begin(const pw_handle *h, const pw_state_wire *w, void *wire, void *stream)
@@ -1154,9 +1189,11 @@ int pw_state_wire_finalize(const pw_handle *h, const pw_state_wire *w, void *wir
     const unsigned env_blocks = (unsigned)((BN + 255) / 256);
     size_t act_blocks = (total + 255) / 256;
     if (act_blocks > 2048) act_blocks = 2048;
+    // the landmarks an in-chunk reset drew: simple_spread U(-1, 1), simple_tag U(-0.9, 0.9) (upstream reset_world)
+    const float lm_lo = w->scenario == PW_SIMPLE_TAG ? -0.9f : -1.0f, lm_hi = w->scenario == PW_SIMPLE_TAG ? 0.9f : 1.0f;
     hipLaunchKernelGGL(pw_state_wire_finalize_kernel, dim3((unsigned)(copy_blocks + env_blocks + act_blocks)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), *w, wire, obs, final_obs, terminal, act, (uint64_t)h->kp.seed,
-                       (uint64_t)h->kp.env_id_base, (unsigned)copy_blocks, env_blocks);
+                       (uint64_t)h->kp.env_id_base, lm_lo, lm_hi, (unsigned)copy_blocks, env_blocks);
     PW_HIP_CHECK(hipGetLastError());
     return PW_OK;
 }
@@ -1164,23 +1201,118 @@ int pw_state_wire_finalize(const pw_handle *h, const pw_state_wire *w, void *wir
 int pw_replay_add_state_wire(const pw_replay_store *st, int64_t start, const pw_state_wire *w, const void *wire, void *stream)
 {
     if (!st) return fail(PW_EINVAL, "null argument");
-    if (int rc = plain_ring_only(st, "pw_replay_add_state_wire")) return rc;
     if (int rc = check_state_wire(w, wire)) return rc;
     if (st->num_agents != w->N || st->obs_dim != w->D) return fail(PW_EINVAL, "ring / wire shape mismatch");
     if (st->capacity < 1 || (int64_t)w->T * w->B > st->capacity || start < 0)
         return fail(PW_EINVAL, "bad ring arguments (the chunk must fit the ring)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (st->state_rows) {  // STATE ring: copy what the block carries; pw_replay_gather rebuilds the rows
+        if (int rc = state_ring_ok(st, "pw_replay_add_state_wire")) return rc;
+        if (st->scenario != w->scenario || st->num_landmarks != w->L || st->num_adversaries != w->num_adversaries)
+            return fail(PW_EINVAL, "STATE ring / wire scenario mismatch");
+        size_t blocks = ((size_t)w->T * w->B * w->N + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(pw_replay_add_state_wire_to_state_ring_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *st, start, *w, wire);
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
+    if (int rc = plain_ring_only(st, "pw_replay_add_state_wire")) return rc;
     const uintptr_t al = reinterpret_cast<uintptr_t>(st->obs) | reinterpret_cast<uintptr_t>(st->next_obs);
+    if (al & 7) return fail(PW_EINVAL, "ring observation planes must be 8-byte aligned");
+    if (w->scenario != PW_SIMPLE_SPREAD) {  // simple_tag: 8-byte units (other agents' states feed every row)
+        size_t blocks = ((size_t)w->T * w->B * w->N * (w->D / 2) + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(pw_replay_add_state_wire_units_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *st, start, *w, wire);
+        PW_HIP_CHECK(hipGetLastError());
+        return PW_OK;
+    }
     const bool v4 = w->L % 2 == 0 && (al & 15) == 0;
-    if (!v4 && (al & 7)) return fail(PW_EINVAL, "ring observation planes must be 8-byte aligned");
     const size_t total = (size_t)w->T * w->B * w->N * (v4 ? w->D / 4 : w->D / 2);
     size_t blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     if (v4)
-        hipLaunchKernelGGL(pw_replay_add_state_wire_kernel<4>, dim3((unsigned)blocks), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), *st, start, *w, wire);
+        hipLaunchKernelGGL(pw_replay_add_state_wire_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, *st, start, *w, wire);
     else
-        hipLaunchKernelGGL(pw_replay_add_state_wire_kernel<2>, dim3((unsigned)blocks), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), *st, start, *w, wire);
+        hipLaunchKernelGGL(pw_replay_add_state_wire_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, *st, start, *w, wire);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+}  // extern "C"
+
+namespace {
+void fill_ref_wire(int32_t T, int32_t B, int32_t F, pw_ref_wire *out)
+{
+    std::memset(out, 0, sizeof(*out));
+    out->T = T; out->B = B; out->F = F;
+    const size_t hd = (size_t)B * kRefN * kRefHead * sizeof(float);
+    size_t off = 0;
+    auto plane = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    out->head0 = plane(hd);
+    out->head = plane((size_t)T * hd);
+    out->final_head = plane((size_t)F * hd);
+    out->goal = plane((size_t)(F + 1) * B * kRefN);
+    out->comm0 = plane((size_t)B * kRefN);
+    out->rew_shared = plane((size_t)T * B * sizeof(float));
+    out->act = plane((size_t)T * B * kRefN * 2);
+    out->epi = plane((size_t)T * B);
+    out->total_bytes = off;
+}
+
+int check_ref_wire(const pw_ref_wire *w, const void *wire)
+{
+    if (!w || !wire) return fail(PW_EINVAL, "null argument");
+    if (w->T < 1 || w->B < 1 || w->F < 0 || w->F > 126) return fail(PW_EINVAL, "bad ref-wire layout");
+    pw_ref_wire ref;
+    fill_ref_wire(w->T, w->B, w->F, &ref);
+    if (std::memcmp(&ref, w, sizeof(ref)) != 0) return fail(PW_EINVAL, "wire layout was not produced by pw_ref_wire_layout");
+    if (reinterpret_cast<uintptr_t>(wire) & 255) return fail(PW_EINVAL, "wire block must be 256-byte aligned");
+    return PW_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int pw_ref_wire_layout(int32_t T, int32_t B, int32_t max_episode_len, pw_ref_wire *out)
+{
+    if (!out) return fail(PW_EINVAL, "null argument");
+    if (T < 1 || B < 1 || max_episode_len < 0) return fail(PW_EINVAL, "bad sizes");
+    const int64_t F = max_episode_len > 0 ? ((int64_t)T + max_episode_len - 1) / max_episode_len : 0;
+    if (F > 126) return fail(PW_EINVAL, "more than 126 episode ends per env and chunk: use shorter chunks");
+    fill_ref_wire(T, B, (int32_t)F, out);
+    return PW_OK;
+}
+
+int pw_ref_wire_finalize(const pw_ref_wire *w, void *wire, const float *obs0, const float *obs, const float *final_obs,
+                         const uint8_t *terminal, const int32_t *act, void *stream)
+{
+    if (int rc = check_ref_wire(w, wire)) return rc;
+    if (!obs0 || !obs || !terminal || !act) return fail(PW_EINVAL, "null argument");
+    if (w->F > 0 && !final_obs) return fail(PW_EINVAL, "final_obs is needed when episodes end inside the chunk");
+    const size_t BN = (size_t)w->B * kRefN;
+    size_t copy_blocks = ((size_t)w->T * BN * kRefHead + 255) / 256;
+    if (copy_blocks > 8192) copy_blocks = 8192;
+    const unsigned env_blocks = (unsigned)((BN + 255) / 256);
+    size_t act_blocks = ((size_t)w->T * BN * 2 + 255) / 256;
+    if (act_blocks > 2048) act_blocks = 2048;
+    hipLaunchKernelGGL(pw_ref_wire_finalize_kernel, dim3((unsigned)(copy_blocks + env_blocks + act_blocks)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *w, wire, obs0, obs, final_obs, terminal, act, (unsigned)copy_blocks, env_blocks);
+    PW_HIP_CHECK(hipGetLastError());
+    return PW_OK;
+}
+
+int pw_replay_add_ref_wire(const pw_replay_store *st, int64_t start, const pw_ref_wire *w, const void *wire, void *stream)
+{
+    if (!st) return fail(PW_EINVAL, "null argument");
+    if (int rc = check_ref_wire(w, wire)) return rc;
+    if (st->state_rows || st->per_agent || st->act_heads != 2 || st->head_width[1] != PW_DIM_C || (st->head_width[0] != 0 && st->head_width[0] != 5))
+        return fail(PW_EINVAL, "pw_replay_add_ref_wire: the ring must be the two-head ring of simple_reference (act_heads = 2, head widths 5 | dim_c)");
+    if (st->num_agents != kRefN || st->obs_dim != kRefD) return fail(PW_EINVAL, "ring / wire shape mismatch (simple_reference: N = 2, D = 21)");
+    if (st->capacity < 1 || (int64_t)w->T * w->B > st->capacity || start < 0)
+        return fail(PW_EINVAL, "bad ring arguments (the chunk must fit the ring)");
+    size_t blocks = ((size_t)w->T * w->B * kRefN * kRefD + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(pw_replay_add_ref_wire_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), *st, start, *w, wire);
     PW_HIP_CHECK(hipGetLastError());
     return PW_OK;
 }

@@ -302,11 +302,13 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     // N = 12: 67 / 33.0 / 34.1; N = 14: 111 / 77 / 41.5; N = 16: 170 / 89 / 49.0; N = 20: 270 / 211 / 60; N = 24: 414 / 495 / 77.1;
     // N = 30: 494 / - / 100; N = 48: - / - / 342.  Automatic wherever the plain third form does not keep its 16 columns busy; policy_form 4 forces it
     // (tests run it at small N too).
-    int E3j = 0;
+    int E3j = 0, NPj = kp.N;
     if (!tag && kp.D == 4 + 2 * kp.L && kp.L <= kp.N && !a.bf16x3 && (form == 4 || (form == 0 && !use_v3))) {
         const int ecap = 8 * (kWave / kp.N) < 16 ? 8 * (kWave / kp.N) : 16;   // at most 8 environment waves of whole environments
         for (int e = kp.B < ecap ? kp.B : ecap; e >= 1; --e)
             if (roll3j_lds_bytes(e, kp.N, kp.L) <= 160 * 1024) { E3j = e; break; }
+        // an odd LDS row stride (no bank conflicts between the sixteen sequences: pw_kernels_policy3j.hpp) wherever it costs no environment
+        if (E3j > 0 && roll3j_lds_bytes(E3j, kp.N | 1, kp.L) <= 160 * 1024) NPj = kp.N | 1;
     }
     if (form == 4 && E3j == 0) return fail(PW_EINVAL, "policy_form 4 (just-in-time dense1) serves the local observation with L <= N");
     if (wide && (E3j == 0 || (form != 0 && form != 4)))
@@ -315,7 +317,8 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     if (form == 0 && !use_v3 && E3j < (kp.B < 8 ? kp.B : 8) && E3 >= (kp.B < 8 ? kp.B : 8)) use_v3 = true;  // the round-3 rule
     if (!use_v3 && E3j > 0 && (form == 4 || wide || E3j >= (kp.B < 8 ? kp.B : 8))) {
         a.E = E3j;
-        const size_t shmj = roll3j_lds_bytes(E3j, kp.N, kp.L);
+        P.NP = NPj;
+        const size_t shmj = roll3j_lds_bytes(E3j, NPj, kp.L);
         const unsigned gridj = (unsigned)((kp.B + E3j - 1) / E3j);
 #define PW_R3J2(C, SK)                                                                                                   \
     do {                                                                                                                 \

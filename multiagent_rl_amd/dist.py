@@ -262,23 +262,40 @@ class FullTransitionGather(object):
 
     SLOTS = 3
 
-    def __init__(self, env, T, rank, world, device, memory=None, group=None, capacity=int(1e6), wire='auto', overlap_ingest=True):
+    def __init__(self, env, T, rank, world, device, memory=None, group=None, capacity=int(1e6), wire='auto', overlap_ingest=True,
+                 ring='rows'):
         from ._lib import PwChunkWire, PwStateWire
         self.rank, self.world, self.device, self.group = rank, world, torch.device(device), group
         self.B, self.N, self.D, self.T = env.num_envs, env.n, env.obs_dim, int(T)
         self.L = int(getattr(env, 'num_landmarks', 0))
+        self.A = int(env.cfg.num_adversaries if hasattr(env, "cfg") else (getattr(env, "num_adversaries", 0) or 0)) if getattr(env, "scenario_name", "") == "simple_tag" else 0
+        self.scenario = getattr(env, 'scenario_name', 'simple_spread')
         self.env = env
+        if ring not in ('rows', 'state'):
+            raise ValueError("ring must be 'rows' or 'state'")
+        # simple_reference (MultiDiscrete: act [T,B,N,2]) travels on its own compact-row blocks (pw_ref_wire: both heads as bytes, the
+        # first 8 numbers of every row, goal bytes per episode; the root rebuilds the 21-number rows into the two-head ring).  The
+        # row / state blocks carry ONE action index per agent (a two-head rollout overran their single-head side buffer).
+        self.ref_wire = self.scenario == 'simple_reference'
+        if self.ref_wire and (wire == 'rows' or ring == 'state'):
+            raise ValueError("FullTransitionGather: simple_reference has a two-head (MultiDiscrete) action; it is served by the "
+                             "compact-row wire (wire='auto') into a two-head row ring only")
+        if self.scenario == 'simple_speaker_listener':
+            raise ValueError('FullTransitionGather: simple_speaker_listener (per-agent action spaces) is not served')
         self.max_episode_len = int(env.cfg.max_episode_len) if hasattr(env, 'cfg') else int(env.max_episode_len)
         if wire not in ('auto', 'state', 'rows'):
             raise ValueError("wire must be 'auto', 'state' or 'rows'")
         if hasattr(env, 'cfg') and self.max_episode_len > 0 and not env.cfg.auto_reset:
             raise ValueError('FullTransitionGather needs an auto-resetting env: the blocks carry the pre-reset observation (state) of '
                              'every episode end, which only the in-kernel reset writes')
-        fits = self._state_wire_applies(env)
+        fits = self._state_wire_applies(env) and not self.ref_wire
         if wire == 'state' and not fits:
-            raise ValueError('state-only wire blocks serve simple_spread with the local observation (D = 4 + 2L)')
+            raise ValueError('state-only wire blocks serve simple_spread with the local observation (D = 4 + 2L) and simple_tag')
         self.state_wire = fits and wire != 'rows'
-        self.lay = self._layout(PwStateWire if self.state_wire else PwChunkWire)
+        if ring == 'state' and not self.state_wire:
+            raise ValueError("ring='state' needs state-only wire blocks (a STATE ring is filled from them only)")
+        self.ring_kind = ring
+        self.lay = self._layout(_lib.PwRefWire if self.ref_wire else PwStateWire if self.state_wire else PwChunkWire)
         nbytes = self.lay.total_bytes
         dev = self.device
         # THREE slots: chunk k's blocks travel (and, at the root, are appended) while chunk k + 1 rolls out into the next slot and
@@ -294,14 +311,15 @@ class FullTransitionGather(object):
         self._ingest_stream = torch.cuda.Stream(dev, priority=-1) if (dev.type == 'cuda' and rank == 0 and overlap_ingest) else None
         self._slot_free = [None] * self.SLOTS
         self._finalized = [None] * self.SLOTS
+        self._reads_done = None     # event behind the learner's last reads of the ring (mark_reads_done)
         B, N, D = self.B, self.N, self.D
         # the rollout's outputs that do NOT travel as they are (finalize condenses them into the block)
         self.side = dict(final_obs=torch.empty(self.T, B, N, D, dtype=torch.float32, device=dev) if self.lay.F else None,
                          terminal=torch.zeros(self.T, B, dtype=torch.bool, device=dev),
-                         act=torch.zeros(self.T, B, N, dtype=torch.int32, device=dev),
+                         act=torch.zeros((self.T, B, N, 2) if self.ref_wire else (self.T, B, N), dtype=torch.int32, device=dev),
                          rew=torch.empty(self.T, B, N, dtype=torch.float32, device=dev),
                          done=torch.zeros(self.T, B, N, dtype=torch.bool, device=dev))
-        if self.state_wire:   # the rows stay on the sender: only their first four columns travel
+        if self.state_wire or self.ref_wire:   # the rows stay on the sender: only their first four (eight) columns travel
             self.side['obs'] = torch.empty(self.T, B, N, D, dtype=torch.float32, device=dev)
         self.memory = memory
         self.capacity = int(capacity)
@@ -313,15 +331,22 @@ class FullTransitionGather(object):
 
     # -- layout / views
     def _state_wire_applies(self, env):
-        """Rows that are a function of {vel, pos} and the landmarks: simple_spread, local observation."""
+        """Rows that are a function of {vel, pos} and the landmarks: simple_spread with the local observation, simple_tag."""
         name = getattr(env, 'scenario_name', None)
         local = env.cfg.obs_mode == _lib.PW_OBS_LOCAL if hasattr(env, 'cfg') else getattr(env, 'local_observation', True)
+        if name == 'simple_tag':
+            return self.D == 4 + 2 * self.L + 2 * (self.N - 1) + 2 * (self.N - self.A)
         return name == 'simple_spread' and local and self.D == 4 + 2 * self.L
 
     def _layout(self, Struct):
         lay = Struct()
-        if Struct is _lib.PwStateWire:
-            check(_lib.load().pw_state_wire_layout(self.T, self.B, self.N, self.L, self.max_episode_len, C.byref(lay)))
+        if Struct is _lib.PwRefWire:
+            if (self.N, self.D) != (2, 21):
+                raise ValueError('simple_reference: N = 2, D = 21 expected')
+            check(_lib.load().pw_ref_wire_layout(self.T, self.B, self.max_episode_len, C.byref(lay)))
+        elif Struct is _lib.PwStateWire:
+            check(_lib.load().pw_state_wire_layout_scn(_lib.SCENARIOS[self.scenario], self.T, self.B, self.N, self.L, self.A,
+                                                       self.max_episode_len, C.byref(lay)))
         else:
             check(_lib.load().pw_chunk_wire_layout(self.T, self.B, self.N, self.D, self.max_episode_len, C.byref(lay)))
         return lay
@@ -336,6 +361,16 @@ class FullTransitionGather(object):
     def views(self, block):
         """Typed views of one wire block (a uint8 tensor of ``lay.total_bytes``)."""
         lay, T, B, N, D = self.lay, self.T, self.B, self.N, self.D
+        if self.ref_wire:
+            F = max(lay.F, 0)
+            return dict(head0=self._view(block, lay.head0, (B, N, 8), torch.float32),
+                        head=self._view(block, lay.head, (T, B, N, 8), torch.float32),
+                        final_head=self._view(block, lay.final_head, (F, B, N, 8), torch.float32),
+                        goal=self._view(block, lay.goal, (F + 1, B, N), torch.uint8),
+                        comm0=self._view(block, lay.comm0, (B, N), torch.uint8),
+                        rew_shared=self._view(block, lay.rew_shared, (T, B), torch.float32),
+                        act=self._view(block, lay.act, (T, B, N, 2), torch.uint8),
+                        epi=self._view(block, lay.epi, (T, B), torch.uint8))
         if self.state_wire:
             F, L = max(lay.F, 0), self.L
             return dict(state0=self._view(block, lay.state0, (B, N, 4), torch.float32),
@@ -363,7 +398,7 @@ class FullTransitionGather(object):
         v = self.views(self.wire[slot])
         if self.state_wire:
             self._begin(self.wire[slot])
-        out = dict(obs=self.side['obs'] if self.state_wire else v['obs'], rew_shared=v['rew_shared'],
+        out = dict(obs=self.side['obs'] if (self.state_wire or self.ref_wire) else v['obs'], rew_shared=v['rew_shared'],
                    terminal=self.side['terminal'], act=self.side['act'], rew=self.side['rew'], done=self.side['done'])
         if self.side['final_obs'] is not None:
             out['final_obs'] = self.side['final_obs']
@@ -381,6 +416,11 @@ class FullTransitionGather(object):
     # -- overridable pieces (the CPU gloo test substitutes torch stand-ins for the two HIP launches)
     def _make_memory(self):
         from .replay_buffer import ReplayBuffer
+        if self.ref_wire:
+            return ReplayBuffer(self.capacity, self.N, self.D, device=self.device, act_heads=(5, _lib.PW_DIM_C))
+        if self.ring_kind == 'state':   # the learner rank writes 32 N + 8 L bytes per transition instead of 8 N D; rows rebuilt when sampled
+            return ReplayBuffer(self.capacity, self.N, self.D, device=self.device,
+                                state_ring=dict(scenario=self.scenario, num_landmarks=self.L, num_adversaries=self.A))
         return ReplayBuffer(self.capacity, self.N, self.D, device=self.device)
 
     def _stream(self):
@@ -392,6 +432,11 @@ class FullTransitionGather(object):
 
     def _finalize(self, block, obs0):
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        if self.ref_wire:
+            assert obs0.is_contiguous() and obs0.dtype == torch.float32 and tuple(obs0.shape) == (self.B, self.N, self.D)
+            check(_lib.load().pw_ref_wire_finalize(C.byref(self.lay), p(block), p(obs0), p(self.side['obs']), p(self.side['final_obs']),
+                                                   p(self.side['terminal']), p(self.side['act']), self._stream()))
+            return
         if self.state_wire:   # obs0 is already in the block as state0 (pw_state_wire_begin)
             check(_lib.load().pw_state_wire_finalize(self.env._h, C.byref(self.lay), p(block), p(self.side['obs']),
                                                      p(self.side['final_obs']), p(self.side['terminal']), p(self.side['act']),
@@ -403,7 +448,8 @@ class FullTransitionGather(object):
 
     def _ingest(self, block):
         m = self.memory
-        add = _lib.load().pw_replay_add_state_wire if self.state_wire else _lib.load().pw_replay_add_wire
+        lib = _lib.load()
+        add = lib.pw_replay_add_ref_wire if self.ref_wire else lib.pw_replay_add_state_wire if self.state_wire else lib.pw_replay_add_wire
         check(add(C.byref(m._store), m._next_idx, C.byref(self.lay), C.c_void_p(block.data_ptr()), self._stream()))
         n = self.T * self.B
         m._next_idx = (m._next_idx + n) % m._maxsize
@@ -443,6 +489,8 @@ class FullTransitionGather(object):
                     w.wait()
             if self._finalized[slot] is not None:
                 side.wait_event(self._finalized[slot])
+            if self._reads_done is not None:     # the ring wraps: never overwrite rows an earlier optimize() is still sampling
+                side.wait_event(self._reads_done)
             for r in range(self.world):
                 self._ingest(self.wire[slot] if r == 0 else self.recv[slot][r])
                 self.rows_ingested += self.T * self.B
@@ -454,6 +502,16 @@ class FullTransitionGather(object):
         """Order the current stream behind every append issued so far (call before the learner samples the ring)."""
         if self._ingest_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._ingest_stream)
+
+    def mark_reads_done(self):
+        """The other direction of the same hand-off: call on the learner's stream right after its last read of the ring
+        (``sample_index``) of an iteration.  The side stream's NEXT appends wait for this point -- at 8 ranks x T B = 409 600
+        transitions per chunk a 1e6-slot ring wraps every other chunk, and an append that overtook a still-running
+        ``optimize()`` would tear the (obs, next_obs) pairs it samples.  (``train_batched`` calls both; a learner that
+        synchronises the host after every update -- ``float(loss)`` -- is ordered anyway.)"""
+        if self._ingest_stream is not None:
+            self._reads_done = torch.cuda.Event()
+            self._reads_done.record(torch.cuda.current_stream(self.device))
 
     def __call__(self, obs0):
         """After the chunk's rollout launch (same stream): condense, complete the PREVIOUS chunk's transfer and

@@ -242,6 +242,12 @@ class FusedActor(object):
             out = env.alloc_outputs(T, coll=False) if out is None else out
             if 'act' not in out:
                 out['act'] = torch.empty((T, B, N, 2) if two else (T, B, N), dtype=torch.int32, device=self.device)
+            # a caller-supplied action buffer of the single-head shape under a two-head actor would be overrun by the kernel
+            # (it writes act[2 row], act[2 row + 1]): refuse it here, whoever built the dict
+            want = (T, B, N, 2) if two else (T, B, N)
+            if tuple(out['act'].shape) != want or out['act'].dtype != torch.int32 or not out['act'].is_contiguous():
+                raise ValueError('rollout: out["act"] must be a contiguous int32 tensor of shape %r (%s actor), got %r %s'
+                                 % (want, 'two-head' if two else 'one-head', tuple(out['act'].shape), out['act'].dtype))
         io = PwStepIO()
         for name in ('obs', 'final_obs', 'rew', 'rew_shared', 'done', 'terminal'):
             t = out.get(name)

@@ -21,6 +21,13 @@ Ring variants (what ``add`` receives decides, or pass them to the constructor):
     per head (experiments/run.py:39-41); the ring keeps one index per head and ``sample_index`` returns the
     concatenated one-hot rows ``act[b, N, 15]`` the reference stored;
   * ``per_agent=True`` -- the BiCNet tuple (experiments/run_BIC.py:46,50): per-agent ``rew[b, N]`` / ``done[b, N]``.
+  * ``state_ring=dict(scenario='simple_spread' | 'simple_tag', num_landmarks=L, num_adversaries=A)`` -- a STATE ring
+    (``pw_replay_store.state_rows``): the planes ``obs`` / ``next_obs`` hold ``{vel, pos}`` of every agent ([cap, N, 4]) and ``lm``
+    the landmarks of the transition's episode ([cap, L, 2]) -- 32 N + 8 L bytes per transition instead of 8 N D (C2: 240 instead of
+    768) -- and ``sample_index`` REBUILDS the observation rows it returns (every entry is the state itself or one float32
+    subtraction: the batch is bit-identical to the row ring's).  It is the learner rank's ring of the multi-GPU gather
+    (``dist.FullTransitionGather(..., ring='state')`` fills it from state-only wire blocks); ``add`` / ``add_batch`` /
+    ``add_rollout`` raise on it -- a row cannot be turned back into the landmarks it was built from.
 The ring holds HARD one-hot actions as indices (what force_discrete_action / hard Gumbel-softmax produce); rows that
 are not one-hot per head, or whose lengths differ between agents, are rejected loudly instead of being squeezed
 through an argmax.  The object pickles (experiments/run.py:186-191 stores the memory in the test history): the
@@ -41,7 +48,7 @@ def _ptr(t):
 
 
 class ReplayBuffer(object):
-    def __init__(self, size, num_agents=None, obs_dim=None, device=None, act_heads=None, per_agent=None):
+    def __init__(self, size, num_agents=None, obs_dim=None, device=None, act_heads=None, per_agent=None, state_ring=None):
         """size: max number of transitions (``ReplayBuffer(size=1e+6)``, experiments/run.py:20).
         Storage is allocated on the first add (when N and D are known) unless given here.
         ``act_heads``: sizes of the action heads, ``(5,)`` (default) or ``(5, dim_c)``; ``per_agent``: per-agent
@@ -57,6 +64,17 @@ class ReplayBuffer(object):
         if self.act_heads is not None and (len(self.act_heads) not in (1, 2) or min(self.act_heads) < 1):
             raise ValueError('act_heads must be one or two positive head sizes, got %r' % (act_heads,))
         self.per_agent = None if per_agent is None else bool(per_agent)
+        self.state_ring = None
+        if state_ring is not None:
+            sr = dict(state_ring)
+            if sr.get('scenario') not in ('simple_spread', 'simple_tag'):
+                raise ValueError("state_ring: scenario must be 'simple_spread' (local observation) or 'simple_tag'")
+            if (self.act_heads or (5,)) != (5,) or self.per_agent:
+                raise ValueError('a STATE ring is a plain single-head, shared-reward ring')
+            if num_agents is None or obs_dim is None:
+                raise ValueError('a STATE ring needs num_agents and obs_dim at construction')
+            self.state_ring = dict(scenario=sr['scenario'], num_landmarks=int(sr['num_landmarks']),
+                                   num_adversaries=int(sr.get('num_adversaries', 0)))
         self.num_agents, self.obs_dim = num_agents, obs_dim
         if num_agents is not None and obs_dim is not None:
             self._allocate(num_agents, obs_dim)
@@ -75,8 +93,11 @@ class ReplayBuffer(object):
         if self.per_agent is None:
             self.per_agent = False
         H = len(self.act_heads)
-        self.obs = torch.empty(cap, N, D, dtype=torch.float32, device=dev)
-        self.next_obs = torch.empty(cap, N, D, dtype=torch.float32, device=dev)
+        sr = self.state_ring
+        Dp = 4 if sr else D                      # a STATE ring keeps {vx, vy, px, py} per agent; the rows are rebuilt when sampled
+        self.obs = torch.empty(cap, N, Dp, dtype=torch.float32, device=dev)
+        self.next_obs = torch.empty(cap, N, Dp, dtype=torch.float32, device=dev)
+        self.lm = torch.empty(cap, max(sr['num_landmarks'], 1), 2, dtype=torch.float32, device=dev) if sr else None
         self.act = torch.empty((cap, N) if H == 1 else (cap, N, H), dtype=torch.uint8, device=dev)
         self.rew = torch.empty((cap, N) if self.per_agent else (cap,), dtype=torch.float32, device=dev)
         self.done = torch.empty((cap, N) if self.per_agent else (cap,), dtype=torch.float32, device=dev)
@@ -87,6 +108,10 @@ class ReplayBuffer(object):
         st.capacity, st.num_agents, st.obs_dim = cap, N, D
         st.act_heads, st.per_agent = H, int(self.per_agent)
         st.head_width[0], st.head_width[1] = self.act_heads[0], (self.act_heads[1] if H == 2 else 0)
+        if sr:
+            st.state_rows, st.num_landmarks, st.num_adversaries = 1, sr['num_landmarks'], sr['num_adversaries']
+            st.scenario = _lib.SCENARIOS[sr['scenario']]
+            st.lm = self.lm.data_ptr()
         self._store = st
         # device copies of _next_idx (hipGraph mode): cell [0] for add_batch(device_cursor=True); add_batch_tail
         # ping-pongs between [0] and [1] (it reads one cell in every workgroup and writes the other)
@@ -94,6 +119,11 @@ class ReplayBuffer(object):
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+    def _rows_only(self, who):
+        if self.state_ring is not None:
+            raise _lib.PworldError('ReplayBuffer.%s: a STATE ring is filled from state-only wire blocks (dist.FullTransitionGather, '
+                                   'pw_replay_add_state_wire) -- observation rows do not determine the landmarks they were built from' % who)
 
     def __len__(self):
         return self._len
@@ -107,14 +137,15 @@ class ReplayBuffer(object):
         host = self._host_state
         if self._store is not None:
             sl = slice(0, self._len)  # add() fills slots [0, len) before it ever wraps
-            host = {k: getattr(self, k)[sl].cpu().numpy() for k in ('obs', 'next_obs', 'act', 'rew', 'done')}
+            host = {k: getattr(self, k)[sl].cpu().numpy() for k in ('obs', 'next_obs', 'act', 'rew', 'done') + (('lm',) if self.state_ring else ())}
         return dict(maxsize=self._maxsize, next_idx=self._next_idx, len=self._len, num_agents=self.num_agents,
-                    obs_dim=self.obs_dim, act_heads=self.act_heads, per_agent=self.per_agent, planes=host)
+                    obs_dim=self.obs_dim, act_heads=self.act_heads, per_agent=self.per_agent, planes=host, state_ring=self.state_ring)
 
     def __setstate__(self, st):
         self.__init__(st['maxsize'], act_heads=st['act_heads'], per_agent=st['per_agent'])
         self._next_idx, self._len = st['next_idx'], st['len']
         self.num_agents, self.obs_dim = st['num_agents'], st['obs_dim']
+        self.state_ring = st.get('state_ring')
         self._host_state = st['planes']   # uploaded by _ensure_device() on first use (unpickling needs no GPU)
 
     def _ensure_device(self):
@@ -196,6 +227,7 @@ class ReplayBuffer(object):
         (``advance_cursor=False``: the caller advances ``_cursor`` itself, e.g. in pw_rollout_tail)."""
         B, N, D = obs.shape
         self._ensure_device()
+        self._rows_only('add / add_batch')
         if self._store is None:
             self._device = obs.device if obs.is_cuda and self._device is None else self._device
             if self.act_heads is None and act_idx.dim() == 3:
@@ -234,6 +266,7 @@ class ReplayBuffer(object):
         adds with ``note_graph_adds``.  All tensors must already be float32 / int32 / uint8 device tensors."""
         B, N, D = obs.shape
         self._ensure_device()
+        self._rows_only('add_batch_tail')
         if self._store is None:
             self._device = obs.device if self._device is None else self._device
             self._allocate(N, D)
@@ -262,6 +295,7 @@ class ReplayBuffer(object):
         from ._lib import PwStepIO
         T, B, N, D = out['obs'].shape
         self._ensure_device()
+        self._rows_only('add_rollout')
         if self._store is None:
             self._device = obs0.device if self._device is None else self._device
             self._allocate(N, D)

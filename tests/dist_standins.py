@@ -7,6 +7,30 @@ import torch
 from multiagent_rl_amd.dist import FullTransitionGather, SampledTransitionGather
 
 
+class HostStateRing(object):
+    """The learner rank's STATE ring on the host: per transition {vel, pos} before / after + the episode's landmarks; ``sample_index``
+    rebuilds the rows (``pw_replay_gather`` on a state ring)."""
+
+    def __init__(self, scenario='simple_spread', num_adversaries=0):
+        self.scenario, self.A, self.transitions = scenario, num_adversaries, []
+
+    def __len__(self):
+        return sum(t['rew'].shape[0] for t in self.transitions)
+
+    def clear(self):
+        self.transitions = []
+
+    def append(self, tr):
+        self.transitions.append({k: tr[k] for k in ('state', 'next_state', 'lm', 'act', 'rew', 'done')})
+
+    def sample_index(self, idx):
+        cat = {k: torch.cat([t[k] for t in self.transitions]) for k in ('state', 'next_state', 'lm', 'act', 'rew', 'done')}
+        i = torch.as_tensor(idx, dtype=torch.long)
+        return (rows_from_state(cat['state'][i], cat['lm'][i], self.scenario, self.A),
+                torch.nn.functional.one_hot(cat['act'][i].long(), 5).float(), cat['rew'][i],
+                rows_from_state(cat['next_state'][i], cat['lm'][i], self.scenario, self.A), cat['done'][i])
+
+
 class HostRing(object):
     """Tuple ring in the reference's order (rls/replay_buffer.py:30-37), unbounded: what the root ingested."""
 
@@ -74,12 +98,31 @@ def wire_transitions_reference(g, block):
 
 
 # ---- state-only wire blocks (include/pworld.h pw_state_wire): simple_spread, local observation --------------------------
-def rows_from_state(state, lm):
-    """The local observation rows (experiments/scenarios.py:6-20) of agents with ``state`` [..., N, 4] = {vx, vy, px, py}
-    among landmarks ``lm`` [..., L, 2]: [vel, pos, lm_0 - pos, lm_1 - pos, ...], float32, one subtraction per entry."""
+def rows_from_state(state, lm, scenario='simple_spread', num_adversaries=0):
+    """The observation rows of agents with ``state`` [..., N, 4] = {vx, vy, px, py} among landmarks ``lm`` [..., L, 2], float32, one
+    subtraction per entry.  simple_spread, local observation (experiments/scenarios.py:6-20): [vel, pos, lm_0 - pos, lm_1 - pos, ...].
+    simple_tag (upstream simple_tag.observation): the same, then [pos_j - pos for j != a], then [vel_j for the GOOD agents j != a],
+    zero-padded to the adversaries' width 4 + 2L + 2(N - 1) + 2(N - A)."""
     pos = state[..., 2:4]
     rel = lm[..., None, :, :] - pos[..., :, None, :]                      # [..., N, L, 2]
-    return torch.cat([state, rel.reshape(*rel.shape[:-2], -1)], dim=-1)
+    rows = torch.cat([state, rel.reshape(*rel.shape[:-2], -1)], dim=-1)
+    if scenario == 'simple_spread':
+        return rows
+    N, A = state.shape[-2], num_adversaries
+    D = rows.shape[-1] + 2 * (N - 1) + 2 * (N - A)
+    out = torch.zeros(*state.shape[:-1], D, dtype=state.dtype)
+    out[..., :rows.shape[-1]] = rows
+    for a in range(N):
+        k = rows.shape[-1]
+        for j in range(N):
+            if j != a:
+                out[..., a, k:k + 2] = pos[..., j, :] - pos[..., a, :]
+                k += 2
+        for j in range(A, N):
+            if j != a:
+                out[..., a, k:k + 2] = state[..., j, 0:2]
+                k += 2
+    return out
 
 
 def state_wire_begin_reference(g, block, state0, lm0, ep0):
@@ -124,8 +167,12 @@ def state_wire_transitions_reference(g, block):
     t, e = torch.nonzero(ended, as_tuple=True)
     if t.numel():
         s_next[t, e] = v['final_state'][k[t, e], e]
-    return dict(obs=rows_from_state(s_obs, lm).reshape(T * B, N, D), next_obs=rows_from_state(s_next, lm).reshape(T * B, N, D),
-                act=v['act'].reshape(T * B, N).clone(), rew=v['rew_shared'].reshape(T * B).clone(), done=torch.zeros(T * B))
+    scen, A = getattr(g, 'scenario', 'simple_spread'), getattr(g, 'A', 0)
+    return dict(obs=rows_from_state(s_obs, lm, scen, A).reshape(T * B, N, D), next_obs=rows_from_state(s_next, lm, scen, A).reshape(T * B, N, D),
+                act=v['act'].reshape(T * B, N).clone(), rew=v['rew_shared'].reshape(T * B).clone(), done=torch.zeros(T * B),
+                # what a STATE ring keeps of the same transitions (pw_replay_add_state_wire into pw_replay_store.state_rows)
+                state=s_obs.reshape(T * B, N, 4).clone(), next_state=s_next.reshape(T * B, N, 4).clone(),
+                lm=lm.reshape(T * B, lm.shape[-2], 2).clone())
 
 
 class CpuFullGather(FullTransitionGather):
@@ -134,6 +181,8 @@ class CpuFullGather(FullTransitionGather):
         return super()._layout(PwChunkWire)
 
     def _make_memory(self):
+        if getattr(self, 'ring_kind', 'rows') == 'state':
+            return HostStateRing(self.scenario, self.A)
         return HostRing()
 
     def _begin(self, block):
@@ -146,5 +195,8 @@ class CpuFullGather(FullTransitionGather):
             wire_finalize_reference(self, block, obs0)
 
     def _ingest(self, block):
-        self.memory.transitions.append(state_wire_transitions_reference(self, block) if self.state_wire
-                                       else wire_transitions_reference(self, block))
+        tr = state_wire_transitions_reference(self, block) if self.state_wire else wire_transitions_reference(self, block)
+        if isinstance(self.memory, HostStateRing):
+            self.memory.append(tr)
+        else:
+            self.memory.transitions.append(tr)

@@ -65,6 +65,9 @@ def spread_chunk(rank, k, step0):
     state = torch.randn(T, B, N, 4, generator=g)
     final_state = torch.randn(T, B, N, 4, generator=g)
     out = dict(rew_shared=torch.randn(T, B, generator=g), act=torch.randint(0, 5, (T, B, N), generator=g, dtype=torch.int32))
+    gr = torch.Generator()
+    gr.manual_seed(777 + 1000 * rank + k)                               # (a generator of its own: the draws above keep their values)
+    out['rew'] = torch.randn(T, B, N, generator=gr)                     # per-agent rewards (the ledger's input)
     t = torch.arange(T)[:, None] + step0
     e = torch.arange(B)[None, :].expand(T, B)
     out['terminal'] = ((t + e) % EP) == EP - 1

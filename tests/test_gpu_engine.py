@@ -804,6 +804,190 @@ def test_state_wire_ring_equals_add_rollout_bitwise(B, N, L, T, ep):
         assert torch.equal(x, y), name
 
 
+def _gather_three_chunks(env, T, ep, rings, policy=None):
+    """Three chunks of `env` through one FullTransitionGather per entry of `rings` (ring kind -> gather), all fed from the SAME
+    rollout outputs (the first gather's wire block is the one the rollout writes into; the others ingest copies of it), plus the
+    reference ring filled by pw_replay_add_rollout from the dense outputs.  -> (gathers, want)."""
+    from multiagent_rl_amd.dist import FullTransitionGather
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    B, N, D = env.num_envs, env.n, env.obs_dim
+    dev = torch.device('cuda', 0)
+    cap = T * B * 3 + 17
+    gs = {}
+    for kind in rings:
+        g = FullTransitionGather(env, T, 0, 1, dev, capacity=cap, ring=kind, overlap_ingest=False)
+        assert g.state_wire
+        g.memory._next_idx = g.memory._len = cap - 5          # the first chunk wraps around the ring end
+        gs[kind] = g
+    want = ReplayBuffer(cap, N, D)
+    want._next_idx = want._len = cap - 5
+    lead = gs[rings[0]]
+    obs0 = env.reset()
+    if ep > 1:                                                # desynchronise the episode clocks
+        st = env.get_state()
+        env.set_state(st['pos'], st['vel'], st['landmarks'], ep_step=(torch.arange(B, device='cuda') % ep).int(), ep_count=st['ep_count'])
+    for k in range(3):
+        acts = torch.randint(0, 5, (T, B, N), device='cuda', dtype=torch.int32)
+        out = lead.outputs()
+        out['act'].copy_(acts)
+        env.rollout(acts, out={n_: v for n_, v in out.items() if n_ != 'act'})
+        dense = {n_: v.clone() for n_, v in out.items()}
+        slot = lead.exchanges % lead.SLOTS
+        lead(obs0)
+        for kind in rings[1:]:                                # the same finished block, appended by the other ring kind
+            g = gs[kind]
+            g.wire[slot].copy_(lead.wire[slot])
+            g._pending = ([], slot)
+            g._complete()
+        want.add_rollout(obs0, dense)
+        obs0 = dense['obs'][T - 1]
+    lead.finish()
+    torch.cuda.synchronize()
+    return gs, want
+
+
+@pytest.mark.parametrize('N,L,B,T,ep', [(3, None, 300, 31, 25), (6, None, 512, 60, 25), (12, None, 33, 27, 25), (6, 5, 90, 30, 11),
+                                        (3, 1, 64, 9, 1), (5, None, 50, 12, 0), (6, 9, 40, 26, 7)])
+def test_state_ring_sample_index_equals_the_row_ring_bitwise(N, L, B, T, ep):
+    """The learner rank's STATE ring (pw_replay_store.state_rows: {vel, pos} of every agent before / after + the episode's landmarks per
+    transition, 32 N + 8 L bytes instead of 8 N D): filled from the same state-only wire blocks as the row ring, over three chunks with
+    desynchronised episode clocks (>= two resets per env) and a wrap of the ring end; sample_index on it -- rows REBUILT by
+    pw_replay_gather -- equals the row ring's batch bit for bit (obs, one-hot actions, reward, the pre-reset next_obs, done), and the
+    row ring equals pw_replay_add_rollout on the sender's dense outputs.  Odd L, L != N, L > N, ep = 0 / 1 included."""
+    from multiagent_rl_amd import make_batched_env
+    kw = {} if L is None else dict(num_landmarks=L)
+    env = make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=ep, seed=5, **kw)
+    gs, want = _gather_three_chunks(env, T, ep, ['state', 'rows'])
+    st, rows = gs['state'].memory, gs['rows'].memory
+    assert st.state_ring and tuple(st.obs.shape[1:]) == (N, 4) and tuple(st.lm.shape[1:]) == (max(env.num_landmarks, 1), 2)
+    assert len(st) == len(rows) == len(want) and st._next_idx == rows._next_idx == want._next_idx
+    cap = want._maxsize
+    written = [(cap - 5 + i) % cap for i in range(3 * T * B)]
+    for lo in range(0, len(written), 4096):
+        idx = written[lo:lo + 4096]
+        a, b, c = st.sample_index(idx), rows.sample_index(idx), want.sample_index(idx)
+        for name, x, y, z in zip(('obs', 'act', 'rew', 'next_obs', 'done'), a, b, c):
+            assert torch.equal(x, y), name
+            assert torch.equal(y, z), name
+    # bytes the root writes per transition
+    per_state = sum(t.element_size() * t[0].numel() for t in (st.obs, st.next_obs, st.lm, st.act, st.rew, st.done))
+    per_rows = sum(t.element_size() * t[0].numel() for t in (rows.obs, rows.next_obs, rows.act, rows.rew, rows.done))
+    assert per_state == 32 * N + 8 * max(env.num_landmarks, 1) + N + 8 and per_rows == 8 * N * env.obs_dim + N + 8
+    # a state ring refuses rows
+    with pytest.raises(Exception, match='STATE ring'):
+        st.add_batch(torch.zeros(1, N, env.obs_dim, device='cuda'), torch.zeros(1, N, dtype=torch.int32, device='cuda'),
+                     torch.zeros(1, device='cuda'), torch.zeros(1, N, env.obs_dim, device='cuda'))
+
+
+@pytest.mark.parametrize('A,G,L,B,T,ep', [(4, 2, 2, 8192, 50, 25), (3, 1, 2, 77, 26, 7), (2, 3, 3, 60, 30, 11), (1, 1, 1, 40, 9, 1),
+                                          (4, 2, 2, 50, 12, 0)])
+def test_tag_state_wire_ring_equals_add_rollout_bitwise(A, G, L, B, T, ep):
+    """simple_tag on STATE-ONLY wire blocks (0.1.6): 16 B per agent and step, the landmarks (drawn from U(-0.9, 0.9)) once per episode,
+    the pre-reset state at episode ends; the root rebuilds the 4 + 2L + 2(N - 1) + 2G-number rows (other agents' relative positions, the
+    good agents' velocities, zero padding for the good agents' own rows) -- the row ring equals pw_replay_add_rollout on the sender's
+    dense outputs BIT FOR BIT, and so does the batch a STATE ring rebuilds.  C3's 4 + 2 roster at full size: <= 150 B per env-step."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.dist import FullTransitionGather
+    env = make_batched_env('simple_tag', B, num_adversaries=A, num_good=G, num_landmarks=L, auto_reset=True, max_episode_len=ep, seed=9)
+    N = A + G
+    assert env.obs_dim == 4 + 2 * L + 2 * (N - 1) + 2 * G
+    gs, want = _gather_three_chunks(env, T, ep, ['rows', 'state'])
+    rows, st = gs['rows'].memory, gs['state'].memory
+    for name in ('obs', 'next_obs', 'act', 'rew', 'done'):
+        cap = want._maxsize
+        sl = torch.tensor([(cap - 5 + i) % cap for i in range(3 * T * B)], device='cuda')
+        assert torch.equal(getattr(rows, name)[sl], getattr(want, name)[sl]), name
+    written = [(want._maxsize - 5 + i) % want._maxsize for i in range(3 * T * B)]
+    for lo in range(0, len(written), 8192):
+        idx = written[lo:lo + 8192]
+        for name, x, y in zip(('obs', 'act', 'rew', 'next_obs', 'done'), st.sample_index(idx), want.sample_index(idx)):
+            assert torch.equal(x, y), name
+    per_step = gs['rows'].bytes_per_env_step
+    row_block = FullTransitionGather(env, T, 0, 1, torch.device('cuda', 0), wire='rows').bytes_per_env_step
+    assert per_step < 0.45 * row_block
+    if (A, G, B) == (4, 2, 8192):
+        assert per_step <= 150.0, per_step                   # VERDICT r4: <= 150 B per env-step for tag 4 + 2 (from ~565)
+
+
+@pytest.mark.parametrize('B,T,ep', [(4096, 100, 25), (77, 26, 7), (40, 9, 1), (50, 12, 0)])
+def test_reference_compact_wire_ring_equals_add_rollout_bitwise(B, T, ep):
+    """simple_reference (MultiDiscrete, main.py:24,52-54) through the full gather on COMPACT-ROW wire blocks (pw_ref_wire, 0.1.6): the
+    first eight numbers of every 21-number row, one goal byte per agent and episode, both action heads as bytes; the root rebuilds
+    goal colours and the other agent's one-hot symbol (zeros after a reset) -- the two-head ring equals pw_replay_add_rollout on the
+    sender's dense outputs BIT FOR BIT over three chunks with desynchronised episode clocks and a ring wrap.  <= 80 B per env-step."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.dist import FullTransitionGather
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    torch.manual_seed(4)
+    env = make_batched_env('simple_reference', B, auto_reset=True, max_episode_len=ep, seed=21)
+    N, D = env.n, env.obs_dim
+    assert (N, D) == (2, 21)
+    cap = 3 * T * B + 17
+    full = FullTransitionGather(env, T, 0, 1, torch.device('cuda', 0), capacity=cap)
+    assert full.ref_wire and not full.state_wire and full.memory.act_heads == (5, 10)
+    want = ReplayBuffer(cap, N, D, act_heads=(5, 10))
+    full.memory._next_idx = full.memory._len = want._next_idx = want._len = cap - 5
+    obs0 = env.reset()
+    if ep > 1:
+        st = env.get_state()
+        env.set_state(st['pos'], st['vel'], st['landmarks'], ep_step=(torch.arange(B, device='cuda') % ep).int(), ep_count=st['ep_count'])
+    for k in range(3):
+        acts = torch.stack([torch.randint(0, 5, (T, B, N), device='cuda'), torch.randint(0, 10, (T, B, N), device='cuda')], -1).int()
+        out = full.outputs()
+        out['act'].copy_(acts)
+        env.rollout(acts, out={n_: v for n_, v in out.items() if n_ != 'act'})
+        dense = {n_: v.clone() for n_, v in out.items()}
+        full(obs0)
+        want.add_rollout(obs0, dense)
+        obs0 = dense['obs'][T - 1].clone()
+    full.finish()
+    torch.cuda.synchronize()
+    assert full.rows_ingested == 3 * T * B and full.memory._next_idx == want._next_idx
+    sl = torch.tensor([(cap - 5 + i) % cap for i in range(3 * T * B)], device='cuda')
+    for name in ('obs', 'next_obs', 'act', 'rew', 'done'):
+        assert torch.equal(getattr(full.memory, name)[sl], getattr(want, name)[sl]), name
+    if T == 100:
+        assert full.bytes_per_env_step <= 80.0, full.bytes_per_env_step     # VERDICT r4: <= 80 B per env-step (the row block: 181)
+    with pytest.raises(ValueError, match='two-head'):
+        FullTransitionGather(env, T, 0, 1, torch.device('cuda', 0), wire='rows')
+
+
+def test_reference_compact_wire_carries_the_two_head_policy_rollout():
+    """The two-head actor in the loop (pw_policy_rollout on simple_reference, act [T,B,N,2]) writing into the gather's outputs: the root's
+    two-head ring equals the ring the same rollout's own sink fills, bit for bit (B = 4096, 100-step chunks)."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.dist import FullTransitionGather
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    torch.manual_seed(0)
+    B, T = 4096, 100
+    mk = lambda: make_batched_env('simple_reference', B, auto_reset=True, max_episode_len=25, seed=3)  # noqa: E731
+    env_a, env_b = mk(), mk()
+    actor = ActorNetwork(env_a.obs_dim, [5, 10]).cuda().eval()
+    wire_actor, sink_actor = FusedActor(actor, seed=7), FusedActor(actor, seed=7)
+    full = FullTransitionGather(env_a, T, 0, 1, torch.device('cuda', 0), capacity=2 * T * B)
+    want = ReplayBuffer(2 * T * B, 2, env_b.obs_dim, act_heads=(5, 10))
+    env_a.reset()
+    env_b.reset()
+    obs0 = env_a.observe()
+    for k in range(2):
+        out = full.outputs()
+        assert tuple(out['act'].shape) == (T, B, 2, 2)
+        wire_actor.rollout(env_a, T, out)
+        full(obs0)
+        obs0 = out['obs'][T - 1].clone()
+        sink_actor.rollout(env_b, T, False, memory=want)
+    full.finish()
+    torch.cuda.synchronize()
+    assert full.rows_ingested == 2 * T * B == len(full.memory) == len(want)
+    for name in ('obs', 'next_obs', 'act', 'rew', 'done'):
+        assert torch.equal(getattr(full.memory, name), getattr(want, name)), name
+    # a single-head action buffer under the two-head actor is refused, not overrun (ADVICE r4)
+    bad = dict(out, act=torch.zeros(T, B, 2, dtype=torch.int32, device='cuda'))
+    with pytest.raises(ValueError, match='two-head'):
+        wire_actor.rollout(env_a, T, bad)
+
+
 def test_state_wire_carries_the_policy_rollout_and_stays_under_130_bytes_per_env_step():
     """C2 (B = 4096, N = 6, 100-step chunks) with the policy in the loop, as bench.py --gpus N drives it: FusedActor.rollout
     writes into FullTransitionGather.outputs(); the root ring equals the ring the same launch's own sink fills
@@ -886,7 +1070,13 @@ def test_state_wire_functions_reject_foreign_layouts_and_scenarios():
     assert lib.pw_state_wire_begin(other._h, C.byref(lay), p(block), None) < 0 and b'shape mismatch' in lib.pw_last_error()
     tag = make_batched_env('simple_tag', 8, num_adversaries=3, num_good=1, auto_reset=True, seed=1)
     tag.reset()
-    assert lib.pw_state_wire_begin(tag._h, C.byref(lay), p(block), None) < 0 and b'simple_spread' in lib.pw_last_error()
+    assert lib.pw_state_wire_begin(tag._h, C.byref(lay), p(block), None) < 0 and b'shape mismatch' in lib.pw_last_error()   # a simple_spread block
+    tlay = _lib.PwStateWire()
+    assert lib.pw_state_wire_layout_scn(_lib.PW_SIMPLE_TAG, 10, 8, 4, 2, 3, 25, C.byref(tlay)) == 0 and tlay.D == 4 + 4 + 6 + 2
+    tblock = torch.zeros(tlay.total_bytes, dtype=torch.uint8, device='cuda')
+    assert lib.pw_state_wire_begin(tag._h, C.byref(tlay), p(tblock), None) == 0                 # simple_tag is served since 0.1.6
+    assert lib.pw_state_wire_begin(env._h, C.byref(tlay), p(tblock), None) < 0
+    assert lib.pw_state_wire_layout_scn(_lib.PW_SIMPLE_REFERENCE, 10, 8, 2, 3, 0, 25, C.byref(tlay)) < 0
     full_obs = make_batched_env('simple_spread', 8, n=3, local_observation=False, auto_reset=True, seed=1)
     full_obs.reset()
     assert lib.pw_state_wire_begin(full_obs._h, C.byref(lay), p(block), None) < 0
@@ -895,9 +1085,15 @@ def test_state_wire_functions_reject_foreign_layouts_and_scenarios():
     # the host side picks the block kind by the same rule
     dev = torch.device('cuda', 0)
     assert FullTransitionGather(env, 10, 0, 1, dev).state_wire
-    assert not FullTransitionGather(tag, 10, 0, 1, dev).state_wire and not FullTransitionGather(full_obs, 10, 0, 1, dev).state_wire
+    assert FullTransitionGather(tag, 10, 0, 1, dev).state_wire and not FullTransitionGather(full_obs, 10, 0, 1, dev).state_wire
     with pytest.raises(ValueError, match='state-only'):
-        FullTransitionGather(tag, 10, 0, 1, dev, wire='state')
+        FullTransitionGather(full_obs, 10, 0, 1, dev, wire='state')
+    with pytest.raises(ValueError, match="ring='state'"):
+        FullTransitionGather(full_obs, 10, 0, 1, dev, ring='state')
+    ref = make_batched_env('simple_reference', 8, auto_reset=True, seed=1)
+    assert FullTransitionGather(ref, 10, 0, 1, dev).ref_wire
+    with pytest.raises(ValueError, match='two-head'):
+        FullTransitionGather(ref, 10, 0, 1, dev, wire='rows')
     with pytest.raises(ValueError, match='auto-resetting'):
         FullTransitionGather(make_batched_env('simple_spread', 8, n=3, auto_reset=False, seed=1), 10, 0, 1, dev)
 

@@ -47,7 +47,7 @@ class _Fused(object):
 
     def rollout(self, env, chunk, out, stats=None):
         src = spread_chunk(self.rank, self.k, self.k * T)
-        for name in ('obs', 'rew_shared', 'terminal', 'act', 'final_obs'):
+        for name in ('obs', 'rew_shared', 'terminal', 'act', 'final_obs', 'rew'):
             out[name].copy_(src[name])
         stats[2].add_(int(src['terminal'].sum()))                       # finished episodes of this rank
         self.k += 1
@@ -72,26 +72,33 @@ class _Rollout(object):
         return dict(env_steps=self.env_steps, episodes=n, mean_episode_reward=0.0)
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _run(data_rank, rank, world):
+    """train_batched on the shard of `data_rank` as rank `rank` of `world` (world = 1: no process group is touched)."""
     from multiagent_rl_amd.policy import ActorNetwork
     from multiagent_rl_amd.train import train_batched
     from tests.dist_standins import CpuFullGather
-    env = _SpreadEnv(rank)
+    env = _SpreadEnv(data_rank)
     env.observation_space, env.action_space = [_Space()] * N, [_Space()] * N
-    torch.manual_seed(100 + rank)                                       # the ranks start from DIFFERENT weights
+    torch.manual_seed(100 + data_rank)                                  # the ranks start from DIFFERENT weights
     actor = ActorNetwork(10, 5)
     gather = CpuFullGather(env, T, rank, world, 'cpu')
-    fused = _Fused(env, rank)
+    fused = _Fused(env, data_rank)
     hist = train_batched(env, actor, None, _Trainer, 'simple_spread', 'Discrete', cnt=0, arglist=_Cfg(), out_dir=None,
                          log=lambda *a: None, chunk=T, gather=gather, rank=rank, world=world,
                          make_rollout=lambda e, a, m, s: (fused, _Rollout(e)))
+    return hist, actor, gather, fused
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    hist, actor, gather, fused = _run(rank, rank, world)
     tr = _Trainer.last
     q.put(dict(rank=rank, chunks=fused.k, optimize=tr.calls, refreshed=fused.refreshed, saved=tr.saved,
                bias=actor.dense2.module.bias.detach().clone().numpy(), w1=actor.dense1.module.weight.detach().clone().numpy(),
                ring=None if rank else sum(t['rew'].shape[0] for t in gather.memory.transitions),
-               stats=hist['stats'], memory_is_ring=tr.memory is gather.memory))
+               stats=hist['stats'], memory_is_ring=tr.memory is gather.memory,
+               hist={k: hist[k] for k in hist if k != 'stats'}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -129,3 +136,15 @@ def test_train_batched_over_two_ranks():
     assert (r0['w1'] == want.dense1.module.weight.detach().numpy()).all()
     assert abs(float(r0['bias'][0]) - (float(want.dense2.module.bias[0].detach()) + updates)) < 1e-4
     assert r0['refreshed'] == r1['refreshed'] == chunks                 # broadcast_actor(..., fused=...) refreshes the snapshot
+    # the history the learner rank pickles (run.py:96-100): every rank's episodes, concatenated in rank order = the two
+    # single-rank runs of the same shards one after the other (episode ends are NOT in lockstep across envs here)
+    solo = [_run(r, 0, 1)[0] for r in range(2)]
+    h = r0['hist']
+    assert h['episodes_per_rank'] == [len(x['reward_episodes']) for x in solo] and h['open_episodes'] == [B, B]
+    assert h['reward_episodes'] == solo[0]['reward_episodes'] + solo[1]['reward_episodes']
+    assert len(h['reward_episodes']) >= 2 * (40 + B)
+    for i in range(N):
+        assert h['reward_episodes_by_agents'][i] == solo[0]['reward_episodes_by_agents'][i] + solo[1]['reward_episodes_by_agents'][i]
+    # a rank that does not learn keeps its own shard's history (nothing is lost if the root's pickle is)
+    assert r1['hist']['reward_episodes'] == solo[1]['reward_episodes']
+    assert r0['stats']['updates_owed'] == 4 * chunks and r0['stats']['updates_run'] == updates

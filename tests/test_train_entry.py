@@ -113,23 +113,25 @@ def test_chunk_ledger_splits_a_chunk_into_episode_returns():
     led = ChunkLedger(B, N, 'cpu')
     led.absorb(rew[:T], term[:T])
     led.absorb(rew[T:], term[T:])
-    want = []
-    for half in (slice(0, T), slice(T, 2 * T)):           # (chunk, episode index inside the chunk, env) order
-        per_env = []
+    # what experiments/run.py:55-65 appends when it steps the B worlds side by side: at every step, for every env in order, a
+    # finished episode's per-agent sums -- (END STEP, env) order, whatever the chunking
+    want, run = [], np.zeros((B, N))
+    for t in range(2 * T):
         for e in range(B):
-            ends = [t for t in range(half.start, half.stop) if term[t, e]]
-            per_env.append(ends)
-        for k in range(max(len(x) for x in per_env)):
-            for e in range(B):
-                if k < len(per_env[e]):
-                    t1 = per_env[e][k]
-                    prev = [t for t in range(0, t1) if term[t, e]]
-                    t0 = prev[-1] + 1 if prev else 0
-                    want.append(rew[t0:t1 + 1, e].double().sum(0).numpy())
+            run[e] += rew[t, e].double().numpy()
+            if term[t, e]:
+                want.append(run[e].copy())
+                run[e] = 0.0
     got = np.stack([np.array(a) for a in led.by_agent], 1)
     np.testing.assert_allclose(got, np.stack(want), rtol=0, atol=1e-9)
     np.testing.assert_allclose(led.totals, np.stack(want).sum(1), rtol=0, atol=1e-9)
-    assert sorted(led.history().keys()) == ['reward_episodes', 'reward_episodes_by_agents']
+    h = led.history()
+    assert sorted(h.keys()) == ['open_episodes', 'reward_episodes', 'reward_episodes_by_agents'] and h['open_episodes'] == B
+    # behind the finished episodes: the episode in progress of every env (run.py:62-65 leaves ONE such trailing entry at B = 1)
+    assert len(h['reward_episodes']) == len(want) + B and len(h['reward_episodes_by_agents'][0]) == len(want) + B
+    np.testing.assert_allclose(h['reward_episodes'][-B:], run.sum(1), rtol=0, atol=1e-9)
+    assert len(led.history(include_open=False)['reward_episodes']) == len(want)
+    assert abs(led.mean_of_last(3) - np.mean(np.stack(want).sum(1)[-3:])) < 1e-9
 
 
 def test_train_batched_orders_collect_learn_refresh_and_writes_the_history(tmp_path):
@@ -158,17 +160,30 @@ def test_train_batched_orders_collect_learn_refresh_and_writes_the_history(tmp_p
     assert trace[1:-1] == want
     assert kinds.count('optimize') == g.due_between(0, 1600) == 6      # at 1100, 1200, ..., 1600 env-steps
     assert hist['stats']['env_steps'] == 1600 and hist['stats']['updates'] == 6 and hist['stats']['episodes'] == 64
-    assert len(hist['reward_episodes']) == 64 and all(abs(x + 75.0) < 1e-9 for x in hist['reward_episodes'])
-    assert len(hist['reward_episodes_by_agents']) == 3 and len(hist['reward_episodes_by_agents'][0]) == 64
+    assert hist['stats']['updates_owed'] == hist['stats']['updates_run'] == 6 and hist['stats']['updates_skipped'] == 0
+    # 64 finished episodes + the 16 envs' episodes in progress (just reset: 0), as run.py:62-65 leaves its trailing entry
+    assert hist['open_episodes'] == 16 and len(hist['reward_episodes']) == 64 + 16
+    assert all(abs(x + 75.0) < 1e-9 for x in hist['reward_episodes'][:64]) and all(x == 0 for x in hist['reward_episodes'][64:])
+    assert len(hist['reward_episodes_by_agents']) == 3 and len(hist['reward_episodes_by_agents'][0]) == 64 + 16
     saved = pickle.load(open(tmp_path / 'history_simple_spread_3.pkl', 'rb'))
     assert saved['reward_episodes'] == hist['reward_episodes']
     assert any('mean episode reward' in str(a[0]) for a in logs)          # the report line at save_rate episodes
     # a cap on the updates owed per chunk
     trace.clear()
-    train_batched(env, 'actor', 'critic', _StubTrainer, 'simple_spread', 'Discrete', arglist=cfg, memory=_StubMemory(),
-                  out_dir=None, log=lambda *a: None, chunk=50, max_updates_per_chunk=2,
-                  make_rollout=lambda e, actor, memory, seed: (_StubFused(trace), _StubRollout(e, memory, trace)))
+    logs.clear()
+    capped = train_batched(env, 'actor', 'critic', _StubTrainer, 'simple_spread', 'Discrete', arglist=cfg, memory=_StubMemory(),
+                           out_dir=None, log=lambda *a: logs.append(a), chunk=50, max_updates_per_chunk=2,
+                           make_rollout=lambda e, actor, memory, seed: (_StubFused(trace), _StubRollout(e, memory, trace)))
     assert [e[0] for e in trace].count('optimize') == 2      # chunk 1: 800 env-steps (warm-up), chunk 2: 6 owed, 2 run
+    st = capped['stats']                                       # ... and the run says so instead of dropping them silently
+    assert (st['updates_owed'], st['updates_run'], st['updates_skipped']) == (6, 2, 4)
+    assert any('2 of 6 owed updates' in str(a[0]) for a in logs)
+    # MultiDiscrete runs keep the per-episode history too (run.py:96-100 pickles it whatever the action type)
+    trace.clear()
+    md = train_batched(env, 'actor', 'critic', _StubTrainer, 'simple_reference', 'MultiDiscrete', arglist=cfg, memory=_StubMemory(),
+                       out_dir=None, log=lambda *a: None, chunk=10,
+                       make_rollout=lambda e, actor, memory, seed: (_StubFused(trace), _StubRollout(e, memory, trace)))
+    assert len(md['reward_episodes']) == 64 + 16 and trace[1] == ('collect', 10, True)
     assert dims_from_env(env) == (10, 5, 'Discrete')
 
 
@@ -193,8 +208,8 @@ def test_entry_script_two_chunks_on_the_gpu(tmp_path):
     assert name == 'simple_spread' and cnt == 0 and st['episodes'] == 1024 and st['env_steps'] == 100 * 256
     assert st['updates'] == 6 and np.isfinite(st['mean_episode_reward']) and st['mean_episode_reward'] < 0
     hist = pickle.load(open(tmp_path / 'Models' / 'history_simple_spread_0.pkl', 'rb'))
-    assert len(hist['reward_episodes']) == 1024 and len(hist['reward_episodes_by_agents']) == 3
-    assert abs(np.mean(hist['reward_episodes']) - st['mean_episode_reward']) < 1e-3 * abs(st['mean_episode_reward'])
+    assert hist['open_episodes'] == 256 and len(hist['reward_episodes']) == 1024 + 256 and len(hist['reward_episodes_by_agents']) == 3
+    assert abs(np.mean(hist['reward_episodes'][:1024]) - st['mean_episode_reward']) < 1e-3 * abs(st['mean_episode_reward'])
     assert os.path.exists(tmp_path / 'Models' / 'simple_spread_fin_0_actor.pt')
 
 
@@ -225,6 +240,9 @@ def test_train_batched_through_the_full_gather_on_one_rank(tmp_path):
                          out_dir=str(tmp_path), log=lambda *a: None, chunk=T, gather=gather, rank=0, world=1)
     assert hist['stats']['episodes'] == 512 and hist['stats']['env_steps'] == 2 * T * B and hist['stats']['updates'] == 0
     assert len(gather.memory) == 2 * T * B
+    # the gather mode keeps the per-episode history as well: 4 finished episodes per env, then the 128 open ones
+    assert hist['open_episodes'] == B and len(hist['reward_episodes']) == 512 + B
+    assert abs(np.mean(hist['reward_episodes'][:512]) - hist['stats']['mean_episode_reward']) < 1e-3 * abs(hist['stats']['mean_episode_reward'])
     # the same rollout with the kernel's own ring sink: same seeds, same weights -> the same ring
     env2 = mk()
     want = ReplayBuffer(4 * T * B, N, env2.obs_dim)
@@ -266,7 +284,7 @@ def test_learn_gate_and_ledger_properties():
         parts.absorb(rew[:cut], term[:cut])
         parts.absorb(rew[cut:], term[cut:])
         assert len(whole.totals) == len(parts.totals) == int(term.sum())
-        np.testing.assert_allclose(sorted(whole.totals), sorted(parts.totals), rtol=0, atol=1e-9)   # the order inside a chunk is (episode index, env)
+        np.testing.assert_allclose(whole.totals, parts.totals, rtol=0, atol=1e-9)   # (end step, env) order: independent of the cuts
         np.testing.assert_allclose(whole.carry.numpy(), parts.carry.numpy(), rtol=0, atol=1e-9)
 
     gate()

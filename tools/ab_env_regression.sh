@@ -11,11 +11,13 @@ REPS=${REPS:-5}
 export PW_BENCH_NO_POLICY=1
 O=$R/gpurun_out/ab_env
 mkdir -p $O
+if [ -n "$AB_CASES" ]; then IFS=';' read -r -a CASES <<< "$AB_CASES"; else
 CASES=(
   "b65536_n6|--envs 65536 --agents 6 --chunk 100"
   "c5_n24|--envs 4096 --agents 24 --chunk 500"
   "c2|--envs 4096 --agents 6 --chunk 1000"
 )
+fi
 echo "# side case rep env-steps/s launch_ms kernel"
 for rep in $(seq 1 $REPS); do
   for c in "${CASES[@]}"; do
@@ -36,7 +38,7 @@ python3 - $O $REPS <<'EOF'
 import glob, json, os, statistics, sys
 o = sys.argv[1]
 print('# medians (env-steps/s), min .. max, new / old')
-for tag in ('b65536_n6', 'c5_n24', 'c2'):
+for tag in sorted(set(os.path.basename(f).split('_', 1)[1].rsplit('_', 1)[0] for f in glob.glob(os.path.join(o, 'old_*.json')))):
     v = {}
     for side in ('old', 'new'):
         xs = []
@@ -53,6 +55,7 @@ for tag in ('b65536_n6', 'c5_n24', 'c2'):
 EOF
 # the driver's own view: those figures come from other_configs INSIDE the default run (after the headline and the policy extra)
 unset PW_BENCH_NO_POLICY
+[ -n "$AB_NO_FULL" ] && exit 0
 for rep in 1 2; do
   for side in old new; do
     D=$R; [ $side = old ] && D=$OLD
