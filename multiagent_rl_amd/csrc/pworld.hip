@@ -281,6 +281,12 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
     }
     const dim3 grid((kp.B + kp.epw - 1) / kp.epw), block(kWave);
     const size_t shmem = smem_bytes(kp);
+    // max_episode_len = 1 with auto-reset: EVERY step ends an episode.  The multi-wave forms (duo / trio / quad) hand {pos, vel} from
+    // the physics wave to the output waves through a 3- or 4-slot LDS ring and use TWO slots in a step that resets (pre-reset state,
+    // post-reset state); with a reset in every step the physics wave, one step ahead, overwrites the pre-reset slot the output
+    // wave is still composing final_obs from (found in round 5 by rebuilding simple_tag rows from the state: the other agents' entries of
+    // the pre-reset row were post-reset values).  The one-wave forms keep the state in registers: they serve this degenerate setting.
+    const bool every_step_resets = kp.auto_reset && kp.max_episode_len == 1;
     if (h->tag_fast && io->act_idx && io->obs && io->rew && io->rew_shared && io->done && io->terminal &&
         (size_t)kp.B * kp.N * kp.D * sizeof(float) < (1ull << 31) && !h->disp.no_stream) {
         const pw_dispatch &dp = h->disp;
@@ -295,7 +301,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         const bool um = kp.mass == 1.0f;
         // two waves per env group, as for simple_spread.  With the block-wise observation stores (below) the duo form
         // leads on every grid measured: B = 8192: 1.69 vs 2.41 us per step, B = 65536: 10.3 vs 19.0 (profiles/r2_tag_block.txt)
-        const bool duo = dp.duo < 0 ? grid.x <= 8192 : dp.duo != 0;
+        const bool duo = !every_step_resets && (dp.duo < 0 ? grid.x <= 8192 : dp.duo != 0);
         size_t shm2 = ((3 * kWave * sizeof(float4) + 3 * kWave * sizeof(float) + 2 * (size_t)kp.epw * kp.L * sizeof(float2) + 15) &
                        ~(size_t)15) + kActRingBytes;  // ring, masks, rewards, both waves' landmarks | wave P's action ring
         // Block-wise observation stores of the duo kernel (rows staged in LDS): short rows only (LDS), chunks of 4 floats
@@ -379,6 +385,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
             const bool quad_ok = kp.N == 6 && kp.L == 6 && um;
             bool quad = quad_ok && qgrid <= 1536 && dp.duo != 0;  // B <= 12288: measured crossover (profiles/r2_sweeps_final.txt)
             if (dp.quad >= 0) quad = quad_ok && dp.quad != 0;
+            if (every_step_resets) quad = false;
             if (quad) {
                 const size_t qshm = 4 * kWave * sizeof(float4) + 2 * 4 * 6 * 6 * sizeof(float2) + 2 * kWave * sizeof(float) +
                                     8 * 6 * sizeof(float2) + 2 * kQuadActRingBytes + 2 * 8 * sizeof(float2);
@@ -393,7 +400,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         }
         // two cooperating waves per env group pay off while the chip is latency bound (few workgroups
         // per CU); once every SIMD holds several waves the single-wave kernel issues fewer instructions
-        const bool duo = dp.duo < 0 ? grid.x <= 8192 : dp.duo != 0;
+        const bool duo = !every_step_resets && (dp.duo < 0 ? grid.x <= 8192 : dp.duo != 0);
         if (duo) {
             const size_t shm2 = 3 * kWave * sizeof(float4) + (size_t)kp.epw * kp.L * sizeof(float2) +
                                 2 * kWave * sizeof(float) + 16 + kWave * sizeof(float4) + 8 * sizeof(float2) + 16;

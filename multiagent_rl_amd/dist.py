@@ -361,7 +361,7 @@ class FullTransitionGather(object):
     def views(self, block):
         """Typed views of one wire block (a uint8 tensor of ``lay.total_bytes``)."""
         lay, T, B, N, D = self.lay, self.T, self.B, self.N, self.D
-        if self.ref_wire:
+        if getattr(self, 'ref_wire', False):
             F = max(lay.F, 0)
             return dict(head0=self._view(block, lay.head0, (B, N, 8), torch.float32),
                         head=self._view(block, lay.head, (T, B, N, 8), torch.float32),

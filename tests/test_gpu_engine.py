@@ -904,7 +904,7 @@ def test_tag_state_wire_ring_equals_add_rollout_bitwise(A, G, L, B, T, ep):
             assert torch.equal(x, y), name
     per_step = gs['rows'].bytes_per_env_step
     row_block = FullTransitionGather(env, T, 0, 1, torch.device('cuda', 0), wire='rows').bytes_per_env_step
-    assert per_step < 0.45 * row_block
+    assert per_step < (0.45 if ep != 1 else 0.7) * row_block   # (ep = 1: every step ships a pre-reset state and fresh landmarks too)
     if (A, G, B) == (4, 2, 8192):
         assert per_step <= 150.0, per_step                   # <= 150 B per env-step for tag 4 + 2 (from ~565)
 

@@ -241,6 +241,38 @@ def test_rollout_with_auto_reset_matches_oracle_bitwise(case, kernel_path):
     assert np.array_equal(_np(st['ep_step']), o32.ep_step) and np.array_equal(_np(st['ep_count']).astype(np.uint32), o32.ep_count)
 
 
+@pytest.mark.parametrize('case', [
+    dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192),
+    dict(scenario='simple_tag', num_agents=2, num_adversaries=1, num_landmarks=1, num_envs=40),
+    dict(scenario='simple_spread', num_agents=3, num_envs=4096),
+    dict(scenario='simple_spread', num_agents=6, num_envs=4096),
+    dict(scenario='simple_spread', num_agents=12, num_envs=333),
+], ids=['tag4+2', 'tag1+1', 'spread3', 'spread6', 'spread12'])
+def test_every_step_resets_matches_oracle_bitwise(case):
+    """max_episode_len = 1 with auto-reset under the DEFAULT dispatch: every step ends an episode, so every step writes a pre-reset
+    row (final_obs) and publishes a post-reset state.  The multi-wave kernel forms would need two ring slots per step here (their
+    physics wave, one step ahead, overwrote the pre-reset slot the output wave was still reading: found in round 5 through simple_tag rows
+    whose other-agent entries were post-reset values); the dispatcher serves this setting with the one-wave forms.  Every output of
+    every step against the float32 oracle, bit for bit."""
+    T = 9
+    env, cfg = _mk(max_episode_len=1, auto_reset=True, seed=7, want_coll=False, **case)
+    B, N = env.num_envs, env.n
+    acts = np.random.RandomState(3).randint(0, 5, (T, B, N)).astype(np.int32)
+    o32 = co.COracle(cfg, B, np.float32)
+    _assert_same_bits(_np(env.reset()), o32.reset(), 'reset obs')
+    out = env.rollout(torch.from_numpy(acts))
+    assert 'duo' not in env.last_kernel() and 'quad' not in env.last_kernel(), env.last_kernel()
+    for t in range(T):
+        w = o32.step(act_idx=acts[t])
+        assert w['terminal'].all()
+        for name in ('obs', 'final_obs', 'rew', 'rew_shared'):
+            _assert_same_bits(_np(out[name][t]), w[name], '%s[%d]' % (name, t))
+        _assert_same_bits(_np(out['terminal'][t]).astype(np.uint8), w['terminal'], 'terminal[%d]' % t)
+    st = env.get_state()
+    _assert_same_bits(_np(st['pos']), o32.pos, 'pos')
+    _assert_same_bits(_np(st['landmarks']), o32.lm, 'landmarks')
+
+
 def test_rollout_equals_repeated_steps_and_onehot_equals_index():
     T = 30
     rng = np.random.RandomState(11)

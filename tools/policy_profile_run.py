@@ -18,6 +18,9 @@ WORKLOADS = {
     'n3': ('simple_spread', 4096, dict(num_agents=3), 5),
     'n12': ('simple_spread', 4096, dict(num_agents=12), 5),
     'n24': ('simple_spread', 4096, dict(num_agents=24), 5),
+    'n16': ('simple_spread', 4096, dict(num_agents=16), 5),
+    'n30': ('simple_spread', 4096, dict(num_agents=30), 5),
+    'n48': ('simple_spread', 4096, dict(num_agents=48), 5),
     'tag': ('simple_tag', 8192, dict(num_adversaries=4, num_good=2), 5),
     'ref': ('simple_reference', 4096, {}, [5, 10]),
 }
