@@ -79,7 +79,10 @@ def main(argv=None):
                 from multiagent_rl_amd.dist import FullTransitionGather, broadcast_actor
                 actor = actor.to(dev)
                 broadcast_actor(actor, src=0)                                  # same initial weights on every rank
-                gather = FullTransitionGather(env, args.chunk, rank, world, dev)
+                # state-only blocks (simple_spread, simple_tag) land in a STATE ring on the learner rank (rows rebuilt when a batch is
+                # sampled: a third of the ring writes); simple_reference travels on compact-row blocks into its two-head row ring
+                state_ring = scenario_name in ('simple_spread', 'simple_tag')
+                gather = FullTransitionGather(env, args.chunk, rank, world, dev, ring='state' if state_ring else 'rows')
                 gather.prime()
             hist = train_batched(env, actor, critic, Trainer, scenario_name, action_type, cnt=cnt, out_dir=args.out_dir,
                                  chunk=args.chunk, max_updates_per_chunk=args.max_updates_per_chunk, gather=gather,

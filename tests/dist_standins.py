@@ -175,12 +175,71 @@ def state_wire_transitions_reference(g, block):
                 lm=lm.reshape(T * B, lm.shape[-2], 2).clone())
 
 
+# ---- compact-row wire blocks of simple_reference (include/pworld.h pw_ref_wire) ---------------------------------------------
+REF_COLOURS = torch.tensor([[0.75, 0.25, 0.25], [0.25, 0.75, 0.25], [0.25, 0.25, 0.75]])
+
+
+def ref_rows(head, goal, symbol):
+    """The 21-number rows of simple_reference (experiments/scenarios.py:23-42) from their three parts: ``head`` [..., 2, 8] =
+    [p_vel, landmark - p_pos x 3] as the env wrote it, ``goal`` [..., 2] the agent's goal landmark (0.75 on its colour channel),
+    ``symbol`` [..., 2] the symbol the OTHER agent emitted (255: none -> zeros)."""
+    sym = symbol.long()
+    onehot = torch.nn.functional.one_hot(sym.clamp(max=9), 10).float() * (sym != 255)[..., None].float()
+    return torch.cat([head, REF_COLOURS[goal.long()], onehot], dim=-1)
+
+
+def ref_wire_finalize_reference(g, block, obs0):
+    """pw_ref_wire_finalize: heads of every row, the chunk's start (head, goal, visible symbol), per episode end the pre-reset head and
+    the goal the reset drew (read off the post-reset row), both action heads as bytes, the episode map."""
+    v = g.views(block)
+    T, B, F = g.T, g.B, g.lay.F
+    obs, fin, term = g.side['obs'], g.side['final_obs'], g.side['terminal'].bool()
+    v['head0'].copy_(obs0[..., :8])
+    v['goal'][0].copy_(obs0[..., 8:11].argmax(-1).to(torch.uint8))
+    c0 = obs0[..., 11:]
+    v['comm0'].copy_(torch.where(c0.any(-1), c0.argmax(-1), torch.full_like(c0.argmax(-1), 255)).to(torch.uint8))
+    v['head'].copy_(obs[..., :8])
+    k = torch.zeros(B, dtype=torch.long)
+    for t in range(T):
+        m = term[t] & (k < F) if fin is not None else torch.zeros(B, dtype=torch.bool)
+        v['epi'][t] = (k + 128 * m.long()).to(torch.uint8)
+        e = torch.nonzero(m).flatten()
+        if e.numel():
+            v['final_head'][k[e], e] = fin[t, e][..., :8]
+            v['goal'][k[e] + 1, e] = obs[t, e][..., 8:11].argmax(-1).to(torch.uint8)
+        k = k + m.long()
+    v['act'].copy_(g.side['act'].to(torch.uint8))
+
+
+def ref_wire_transitions_reference(g, block):
+    """pw_replay_add_ref_wire: the block's T*B transitions in (t, e) order, rows rebuilt; act [T*B, 2, 2] = (movement, symbol)."""
+    v = g.views(block)
+    T, B = g.T, g.B
+    epi = v['epi'].long()
+    k, ended = epi & 127, (epi & 128) != 0
+    e_idx = torch.arange(B)[None, :].expand(T, B)
+    goal = v['goal'][k, e_idx]                                            # [T, B, 2]: the episode in progress at step t
+    head_obs = torch.cat([v['head0'][None], v['head'][:-1]], 0)
+    head_next = v['head'].clone()
+    t, e = torch.nonzero(ended, as_tuple=True)
+    if t.numel():
+        head_next[t, e] = v['final_head'][k[t, e], e]
+    sym_now = v['act'][..., 1].flip(-1)                                   # [T, B, 2]: what agent a sees = the OTHER agent's symbol
+    prev_ended = torch.cat([torch.zeros(1, B, dtype=torch.bool), ended[:-1]], 0)
+    sym_prev = torch.cat([v['comm0'][None], sym_now[:-1]], 0)
+    sym_prev = torch.where(prev_ended[:, :, None], torch.full_like(sym_prev, 255), sym_prev)
+    return dict(obs=ref_rows(head_obs, goal, sym_prev).reshape(T * B, 2, 21), next_obs=ref_rows(head_next, goal, sym_now).reshape(T * B, 2, 21),
+                act=v['act'].reshape(T * B, 2, 2).clone(), rew=v['rew_shared'].reshape(T * B).clone(), done=torch.zeros(T * B))
+
+
 class CpuFullGather(FullTransitionGather):
     def _layout(self, PwChunkWire):
         # the layout arithmetic is host code of libpworld (no GPU needed)
         return super()._layout(PwChunkWire)
 
     def _make_memory(self):
+        if self.ref_wire:
+            return HostRing()
         if getattr(self, 'ring_kind', 'rows') == 'state':
             return HostStateRing(self.scenario, self.A)
         return HostRing()
@@ -189,13 +248,16 @@ class CpuFullGather(FullTransitionGather):
         state_wire_begin_reference(self, block, *self.env.wire_start())     # the stub env's (state0, landmarks, episode numbers)
 
     def _finalize(self, block, obs0):
-        if self.state_wire:
+        if self.ref_wire:
+            ref_wire_finalize_reference(self, block, obs0)
+        elif self.state_wire:
             state_wire_finalize_reference(self, block, self.env.landmarks_of_episode)
         else:
             wire_finalize_reference(self, block, obs0)
 
     def _ingest(self, block):
-        tr = state_wire_transitions_reference(self, block) if self.state_wire else wire_transitions_reference(self, block)
+        tr = ref_wire_transitions_reference(self, block) if self.ref_wire else \
+            state_wire_transitions_reference(self, block) if self.state_wire else wire_transitions_reference(self, block)
         if isinstance(self.memory, HostStateRing):
             self.memory.append(tr)
         else:

@@ -17,7 +17,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from multiagent_rl_amd.dist import broadcast_actor, row_width, shard_env_ids
-from tests.dist_standins import CpuFullGather, CpuSampledGather, pack_reference, rows_from_state
+from tests.dist_standins import CpuFullGather, CpuSampledGather, pack_reference, ref_rows, rows_from_state
 
 B, N, D, T = 8, 3, 10, 5
 EP = 3  # episode length of the full-gather test: chunks of T = 5 steps see 1 or 2 episode ends per env
@@ -45,6 +45,47 @@ class _SpreadEnv(_Env):
         return landmarks_of(self.rank, e, epn)
 
 
+class _TagEnv(_SpreadEnv):
+    """simple_tag 2 + 1 (A = 2 adversaries, one good agent) with L = 3 landmarks: rows of 4 + 2L + 2(N - 1) + 2G = 16 numbers."""
+    scenario_name, num_adversaries, obs_dim = 'simple_tag', 2, 4 + 2 * L + 2 * (N - 1) + 2 * (N - 2)
+
+
+class _RefEnv(object):
+    """simple_reference: two agents, 21-number rows, two-head actions (movement, symbol)."""
+    num_envs, n, obs_dim, max_episode_len, num_landmarks, scenario_name = B, 2, 21, EP, 3, 'simple_reference'
+
+
+def ref_goal(rank, e, a, epn):
+    return (torch.as_tensor(e) + 2 * a + torch.as_tensor(epn) + rank) % 3
+
+
+def ref_chunk(rank, k, step0):
+    """A simple_reference rollout chunk whose rows are what the env writes: head (vel, landmark - pos) arbitrary, the goal colour of
+    the episode in progress, the one-hot of the symbol the other agent emitted in this step (zeros on a post-reset row)."""
+    g = torch.Generator()
+    g.manual_seed(555 + 1000 * rank + k)
+    head, fhead = torch.randn(T, B, 2, 8, generator=g), torch.randn(T, B, 2, 8, generator=g)
+    act = torch.stack([torch.randint(0, 5, (T, B, 2), generator=g), torch.randint(0, 10, (T, B, 2), generator=g)], -1).int()
+    t = torch.arange(T)[:, None] + step0
+    e = torch.arange(B)[None, :].expand(T, B)
+    term = ((t + e) % EP) == EP - 1
+    a = torch.arange(2)[None, None, :]
+    goal_after = ref_goal(rank, e[..., None], a, episode_number(e, t + 1)[..., None])
+    goal_before = ref_goal(rank, e[..., None], a, episode_number(e, t)[..., None])
+    sym = act[..., 1].flip(-1).long()                                     # the OTHER agent's symbol
+    obs = ref_rows(head, goal_after, torch.where(term[..., None], torch.full_like(sym, 255), sym))
+    return dict(obs=obs, final_obs=ref_rows(fhead, goal_before, sym), terminal=term, act=act,
+                rew_shared=torch.randn(T, B, generator=g))
+
+
+def ref_obs0(rank):
+    g = torch.Generator()
+    g.manual_seed(31 + rank)
+    e = torch.arange(B)
+    goal = ref_goal(rank, e[:, None], torch.arange(2)[None, :], episode_number(e, 0)[:, None])
+    return ref_rows(torch.randn(B, 2, 8, generator=g), goal, torch.full((B, 2), 255))
+
+
 def landmarks_of(rank, e, epn):
     """Stand-in for the reset's Philox draw: landmarks [n, L, 2] of env e's episode number epn on this rank."""
     e, epn = torch.as_tensor(e).double()[:, None, None], torch.as_tensor(epn).double()[:, None, None]
@@ -57,8 +98,8 @@ def episode_number(e, s):
     return 1 + (s + e % EP) // EP
 
 
-def spread_chunk(rank, k, step0):
-    """A rollout chunk of a simple_spread env: random states, rows that ARE the local observation of those states among the
+def spread_chunk(rank, k, step0, scenario='simple_spread', num_adversaries=0):
+    """A rollout chunk of a simple_spread (or simple_tag) env: random states, rows that ARE the local observation of those states among the
     landmarks of the episode in progress, pre-reset rows among the landmarks of the episode that just ended."""
     g = torch.Generator()
     g.manual_seed(4242 + 1000 * rank + k)
@@ -73,8 +114,8 @@ def spread_chunk(rank, k, step0):
     out['terminal'] = ((t + e) % EP) == EP - 1
     lm_after = landmarks_of(rank, e.reshape(-1), episode_number(e, t + 1).reshape(-1)).reshape(T, B, L, 2)
     lm_before = landmarks_of(rank, e.reshape(-1), episode_number(e, t).reshape(-1)).reshape(T, B, L, 2)
-    out['obs'] = rows_from_state(state, lm_after)
-    out['final_obs'] = rows_from_state(final_state, lm_before)
+    out['obs'] = rows_from_state(state, lm_after, scenario, num_adversaries)
+    out['final_obs'] = rows_from_state(final_state, lm_before, scenario, num_adversaries)
     return out
 
 
@@ -147,6 +188,50 @@ def _worker(rank, world, port, q):
     sfull.finish()
     dist.barrier()
 
+    # ---- the same blocks into the learner rank's STATE ring (rows rebuilt when sampled), and simple_tag on the same layout
+    extra = {}
+    for name, mk_env, kw in (('state_ring', lambda: _SpreadEnv(rank), dict(ring='state')), ('tag', lambda: _TagEnv(rank), {})):
+        xenv = mk_env()
+        xg = CpuFullGather(xenv, T, rank, world, 'cpu', **kw)
+        assert xg.state_wire and xg.scenario == xenv.scenario_name and xg.A == getattr(xenv, 'num_adversaries', 0)
+        scen, A = xg.scenario, xg.A
+        state0, lm0, ep0 = spread_start(rank)
+        for k in range(3):
+            src = spread_chunk(rank, k, k * T, scen, A)
+            xenv.start = (state0, lm0, ep0)
+            out = xg.outputs()
+            for nm in ('obs', 'rew_shared', 'terminal', 'act', 'final_obs'):
+                out[nm].copy_(src[nm])
+            xg(None)
+            e = torch.arange(B)
+            state0, ep0 = src['obs'][T - 1][..., :4].clone(), episode_number(e, (k + 1) * T)
+            lm0 = landmarks_of(rank, e, ep0)
+        xg.finish()
+        dist.barrier()
+        if rank == 0:
+            if name == 'state_ring':
+                n = len(xg.memory)
+                extra[name] = (xg.rows_ingested, [x.numpy() for x in xg.memory.sample_index(list(range(n)))],
+                               sum(t['state'].numel() + t['next_state'].numel() + t['lm'].numel() for t in xg.memory.transitions) * 4 // n)
+            else:
+                extra[name] = (xg.rows_ingested, [{kk: vv.numpy() for kk, vv in tr.items() if kk in ('obs', 'next_obs', 'act', 'rew')}
+                                                  for tr in xg.memory.transitions], xg.bytes_per_env_step)
+    # ---- simple_reference on compact-row blocks: two action heads, the 21-number rows rebuilt at the root
+    rg = CpuFullGather(_RefEnv(), T, rank, world, 'cpu')
+    assert rg.ref_wire and not rg.state_wire and tuple(rg.side['act'].shape) == (T, B, 2, 2)
+    obs0 = ref_obs0(rank)
+    for k in range(3):
+        src = ref_chunk(rank, k, k * T)
+        out = rg.outputs()
+        for nm in ('obs', 'rew_shared', 'terminal', 'act', 'final_obs'):
+            out[nm].copy_(src[nm])
+        rg(obs0)
+        obs0 = src['obs'][T - 1].clone()
+    rg.finish()
+    dist.barrier()
+    if rank == 0:
+        extra['ref'] = (rg.rows_ingested, [{kk: vv.numpy() for kk, vv in tr.items()} for tr in rg.memory.transitions], rg.bytes_per_env_step)
+
     # ---- sampled gather
     gat = CpuSampledGather(_Env(), batch_size=4 * world, rank=rank, world=world, device='cpu', every=2, seed=3)
     assert gat.R == 4 and gat.W == row_width(N, D)
@@ -171,9 +256,9 @@ def _worker(rank, world, port, q):
         ring = [{k: v.numpy() for k, v in tr.items()} for tr in full.memory.transitions]
         sring = [{k: v.numpy() for k, v in tr.items()} for tr in sfull.memory.transitions]
         q.put((gat.exchanges, gat.rows_ingested, [r.numpy() for r in gat.memory.rows], full.rows_ingested, ring,
-               sfull.rows_ingested, sring))
+               sfull.rows_ingested, sring, extra))
     else:
-        q.put((gat.exchanges, gat.rows_ingested, None, full.rows_ingested, None, sfull.rows_ingested, None))
+        q.put((gat.exchanges, gat.rows_ingested, None, full.rows_ingested, None, sfull.rows_ingested, None, None))
     dist.destroy_process_group()
 
 
@@ -276,6 +361,73 @@ def test_full_transition_gather_state_only_wire(worldn):
             n_final += int(src['terminal'].sum())
             i += 1
     assert 0 < n_final < 3 * world * T * B
+
+
+def _expected_transitions(world, chunk_fn, obs0_fn):
+    """(exchange, rank, step, env) order of the root's ring: per block obs_t = the previous step's row, next_obs_t = the pre-reset row."""
+    out = []
+    for k in range(3):
+        for r in range(world):
+            src = chunk_fn(r, k, k * T)
+            obs0 = obs0_fn(r) if k == 0 else chunk_fn(r, k - 1, (k - 1) * T)['obs'][T - 1]
+            rows = src['obs'].shape[2:]
+            out.append(dict(obs=torch.cat([obs0[None], src['obs'][:-1]], 0).reshape(T * B, *rows).numpy(),
+                            next_obs=torch.where(src['terminal'][:, :, None, None], src['final_obs'], src['obs']).reshape(T * B, *rows).numpy(),
+                            act=src['act'].reshape(T * B, *src['act'].shape[2:]).numpy().astype(np.uint8),
+                            rew=src['rew_shared'].reshape(T * B).numpy()))
+    return out
+
+
+@pytest.mark.timeout(240)
+def test_full_gather_into_the_state_ring(worldn):
+    """The learner rank's STATE ring (2, 4, 8 ranks): it keeps {vel, pos} before / after + the episode's landmarks per transition
+    (32 N + 8 L bytes instead of 8 N D) and sample_index rebuilds the rows -- every transition of every rank, in ring order, equals
+    the senders' dense rows exactly (and hence the row ring of test_full_transition_gather_state_only_wire)."""
+    world, root = worldn
+    ingested, sampled, bytes_per = root[7]['state_ring']
+    assert ingested == 3 * world * T * B and bytes_per == 32 * N + 8 * L < 8 * N * D
+    want = _expected_transitions(world, spread_chunk, lambda r: rows_from_state(*spread_start(r)[:2]))
+    obs, act, rew, nxt, done = sampled
+    np.testing.assert_array_equal(obs, np.concatenate([w['obs'] for w in want]))
+    np.testing.assert_array_equal(nxt, np.concatenate([w['next_obs'] for w in want]))
+    np.testing.assert_array_equal(act.argmax(-1), np.concatenate([w['act'] for w in want]))
+    np.testing.assert_array_equal(rew, np.concatenate([w['rew'] for w in want]))
+    assert not done.any()
+
+
+@pytest.mark.timeout(240)
+def test_full_gather_simple_tag_state_only_wire(worldn):
+    """simple_tag (2 adversaries + 1 good agent, L = 3) on state-only blocks at 2, 4, 8 ranks: the 16-number rows (other agents'
+    relative positions, the good agent's velocity, zero padding) rebuilt at the root equal the senders' dense rows exactly."""
+    world, root = worldn
+    ingested, ring, per_step = root[7]['tag']
+    Dt = _TagEnv.obs_dim
+    assert ingested == 3 * world * T * B and len(ring) == 3 * world and per_step > 0
+    tag = lambda r, k, s0: spread_chunk(r, k, s0, 'simple_tag', 2)   # noqa: E731
+    want = _expected_transitions(world, tag, lambda r: rows_from_state(*spread_start(r)[:2], 'simple_tag', 2))
+    assert want[0]['obs'].shape[-1] == Dt == 16
+    for got, w in zip(ring, want):
+        for name in ('obs', 'next_obs', 'act', 'rew'):
+            np.testing.assert_array_equal(got[name], w[name], err_msg=name)
+
+
+@pytest.mark.timeout(240)
+def test_full_gather_simple_reference_compact_rows(worldn):
+    """simple_reference (MultiDiscrete: two action heads) on compact-row blocks at 2, 4, 8 ranks: 8 of the 21 numbers of a row, one
+    goal byte per agent and episode and both heads as bytes travel; the rows rebuilt at the root (goal colour, the other agent's one-hot
+    symbol, zeros after a reset) equal the senders' dense rows exactly, and BOTH heads arrive."""
+    world, root = worldn
+    ingested, ring, per_step = root[7]['ref']
+    assert ingested == 3 * world * T * B and len(ring) == 3 * world and per_step > 0   # (bytes per env-step at real sizes: the GPU test)
+    want = _expected_transitions(world, ref_chunk, ref_obs0)
+    ends = 0
+    for got, w in zip(ring, want):
+        for name in ('obs', 'next_obs', 'rew'):
+            np.testing.assert_array_equal(got[name], w[name], err_msg=name)
+        np.testing.assert_array_equal(got['act'], w['act'])
+        assert got['act'].shape == (T * B, 2, 2) and got['act'][..., 1].max() > 4      # the symbol head is there (0..9)
+        ends += int((got['obs'][1:, :, 11:].sum(-1) == 0).all(-1).sum())
+    assert ends > 0                                                                    # post-reset rows (no symbol visible) occurred
 
 
 @pytest.mark.timeout(120)

@@ -937,7 +937,30 @@ def test_reference_compact_wire_ring_equals_add_rollout_bitwise(B, T, ep):
         out['act'].copy_(acts)
         env.rollout(acts, out={n_: v for n_, v in out.items() if n_ != 'act'})
         dense = {n_: v.clone() for n_, v in out.items()}
+        block = full.wire[full.exchanges % full.SLOTS]
         full(obs0)
+        # the block equals the torch restatement the gloo tests run (tests/dist_standins.py), and so do the rebuilt transitions
+        from tests.dist_standins import ref_wire_finalize_reference, ref_wire_transitions_reference
+        cpu = FullTransitionGather.__new__(FullTransitionGather)
+        cpu.__dict__.update(T=T, B=B, N=N, D=D, lay=full.lay, state_wire=False, ref_wire=True,
+                            side={n_: (None if v is None else v.cpu()) for n_, v in full.side.items()})
+        ref_block = torch.zeros_like(block, device='cpu')
+        cpu.views(ref_block)['rew_shared'].copy_(dense['rew_shared'].cpu())
+        ref_wire_finalize_reference(cpu, ref_block, obs0.cpu())
+        got_v, ref_v = full.views(block), cpu.views(ref_block)
+        for name in ('head0', 'head', 'comm0', 'rew_shared', 'act', 'epi'):
+            assert torch.equal(got_v[name].cpu(), ref_v[name]), name
+        epi = ref_v['epi'].long()
+        ended, kk = (epi & 128) != 0, epi & 127
+        assert torch.equal(got_v['goal'][0].cpu(), ref_v['goal'][0])
+        tt, ee = torch.nonzero(ended, as_tuple=True)
+        if tt.numel():
+            assert torch.equal(got_v['final_head'].cpu()[kk[tt, ee], ee], ref_v['final_head'][kk[tt, ee], ee])
+            assert torch.equal(got_v['goal'].cpu()[kk[tt, ee] + 1, ee], ref_v['goal'][kk[tt, ee] + 1, ee])
+        tr = ref_wire_transitions_reference(cpu, block.cpu())
+        assert torch.equal(tr['obs'].reshape(T, B, N, D), torch.cat([obs0[None], dense['obs'][:-1]], 0).cpu())
+        assert torch.equal(tr['next_obs'].reshape(T, B, N, D),
+                           (torch.where(dense['terminal'][:, :, None, None], dense['final_obs'], dense['obs']) if ep > 0 else dense['obs']).cpu())
         want.add_rollout(obs0, dense)
         obs0 = dense['obs'][T - 1].clone()
     full.finish()

@@ -255,6 +255,49 @@ def test_train_batched_through_the_full_gather_on_one_rank(tmp_path):
         assert torch.equal(getattr(gather.memory, name)[:2 * T * B], getattr(want, name)[:2 * T * B]), name
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('scenario', ['simple_spread', 'simple_tag', 'simple_reference'])
+def test_train_batched_learns_from_the_gathers_ring_in_every_scenario(tmp_path, scenario):
+    """The multi-rank form of train_batched with world = 1 on cuda:0, the learner RUNNING: simple_spread and simple_tag through state-only
+    wire blocks into a STATE ring (sample_index rebuilds the rows the learner trains on), simple_reference (MultiDiscrete, two action
+    heads) through compact-row blocks into its two-head ring.  The history has one entry per finished episode (+ the open ones), the
+    owed / run update counts are reported, the actor's weights moved."""
+    sys.path.insert(0, os.path.join(ROOT, 'examples'))
+    from madr_learner import CriticNetwork, Trainer
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.dist import FullTransitionGather
+    from multiagent_rl_amd.policy import ActorNetwork
+
+    class Cfg(_Args):
+        num_episodes, batch_size, warmup_steps, update_rate, save_rate = 1024, 256, 1024, 1000, 512
+
+    torch.manual_seed(5)
+    B, T = 128, 50
+    dev = torch.device('cuda', 0)
+    kw = dict(n=3) if scenario == 'simple_spread' else dict(num_adversaries=2, num_good=1) if scenario == 'simple_tag' else {}
+    env = make_batched_env(scenario, B, auto_reset=True, max_episode_len=25, seed=12345678, **kw)
+    dim_obs, dim_action, action_type = dims_from_env(env)
+    assert action_type == ('MultiDiscrete' if scenario == 'simple_reference' else 'Discrete')
+    actor = ActorNetwork(dim_obs, dim_action)
+    before = actor.dense1.module.weight.detach().clone()
+    n_act = sum(dim_action) if isinstance(dim_action, list) else dim_action
+    gather = FullTransitionGather(env, T, 0, 1, dev, capacity=6 * T * B, ring='rows' if scenario == 'simple_reference' else 'state')
+    assert gather.ref_wire == (scenario == 'simple_reference') and (gather.memory.state_ring is not None) == (scenario != 'simple_reference')
+    hist = train_batched(env, actor, CriticNetwork(dim_obs + n_act), Trainer, scenario, action_type, cnt=0, arglist=Cfg(),
+                         out_dir=str(tmp_path), log=lambda *a: None, chunk=T, gather=gather, rank=0, world=1, max_updates_per_chunk=2)
+    st = hist['stats']
+    assert st['episodes'] == 1024 and st['env_steps'] == 4 * T * B and len(gather.memory) == 4 * T * B
+    assert st['updates_run'] >= 2 and st['updates_owed'] > st['updates_run'] and st['updates_skipped'] == st['updates_owed'] - st['updates_run']
+    assert hist['open_episodes'] == B and len(hist['reward_episodes']) == 1024 + B and len(hist['reward_episodes_by_agents']) == env.n
+    assert not torch.equal(before, actor.dense1.module.weight.detach().cpu())
+    saved = pickle.load(open(tmp_path / ('history_%s_0.pkl' % scenario), 'rb'))
+    assert saved['reward_episodes'] == hist['reward_episodes']
+    # what the learner sampled from: finite rows of the right shape (state ring: rebuilt by pw_replay_gather)
+    obs, act, rew, nxt, done = gather.memory.sample_index(list(range(0, 4 * T * B, 97)))
+    assert obs.shape[1:] == (env.n, dim_obs) and act.shape[-1] == n_act and torch.isfinite(obs).all() and torch.isfinite(nxt).all()
+    assert (act.sum(-1) == (2 if scenario == 'simple_reference' else 1)).all()
+
+
 def test_learn_gate_and_ledger_properties():
     """Property checks (hypothesis): chunked gate openings add up to the per-step gate whatever the chunking; the ledger's episode
     returns do not depend on where the chunks are cut."""
