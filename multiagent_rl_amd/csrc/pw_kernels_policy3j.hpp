@@ -37,27 +37,51 @@ namespace {
 // bank period) hit the SAME bank pair -- a 64-way conflict per wave and timestep -- and the sixteen state reads of dense1 (16 bytes x N apart)
 // the same four banks: profiles/r4_policy_n24_summary.json counted 0.67 of all LDS cycles as conflict cycles.  An ODD stride makes
 // n * NP + ts run through all residues modulo 16: the host passes NP = N | 1 wherever the 16 environments still fit (the padding
-// rows are never read; the Gumbel noise stays keyed by the TRUE global row env * N + agent).
+// rows are never read; the Gumbel noise stays keyed by the TRUE global row env * N + agent).  (Measured: the step time did not move --
+// N = 24 74.3 us before and after -- the kernel does not wait for LDS; kept because it is free and removes 0.67 -> of the conflict cycles.)
+// Sixteen environments per workgroup beyond N = 30 (round 5; template parameter HALF = rows longer than 64 numbers, N = L = 31 .. 50).  Two things
+// capped the workgroup at 8 environments there -- half of the 16 MFMA columns: the head input (256 B per agent: 196 KB at N = 48) and the
+// environment lanes (lane = (environment, agent): one environment per wave).
+//   * HALF-STORAGE HEAD.  The head of timestep ts needs relu(h_fwd(ts)) and relu(h_bwd(ts)), i.e. it can run as soon as BOTH directions have
+//     visited ts -- at iteration max(ts, N - 1 - ts) -- instead of after the whole pass.  Only the FIRST visitor's half has to be kept (the
+//     second one's is still in the h exchange buffer when the head runs): s_hh[ts] = that half in the exchange buffer's own B-fragment layout
+//     (2 KB per timestep), written beside the exchange write.  After the barrier of iteration s2 up to two timesteps are complete (ts = s2 if
+//     the backward direction was there first, ts = N - 1 - s2 if the forward one was); two waves (rotating) run their heads -- logits chain
+//     b2, k = 0 .. 31 (forward), k = 32 .. 63 (backward): the order of every other form -- draw the noise, take the arg-max and write the byte
+//     action, while the others go on with iteration s2 + 1.  128 B per agent instead of 256, and no head phase after the loop.
+//   * ENVIRONMENT SLOTS.  No environment state lives in registers across steps any more: {vel, pos} is the published s_st row, landmarks s_lmb,
+//     the episode clock / counters small per-environment arrays in LDS.  An environment wave walks `slots` groups of environments one after the
+//     other (N = 48, E = 16: two); the near mask the step's forces need is kept per row in LDS too (re-deriving it by a second partner
+//     pass per step cost 4 us per step at N = 24: measured).  This also took ~20 registers off every instantiation.
+//   HALF is chosen by the host wherever the full head input does not leave room for 16 environments (N >= 30) and compiled for rows of more
+//   than 48 numbers (S1C >= 7); below that the full head (no head work inside the timestep loop) is ~5 % faster.
 // ------------------------------------------------------------------------------------------
 struct Roll3jLds {
     float4 *s_xf;    // [2 buffers][2 dir][4 j][64 lane]: x1 fragments of one timestep per (buffer, direction)
-    float4 *s_hx;    // [2 buffers][2 dir][2 j][64 lane]
-    float4 *s_hf;    // [rows / 16 tiles][4 j][64 lane]
+    float4 *s_hx;    // [2 buffers][2 dir][2 j][64 lane]: h exchange, element e of (j, lane (n, kq)) = h[seq n][16 j + 4 e + kq]
+    float4 *s_hf;    // !HALF: head input [rows / 16 tiles][4 j][64 lane];  HALF: s_hh [NP timesteps][2 j][64 lane] = the first visitor's h(ts)
     float *s_b2;     // [16]
-    float4 *s_st;    // [rows] {vx, vy, px, py} of the agents as the policy sees them (row = env * N + agent)
-    int32_t *s_act;  // [rows]: aliases the x1 ring (written by the head, read by the environment lanes: the ring is idle in between)
+    float4 *s_st;    // [rows] {vx, vy, px, py} of the agents as the policy sees them (row = env * NP + agent)
+    uint8_t *s_act;  // [rows] sampled actions (written by the head, read by the environment lanes)
+    uint64_t *s_near; // [rows] near mask of every agent on the current positions (what the next step's contact forces visit)
     float2 *s_posb;  // [8 env waves][64]
     float2 *s_lmb;   // [E * L]
+    int *s_eps;      // [16] episode step of every environment of the workgroup
+    uint32_t *s_epc; // [16] episode number
+    float *s_ret;    // [16] running episode return (SINK)
     double *s_fs;    // [16]
     int *s_fc;       // [16]
 };
-__host__ __device__ inline size_t roll3j_lds_bytes(int E, int NP, int L)   // NP: the row stride (>= N)
+__host__ __device__ inline size_t roll3j_lds_bytes(int E, int NP, int L, bool half)   // NP: the row stride (>= N)
 {
     const size_t rows = (size_t)E * NP;
-    const size_t fl = 2 * 2 * 4 * 64 * 4 + 2 * 2 * 2 * 64 * 4 + ((rows + 15) / 16) * 1024 + 16 + 3 + rows * 4 + 1;
-    return fl * 4 + 8 * kWave * sizeof(float2) + (size_t)E * L * sizeof(float2) + 16 * (sizeof(double) + sizeof(int)) + 64;
+    const size_t head = half ? (size_t)NP * 2 * 64 * 4 : ((rows + 15) / 16) * 1024;
+    const size_t fl = 2 * 2 * 4 * 64 * 4 + 2 * 2 * 2 * 64 * 4 + head + 16 + 3 + rows * 4 + 1;
+    // (!HALF: the byte actions alias the x1 ring -- idle between the head and the environment step -- and no near masks are kept: at
+    // N = 30 the full-head form fits its 16 environments with 240 bytes to spare)
+    return fl * 4 + (half ? ((rows + 15) & ~(size_t)15) + rows * sizeof(uint64_t) : 0) + 8 * kWave * sizeof(float2) + (size_t)E * L * sizeof(float2) + 16 * (3 * 4 + sizeof(double) + sizeof(int)) + 64;
 }
-__device__ __forceinline__ Roll3jLds roll3j_carve(unsigned char *raw, int E, int NP, int L)
+__device__ __forceinline__ Roll3jLds roll3j_carve(unsigned char *raw, int E, int NP, int L, bool half)
 {
     const int rows = E * NP;
     float *base = reinterpret_cast<float *>(raw);
@@ -65,20 +89,30 @@ __device__ __forceinline__ Roll3jLds roll3j_carve(unsigned char *raw, int E, int
     int o = 0;
     S.s_xf = reinterpret_cast<float4 *>(base + o); o += 2 * 2 * 4 * 64 * 4;
     S.s_hx = reinterpret_cast<float4 *>(base + o); o += 2 * 2 * 2 * 64 * 4;
-    S.s_hf = reinterpret_cast<float4 *>(base + o); o += ((rows + 15) / 16) * 1024;
+    S.s_hf = reinterpret_cast<float4 *>(base + o); o += half ? NP * 2 * 64 * 4 : ((rows + 15) / 16) * 1024;
     S.s_b2 = base + o; o += 16;
     o = (o + 3) & ~3;
     S.s_st = reinterpret_cast<float4 *>(base + o); o += rows * 4;
-    S.s_act = reinterpret_cast<int32_t *>(S.s_xf);   // rows <= 512 ints of the ring's 4096 floats
-    o = (o + 1) & ~1;
+    if (half) {
+        S.s_act = reinterpret_cast<uint8_t *>(base + o); o += ((rows + 15) & ~15) / 4;
+        o = (o + 1) & ~1;
+        S.s_near = reinterpret_cast<uint64_t *>(base + o); o += rows * 2;
+    } else {
+        S.s_act = reinterpret_cast<uint8_t *>(S.s_xf);   // rows <= 1024 bytes of the ring's 16 KB: written by the head, read by the environment lanes
+        S.s_near = nullptr;
+        o = (o + 1) & ~1;
+    }
     S.s_posb = reinterpret_cast<float2 *>(base + o); o += 8 * kWave * 2;
     S.s_lmb = reinterpret_cast<float2 *>(base + o); o += E * L * 2;
     S.s_fs = reinterpret_cast<double *>(base + o); o += 32;
-    S.s_fc = reinterpret_cast<int *>(base + o);
+    S.s_fc = reinterpret_cast<int *>(base + o); o += 16;
+    S.s_eps = reinterpret_cast<int *>(base + o); o += 16;
+    S.s_epc = reinterpret_cast<uint32_t *>(base + o); o += 16;
+    S.s_ret = base + o;
     return S;
 }
 
-template <int S1C, bool SINK>
+template <int S1C, bool SINK, bool HALF>
 __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRolloutArgs P)
 {
     constexpr int S1 = 4 * S1C;     // 32x32x2 k steps of the packed W1 image (2 k each)
@@ -87,7 +121,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
     const ActorFusedArgs &A = P.A;
     const StreamParams &V = P.V;
     const int N = A.N, L = V.L, D = A.D, E = A.E, NP = P.NP;
-    const Roll3jLds S = roll3j_carve(smem_raw, E, NP, L);
+    const Roll3jLds S = roll3j_carve(smem_raw, E, NP, L, HALF);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,49 +135,73 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
 
     if (tid < OUT) S.s_b2[tid] = A.b2[tid];
 
-    // ---- environment lanes: wave w >= 8 - n_env_waves owns local envs [ew * epw, ...), lane = (env, agent)
+    // ---- environment lanes.  The environments of the workgroup are dealt to "virtual waves" of epw environments each (lane = (env, agent));
+    // environment wave ew (the LAST n_env_waves waves) serves virtual waves ew, ew + 8, ... one after the other (slots).
     const int epw_max = E < kWave / N ? E : kWave / N;
-    const int waves_full = (E + epw_max - 1) / epw_max;
-    const int epw = (E + waves_full - 1) / waves_full;
-    const int n_env_waves = (envs_here + epw - 1) / epw;  // <= 8 (the host caps E at 8 * (64 / N))
+    const int vwaves_full = (E + epw_max - 1) / epw_max;
+    const int epw = (E + vwaves_full - 1) / vwaves_full;
+    const int n_vwaves = (envs_here + epw - 1) / epw;
+    const int n_env_waves = n_vwaves < 8 ? n_vwaves : 8;
     const int ew = wave - (8 - n_env_waves);
     const bool env_wave = ew >= 0;
-    int e_loc = lane / N, a = lane - e_loc * N;
-    int el = ew * epw + e_loc;
-    const bool live = env_wave && e_loc < epw && el < envs_here;
-    if (!live) { e_loc = 0; a = 0; el = env_wave ? ew * epw : 0; }
-    const int base = e_loc * N, r = el * NP + a;   // r: this lane's row in LDS (stride NP)
-    const long env = env0 + el;
-    const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
     float2 *s_pos = S.s_posb + (env_wave ? ew : 0) * kWave;
-    const float2 *pp = s_pos + base;
-    float2 *lmv = S.s_lmb + el * L;
-
-    float px = 0.f, py = 0.f, vx = 0.f, vy = 0.f, olx = 0.f, oly = 0.f, best = 0.f;
-    int ep_step = 0;
-    uint32_t ep_count = 0;
-    uint64_t coll = 0, near = 0;
-    float ep_ret = 0.f;
-    double fin_sum = 0.0;
-    int fin_cnt = 0;
-    const int la = a < L ? a : 0;
-    // landmarks: lane a owns landmarks a, a + N, ... (L <= N on this path: one each; checked on the host)
-    if (env_wave) {
-        if (SINK && P.episode_return && live && a == 0) ep_ret = P.episode_return[env];
-        px = V.pos_x[g]; py = V.pos_y[g]; vx = V.vel_x[g]; vy = V.vel_y[g];
-        ep_step = V.ep_step[env];
-        ep_count = V.ep_count[env];
-        if (L > 0) {
-            olx = V.lm_x[(size_t)env * L + la];
-            oly = V.lm_y[(size_t)env * L + la];
-            if (live && a < L) lmv[la] = make_float2(olx, oly);
-        }
-        if (live) s_pos[base + a] = make_float2(px, py);
-        wave_lds_sync();
-        stream_partner_pass<0, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
-        if (live) S.s_st[r] = make_float4(vx, vy, px, py);
-    }
     const float k = V.contact_margin, cf = V.contact_force, dt = V.dt, damp = V.damp, mass = V.mass;
+
+    // one slot's lane coordinates
+    struct EnvLane {
+        int e_loc, a, el, base, r, la;
+        bool live;
+        long env;
+        uint32_t g;
+    };
+    auto env_lane = [&](const int vw) {
+        EnvLane q;
+        q.e_loc = lane / N; q.a = lane - q.e_loc * N;
+        q.el = vw * epw + q.e_loc;
+        q.live = q.e_loc < epw && q.el < envs_here;
+        if (!q.live) { q.e_loc = 0; q.a = 0; q.el = vw * epw; }   // idle lanes shadow lane 0 (vw * epw < envs_here: the caller checks)
+        q.base = q.e_loc * N; q.r = q.el * NP + q.a; q.la = q.a < L ? q.a : 0;
+        q.env = env0 + q.el;
+        q.g = (uint32_t)q.env * (uint32_t)N + (uint32_t)q.a;
+        return q;
+    };
+    // !HALF (one slot per environment wave: the host caps E at 8 x (64 / N) there): the lane's state stays in these registers for the whole
+    // launch, as in every other rollout kernel (through LDS each step it cost 2.5 % at N = 16 .. 24: measured).  HALF: reloaded per slot.
+    float r_px = 0.f, r_py = 0.f, r_vx = 0.f, r_vy = 0.f, r_olx = 0.f, r_oly = 0.f;
+    int r_ep_step = 0;
+    uint32_t r_ep_count = 0;
+    uint64_t r_near = 0;
+    if (env_wave) {   // the workgroup's state: global planes -> LDS
+        for (int vw = ew; vw < n_vwaves; vw += 8) {
+            const EnvLane q = env_lane(vw);
+            if (q.live) {
+                S.s_st[q.r] = make_float4(V.vel_x[q.g], V.vel_y[q.g], V.pos_x[q.g], V.pos_y[q.g]);
+                if (L > 0 && q.a < L) S.s_lmb[q.el * L + q.la] = make_float2(V.lm_x[(size_t)q.env * L + q.la], V.lm_y[(size_t)q.env * L + q.la]);
+                if (q.a == 0) {
+                    S.s_eps[q.el] = V.ep_step[q.env];
+                    S.s_epc[q.el] = V.ep_count[q.env];
+                    S.s_ret[q.el] = (SINK && P.episode_return) ? P.episode_return[q.env] : 0.0f;
+                    S.s_fs[q.el] = 0.0;
+                    S.s_fc[q.el] = 0;
+                }
+            }
+            // the near masks of the first step: a partner pass on the initial positions
+            const float px = V.pos_x[q.g], py = V.pos_y[q.g];
+            wave_lds_sync();
+            if (q.live) s_pos[q.base + q.a] = make_float2(px, py);
+            wave_lds_sync();
+            uint64_t coll = 0, near = 0;
+            float best = 0.f;
+            stream_partner_pass<0, uint64_t>(N, q.a, s_pos + q.base, px, py, 0.0f, 0.0f, V.coll_thr2, V.near_thr2, coll, near, best);
+            if (HALF && q.live) S.s_near[q.r] = near;
+            if (!HALF) {
+                r_px = px; r_py = py; r_vx = V.vel_x[q.g]; r_vy = V.vel_y[q.g];
+                if (L > 0) { r_olx = V.lm_x[(size_t)q.env * L + q.la]; r_oly = V.lm_y[(size_t)q.env * L + q.la]; }
+                r_ep_step = V.ep_step[q.env]; r_ep_count = V.ep_count[q.env];
+                r_near = near;
+            }
+        }
+    }
 
     // ---- this wave's resident weights (lane roles: pw_kernels_actor16.hpp)
     const int dir = wave >> 2, hq = wave & 3;
@@ -183,16 +241,43 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
     const int nseq = seq_ok ? n16 : 0;   // columns past the environments of this workgroup read env 0; nobody uses their results
     wg_lds_barrier();  // constants, first states and landmarks in LDS
 
-    // The head on the matrix cores (pw_policy_rollout3_kernel's), with the Gumbel noise drawn IN the lanes that subtract it: value
-    // (row, logit o) = log(-log(u)), u = word (o & 3) of Philox block (o >> 2) keyed (seed; step, global row) -- the keying of every
-    // other form -- so row group 0 (logits 0..3) needs block 0 and row group 1 (logit 4) block 1 of its row: no noise plane in LDS
-    // (9.6 KB at N = 30: with it, 16 environments per workgroup would not fit).
-    auto head = [&](const uint64_t step) {
+    // Gumbel noise of logits 4 kq .. 4 kq + 3 of global row `grow`, drawn IN the lanes that subtract it: value (row, logit o) = log(-log(u)),
+    // u = word (o & 3) of Philox block (o >> 2) keyed (seed; step, global row) -- the keying of every other form -- so row group 0 (logits
+    // 0..3) needs block 0 and row group 1 (logit 4) block 1 of its row: no noise plane in LDS.  Then the arg-max (first maximum wins).
+    auto sample = [&](const f32x4 lg, const long grow, const uint64_t step) {
+        float nz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (kq < 2) {  // wave-divergent only by row group
+            const uint32_t blk = (uint32_t)kq, tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
+            uint32_t u[4];
+            pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | tag, (uint32_t)step, (uint32_t)(step >> 32),
+                             (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float uo = ((float)(u[i] >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
+                nz[i] = __logf(-__logf(uo));
+            }
+        }
+        const float p0 = lg[0] - nz[0], p1 = lg[1] - nz[1], p2 = lg[2] - nz[2], p3 = lg[3] - nz[3];
+        const float p4 = __shfl(p0, n16 + 16, kWave);  // logit 4 lives in register 0 of row group 1
+        int bi = 0;
+        float bv = p0;
+        if (p1 > bv) { bv = p1; bi = 1; }
+        if (p2 > bv) { bv = p2; bi = 2; }
+        if (p3 > bv) { bv = p3; bi = 3; }
+        if (p4 > bv) { bv = p4; bi = 4; }
+        return bi;
+    };
+    auto head_b2 = [&]() {
+        f32x4 lg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lg[i] = 4 * kq + i < OUT ? S.s_b2[4 * kq + i] : 0.0f;
+        return lg;
+    };
+    // !HALF: the head after the pass, on the tiles of the row-ordered head input (pw_policy_rollout3_kernel's)
+    auto head_rows = [&](const uint64_t step) {
         const int ntile = (rows_here + 15) >> 4;
         for (int tile = wave; tile < ntile; tile += 8) {
-            f32x4 lg;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lg[i] = 4 * kq + i < OUT ? S.s_b2[4 * kq + i] : 0.0f;
+            f32x4 lg = head_b2();
             const float4 *hf = S.s_hf + (tile * 4) * 64 + lane;
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) {
@@ -203,31 +288,39 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
                 lg = __builtin_amdgcn_mfma_f32_16x16x4f32(aw2[4 * jx + 3], b.w, lg, 0, 0, 0);
             }
             const int rr = tile * 16 + n16;
-            float nz[4] = {0.f, 0.f, 0.f, 0.f};
-            if (kq < 2) {  // wave-divergent only by row group
-                const int rq = rr < rows_here ? rr : 0, re = rq / NP, ra = rq - re * NP;   // LDS row -> (environment, agent)
-                const long grow = row_base + (long)re * N + (ra < N ? ra : 0);            // the TRUE global row keys the noise
-                const uint32_t blk = (uint32_t)kq, tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
-                uint32_t u[4];
-                pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | tag, (uint32_t)step, (uint32_t)(step >> 32),
-                                 (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float uo = ((float)(u[i] >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
-                    nz[i] = __logf(-__logf(uo));
-                }
-            }
-            const float p0 = lg[0] - nz[0], p1 = lg[1] - nz[1], p2 = lg[2] - nz[2], p3 = lg[3] - nz[3];
-            const float p4 = __shfl(p0, n16 + 16, kWave);  // logit 4 lives in register 0 of row group 1
-            int bi = 0;
-            float bv = p0;
-            if (p1 > bv) { bv = p1; bi = 1; }
-            if (p2 > bv) { bv = p2; bi = 2; }
-            if (p3 > bv) { bv = p3; bi = 3; }
-            if (p4 > bv) { bv = p4; bi = 4; }
-            if (kq == 0 && rr < rows_here) S.s_act[rr] = bi;
+            const int rq = rr < rows_here ? rr : 0, re = rq / NP, ra = rq - re * NP;   // LDS row -> (environment, agent)
+            const int bi = sample(lg, row_base + (long)re * N + (ra < N ? ra : 0), step);   // the TRUE global row keys the noise
+            if (kq == 0 && rr < rows_here) S.s_act[rr] = (uint8_t)bi;
         }
         wg_lds_barrier();
+    };
+    // HALF: the head of ONE timestep (its 16 sequences are the 16 columns) from the two directions' h fragments ([2 j][64 lane] each)
+    auto head_ts = [&](const int ts, const float4 *hF, const float4 *hB, const uint64_t step) {
+        f32x4 lg = head_b2();
+        auto half = [&](const float4 *hx, const int s0) {
+#pragma unroll
+            for (int jx = 0; jx < 2; ++jx) {
+                float4 b = hx[jx * 64 + lane];
+                if (A.relu_out) { b.x = fmaxf(b.x, 0.0f); b.y = fmaxf(b.y, 0.0f); b.z = fmaxf(b.z, 0.0f); b.w = fmaxf(b.w, 0.0f); }
+                lg = __builtin_amdgcn_mfma_f32_16x16x4f32(aw2[s0 + 4 * jx + 0], b.x, lg, 0, 0, 0);
+                lg = __builtin_amdgcn_mfma_f32_16x16x4f32(aw2[s0 + 4 * jx + 1], b.y, lg, 0, 0, 0);
+                lg = __builtin_amdgcn_mfma_f32_16x16x4f32(aw2[s0 + 4 * jx + 2], b.z, lg, 0, 0, 0);
+                lg = __builtin_amdgcn_mfma_f32_16x16x4f32(aw2[s0 + 4 * jx + 3], b.w, lg, 0, 0, 0);
+            }
+        };
+        half(hF, 0);   // k = 0 .. 31: the forward direction's units
+        half(hB, 8);   // k = 32 .. 63: the backward direction's
+        // the logits replace the stored half (this wave just consumed it; nobody else reads it): [64 lane] float4 of the timestep's slot.
+        // Noise and arg-max follow after the loop, on all eight waves at once (inside the loop they sat on the critical path of two).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        reinterpret_cast<f32x4 *>(S.s_hf + ts * 128)[lane] = lg;
+    };
+    auto sample_all = [&](const uint64_t step) {   // HALF, after the pass: timestep ts = wave, wave + 8, ...
+        for (int ts = wave; ts < N; ts += 8) {
+            const f32x4 lg = reinterpret_cast<const f32x4 *>(S.s_hf + ts * 128)[lane];
+            const int bi = sample(lg, row_base + (long)nseq * N + ts, step);
+            if (kq == 0 && seq_ok) S.s_act[n16 * NP + ts] = (uint8_t)bi;
+        }
     };
 
     // dense1 of timestep ts (this wave's direction) into x1 ring buffer `buf`: rows 16 hq .. + 15, 16 sequences
@@ -239,7 +332,11 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[0], x0, acc, 0, 0, 0);
 #pragma unroll
         for (int s = 1; s < KS; ++s) {
-            const float x = 2 * (s - 1) + (kq >> 1) < L ? lmk[s - 1] - pc : 0.0f;
+            // no "landmark index < L ? .. : 0" here: beyond the row (k >= D) W1's packed image holds +0 weights and lmk holds 0, so the
+            // operand is the finite -pc and the product a zero that leaves the accumulator as it is (the chain starts from +0 and a sum
+            // of zeros or an exact cancellation is +0 in round-to-nearest: the accumulator is never -0, so the zero's sign cannot show).
+            // The KS - 1 loop-invariant lane masks of that select were hoisted into SGPR pairs, spilled, and re-read in every timestep.
+            const float x = lmk[s - 1] - pc;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], x, acc, 0, 0, 0);
         }
         float v[4];
@@ -251,12 +348,53 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
     };
     auto inproj = [&](const int buf, f32x4 (&acc)[2]) { actor16_inproj<false>(S.s_xf, buf * 2 + dir, lane, aih, ah, al, bias, acc); };
 
-    // environment step t after positions and velocities are advanced (pw_policy_rollout3_kernel's env_step_with_reset, run for
-    // every step: partner pass, rewards, stores, bookkeeping, the reset where an episode ends, then the next states published)
-    int ai = 0;
-    size_t slot = 0;
-    auto env_finish = [&](const int t) {
+    // Environment step t of one slot (pw_spread_stream_kernel's arithmetic): state from LDS, near mask from a partner pass on the
+    // current positions, action force + contact forces + integration, then partner pass on the new positions, rewards, stores,
+    // bookkeeping, the reset where an episode ends, and the next state published.
+    auto env_step = [&](const int t, const int vw) {
+        const EnvLane q = env_lane(vw);
+        const int a = q.a, base = q.base, r = q.r, la = q.la, el = q.el;
+        const bool live = q.live;
+        const long env = q.env;
+        const uint32_t g = q.g;
         const size_t tBN = (size_t)t * BN;
+        const float2 *pp = s_pos + base;
+        float2 *lmv = S.s_lmb + el * L;
+        float vx = r_vx, vy = r_vy, px = r_px, py = r_py, olx = r_olx, oly = r_oly, best = 0.f;
+        int ep_step = r_ep_step;
+        uint32_t ep_count = r_ep_count;
+        uint64_t coll = 0, near = r_near;   // on the current positions: left by the previous step's partner pass
+        if (HALF) {
+            const float4 st = S.s_st[r];
+            vx = st.x; vy = st.y; px = st.z; py = st.w;
+            if (L > 0) { const float2 o = lmv[la]; olx = o.x; oly = o.y; }
+            ep_step = S.s_eps[el];
+            ep_count = S.s_epc[el];
+            near = S.s_near[r];
+        }
+        wave_lds_sync();
+        if (live) s_pos[base + a] = make_float2(px, py);   // the contact forces read the partners' positions here
+        wave_lds_sync();
+        const int ai = S.s_act[r];
+        size_t slot = 0;
+        if (SINK && P.has_ring) {  // the observation the policy acted on: rebuilt from the (still pre-step) state
+            slot = ring_slot(P.ring_start, t, A.B, (long)env, P.ring.capacity);
+            if (live) {
+                stream_write_obs<0>(P.ring.obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
+                P.ring.act[slot * N + a] = (uint8_t)ai;
+            }
+        }
+        float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
+        float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
+        ux *= V.sens; uy *= V.sens;
+        if (V.fscale != 1.0f) { ux = V.fscale * ux; uy = V.fscale * uy; }
+        float fx = ux + 0.0f, fy = uy + 0.0f;
+        near_force_loop<uint64_t, float2>(live ? near : 0, pp, px, py, V.dist_min, k, cf, fx, fy);
+        vx = vx * damp; vy = vy * damp;
+        vx = vx + (fx / mass) * dt;
+        vy = vy + (fy / mass) * dt;
+        px = px + vx * dt;
+        py = py + vy * dt;
         wave_lds_sync();
         if (live) s_pos[base + a] = make_float2(px, py);
         wave_lds_sync();
@@ -268,9 +406,9 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
         ep_step += 1;
         const bool term = V.max_episode_len > 0 && ep_step >= V.max_episode_len;
         if (SINK && live && a == 0 && P.episode_return) {  // run.py:55-65, per env
-            const float rsum = ep_ret + acc;
-            if (term) { fin_sum += (double)rsum; fin_cnt += 1; ep_ret = 0.0f; }
-            else ep_ret = rsum;
+            const float rsum = S.s_ret[el] + acc;
+            if (term) { S.s_fs[el] += (double)rsum; S.s_fc[el] += 1; S.s_ret[el] = 0.0f; }
+            else S.s_ret[el] = rsum;
         }
         if (live) {
             if (P.act_out) P.act_out[tBN + g] = ai;
@@ -297,18 +435,27 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
                 pw_reset_xy(V.seed, env_id, ep_count, (uint32_t)(N + la), -1.0f, 1.0f, &olx, &oly);
                 if (live && a < L) lmv[la] = make_float2(olx, oly);
             }
-            if (live) s_pos[base + a] = make_float2(px, py);
         }
         wave_lds_sync();
-        if (V.auto_reset && __any(term))
+        if (V.auto_reset && __any(term)) {   // post-reset positions: the masks of the next step
+            if (live) s_pos[base + a] = make_float2(px, py);
+            wave_lds_sync();
             stream_partner_pass<0, uint64_t>(N, a, pp, px, py, olx, oly, V.coll_thr2, V.near_thr2, coll, near, best);
+        }
         if (live) {
             if (V.obs) stream_write_obs<0>(V.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
             S.s_st[r] = make_float4(vx, vy, px, py);
+            if (HALF) S.s_near[r] = near;
+            if (a == 0) { S.s_eps[el] = ep_step; S.s_epc[el] = ep_count; }
+        }
+        if (!HALF) {
+            r_vx = vx; r_vy = vy; r_px = px; r_py = py; r_olx = olx; r_oly = oly;
+            r_ep_step = ep_step; r_ep_count = ep_count; r_near = near;
         }
     };
 
     for (int t = 0; t < P.T; ++t) {
+        const uint64_t step = step0 + (uint64_t)t;
         // ---- the pass's landmark registers, the first two timesteps' dense1, the first input projection
 #pragma unroll
         for (int s = 1; s < KS; ++s) {
@@ -326,6 +473,12 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
             wg_lds_barrier();                        // ... before anybody's iteration 0 overwrites it
             for (int s2 = 0; s2 < N; ++s2) {
                 const int ts = dir ? N - 1 - s2 : s2;
+                if (HALF && s2 > 0) {  // the timesteps the barrier of iteration s2 - 1 completed: their heads, on two rotating waves
+                    const int p = s2 - 1, tsF = p, tsB = N - 1 - p;
+                    const float4 *hxp = S.s_hx + ((p & 1) * 2) * 2 * 64;   // [dir][2 j][64]: both directions' h of iteration p
+                    if (2 * tsF > N - 1 && wave == ((2 * p) & 7)) head_ts(tsF, hxp, S.s_hf + tsF * 128, step);            // backward was there first
+                    if (2 * tsB <= N - 1 && wave == ((2 * p + 5) & 7)) head_ts(tsB, S.s_hf + tsB * 128, hxp + 128, step);   // forward was there first
+                }
                 if (s2 > 0) {
                     const float4 *hx = S.s_hx + ((((s2 - 1) & 1) * 2 + dir) * 2) * 64 + lane;
                     const float4 h0 = hx[0], h1 = hx[64];
@@ -350,7 +503,11 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
                 lstm_cell(acc[0][0], acc[0][1], acc[0][2], acc[0][3], c0, h0v);
                 lstm_cell(acc[1][0], acc[1][1], acc[1][2], acc[1][3], c1, h1v);
                 reinterpret_cast<float2 *>(S.s_hx + (((s2 & 1) * 2 + dir) * 2 + (hq >> 1)) * 64 + lane)[hq & 1] = make_float2(h0v, h1v);
-                if (seq_ok) {
+                if (HALF) {
+                    // this direction is the FIRST visitor of ts (forward: 2 ts <= N - 1, backward: 2 ts > N - 1): its h(ts) is kept for the head
+                    if (dir ? 2 * ts > N - 1 : 2 * ts <= N - 1)
+                        reinterpret_cast<float2 *>(S.s_hf + ts * 128 + (hq >> 1) * 64 + lane)[hq & 1] = make_float2(h0v, h1v);
+                } else if (seq_ok) {
                     const int rr = n16 * NP + ts;
                     reinterpret_cast<float2 *>(S.s_hf + ((rr >> 4) * 4 + 2 * dir + (hq >> 1)) * 64 + kq * 16 + (rr & 15))[hq & 1] =
                         make_float2(A.relu_out ? fmaxf(h0v, 0.0f) : h0v, A.relu_out ? fmaxf(h1v, 0.0f) : h1v);
@@ -363,50 +520,44 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
                 if (s2 + 1 < N) { acc[0] = accn[0]; acc[1] = accn[1]; }
             }
         }
-        head(step0 + (uint64_t)t);  // one barrier inside
-
-        // ---- environment step (pw_spread_stream_kernel's arithmetic)
-        if (env_wave) {
-            ai = S.s_act[r];
-            if (SINK && P.has_ring) {  // the observation the policy acted on: rebuilt from the (still pre-step) registers
-                slot = ring_slot(P.ring_start, t, A.B, (long)env, P.ring.capacity);
-                if (live) {
-                    stream_write_obs<0>(P.ring.obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
-                    P.ring.act[slot * N + a] = (uint8_t)ai;
-                }
-            }
-            float ux = 0.0f + ((ai == 1 ? 1.0f : 0.0f) - (ai == 2 ? 1.0f : 0.0f));
-            float uy = 0.0f + ((ai == 3 ? 1.0f : 0.0f) - (ai == 4 ? 1.0f : 0.0f));
-            ux *= V.sens; uy *= V.sens;
-            if (V.fscale != 1.0f) { ux = V.fscale * ux; uy = V.fscale * uy; }
-            float fx = ux + 0.0f, fy = uy + 0.0f;
-            near_force_loop<uint64_t, float2>(live ? near : 0, pp, px, py, V.dist_min, k, cf, fx, fy);
-            vx = vx * damp; vy = vy * damp;
-            vx = vx + (fx / mass) * dt;
-            vy = vy + (fy / mass) * dt;
-            px = px + vx * dt;
-            py = py + vy * dt;
-            env_finish(t);
+        if (HALF) {  // the last iteration completed timesteps N - 1 (forward) and 0 (backward)
+            const int p = N - 1;
+            const float4 *hxp = S.s_hx + ((p & 1) * 2) * 2 * 64;
+            if (2 * p > N - 1 && wave == ((2 * p) & 7)) head_ts(p, hxp, S.s_hf + p * 128, step);
+            if (0 <= N - 1 && wave == ((2 * p + 5) & 7)) head_ts(0, S.s_hf, hxp + 128, step);
+            wg_lds_barrier();   // every timestep's logits are in LDS
+            sample_all(step);
+            wg_lds_barrier();
+        } else {
+            head_rows(step);  // one barrier inside
         }
+
+        // ---- environment step: every slot of this wave
+        if (env_wave)
+            for (int vw = ew; vw < n_vwaves; vw += 8) env_step(t, vw);
         wg_lds_barrier();  // the next states (and, after a reset, landmarks) are in LDS
     }
 
-    if (live) {
-        V.pos_x[g] = px; V.pos_y[g] = py;
-        V.vel_x[g] = vx; V.vel_y[g] = vy;
-        if (L > 0 && a < L) {
-            V.lm_x[(size_t)env * L + la] = olx;
-            V.lm_y[(size_t)env * L + la] = oly;
-        }
-        if (a == 0) {
-            V.ep_step[env] = ep_step;
-            V.ep_count[env] = ep_count;
-            if (SINK && P.episode_return) P.episode_return[env] = ep_ret;
+    if (env_wave) {   // the workgroup's state: LDS -> global planes
+        for (int vw = ew; vw < n_vwaves; vw += 8) {
+            const EnvLane q = env_lane(vw);
+            if (q.live) {
+                const float4 st = S.s_st[q.r];
+                V.vel_x[q.g] = st.x; V.vel_y[q.g] = st.y; V.pos_x[q.g] = st.z; V.pos_y[q.g] = st.w;
+                if (L > 0 && q.a < L) {
+                    const float2 o = S.s_lmb[q.el * L + q.la];
+                    V.lm_x[(size_t)q.env * L + q.la] = o.x;
+                    V.lm_y[(size_t)q.env * L + q.la] = o.y;
+                }
+                if (q.a == 0) {
+                    V.ep_step[q.env] = S.s_eps[q.el];
+                    V.ep_count[q.env] = S.s_epc[q.el];
+                    if (SINK && P.episode_return) P.episode_return[q.env] = S.s_ret[q.el];
+                }
+            }
         }
     }
     if (SINK && P.episode_return) {
-        wg_lds_barrier();
-        if (live && a == 0) { S.s_fs[el] = fin_sum; S.s_fc[el] = fin_cnt; }
         wg_lds_barrier();
         rollout_finish_stats(envs_here, S.s_fs, S.s_fc, P.scratch, P.finished_sum, P.finished_count, smem_raw);
     }

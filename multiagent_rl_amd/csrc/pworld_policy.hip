@@ -303,12 +303,23 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     // N = 30: 494 / - / 100; N = 48: - / - / 342.  Automatic wherever the plain third form does not keep its 16 columns busy; policy_form 4 forces it
     // (tests run it at small N too).
     int E3j = 0, NPj = kp.N;
+    bool halfj = S1C >= 9;   // the kernel's half-storage head (pw_kernels_policy3j.hpp): always beyond 64-number rows, by need at S1C = 7, 8
     if (!tag && kp.D == 4 + 2 * kp.L && kp.L <= kp.N && !a.bf16x3 && (form == 4 || (form == 0 && !use_v3))) {
-        const int ecap = 8 * (kWave / kp.N) < 16 ? 8 * (kWave / kp.N) : 16;   // at most 8 environment waves of whole environments
-        for (int e = kp.B < ecap ? kp.B : ecap; e >= 1; --e)
-            if (roll3j_lds_bytes(e, kp.N, kp.L) <= 160 * 1024) { E3j = e; break; }
+        // 16 environments = the 16 MFMA columns.  Full head input (256 B per agent in LDS, the lanes' state in registers: one slot per
+        // environment wave, i.e. at most 8 x (64 / N) environments) wherever that leaves room for all 16; otherwise -- rows of more than 48
+        // numbers only: N >= 30 -- the half-storage head with environment slots (pw_kernels_policy3j.hpp; until round 5 such workgroups held 8).
+        const int want = kp.B < 16 ? kp.B : 16;
+        if (!halfj) {
+            const int ecap = 8 * (kWave / kp.N) < want ? 8 * (kWave / kp.N) : want;
+            for (int e = ecap; e >= 1; --e)
+                if (roll3j_lds_bytes(e, kp.N, kp.L, false) <= 160 * 1024) { E3j = e; break; }
+        }
+        if (S1C >= 7 && E3j < want) {
+            for (int e = want; e > E3j; --e)
+                if (roll3j_lds_bytes(e, kp.N, kp.L, true) <= 160 * 1024) { E3j = e; halfj = true; break; }
+        }
         // an odd LDS row stride (no bank conflicts between the sixteen sequences: pw_kernels_policy3j.hpp) wherever it costs no environment
-        if (E3j > 0 && roll3j_lds_bytes(E3j, kp.N | 1, kp.L) <= 160 * 1024) NPj = kp.N | 1;
+        if (E3j > 0 && roll3j_lds_bytes(E3j, kp.N | 1, kp.L, halfj) <= 160 * 1024) NPj = kp.N | 1;
     }
     if (form == 4 && E3j == 0) return fail(PW_EINVAL, "policy_form 4 (just-in-time dense1) serves the local observation with L <= N");
     if (wide && (E3j == 0 || (form != 0 && form != 4)))
@@ -318,18 +329,20 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     if (!use_v3 && E3j > 0 && (form == 4 || wide || E3j >= (kp.B < 8 ? kp.B : 8))) {
         a.E = E3j;
         P.NP = NPj;
-        const size_t shmj = roll3j_lds_bytes(E3j, NPj, kp.L);
+        const size_t shmj = roll3j_lds_bytes(E3j, NPj, kp.L, halfj);
         const unsigned gridj = (unsigned)((kp.B + E3j - 1) / E3j);
-#define PW_R3J2(C, SK)                                                                                                   \
+#define PW_R3J2(C, SK, HF)                                                                                               \
     do {                                                                                                                 \
         static unsigned long long attr_setj = 0; /* bit = device */                                                      \
-        PW_LDS_OPTIN(&attr_setj, (pw_policy_rollout3j_kernel<C, SK>));                                                   \
-        hipLaunchKernelGGL((pw_policy_rollout3j_kernel<C, SK>), dim3(gridj), dim3(512), shmj, st, P);                    \
+        PW_LDS_OPTIN(&attr_setj, (pw_policy_rollout3j_kernel<C, SK, HF>));                                               \
+        hipLaunchKernelGGL((pw_policy_rollout3j_kernel<C, SK, HF>), dim3(gridj), dim3(512), shmj, st, P);                \
     } while (0)
-#define PW_R3J(C) case C: if (sink) PW_R3J2(C, true); else PW_R3J2(C, false); break;
-        switch (S1C) {
-            PW_R3J(1) PW_R3J(2) PW_R3J(3) PW_R3J(4) PW_R3J(5) PW_R3J(6) PW_R3J(7) PW_R3J(8)
-            PW_R3J(9) PW_R3J(10) PW_R3J(11) PW_R3J(12) PW_R3J(13)     // D = 65 .. 104 (N = L = 31 .. 50)
+#define PW_R3J(C, HF) case C: if (sink) PW_R3J2(C, true, HF); else PW_R3J2(C, false, HF); break;
+        if (halfj) switch (S1C) {
+            PW_R3J(7, true) PW_R3J(8, true)
+            PW_R3J(9, true) PW_R3J(10, true) PW_R3J(11, true) PW_R3J(12, true) PW_R3J(13, true)     // D = 65 .. 104 (N = L = 31 .. 50)
+        } else switch (S1C) {
+            PW_R3J(1, false) PW_R3J(2, false) PW_R3J(3, false) PW_R3J(4, false) PW_R3J(5, false) PW_R3J(6, false) PW_R3J(7, false) PW_R3J(8, false)
         }
 #undef PW_R3J2
 #undef PW_R3J
