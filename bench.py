@@ -889,7 +889,9 @@ def policy_in_loop(args, stub_env, rank, world, dev, use_dist, sync):
                 ('simple_spread N=12, B=4096 (the reference\'s largest scalability setting)',
                  lambda: BatchedParticleEnv('simple_spread', 4096, num_agents=12, max_episode_len=25, auto_reset=True, seed=12345678), 5, 1e6),
                 ('simple_spread N=24, B=4096 (C5 point; just-in-time form)',
-                 lambda: BatchedParticleEnv('simple_spread', 4096, num_agents=24, max_episode_len=25, auto_reset=True, seed=12345678), 5, 1e6)):
+                 lambda: BatchedParticleEnv('simple_spread', 4096, num_agents=24, max_episode_len=25, auto_reset=True, seed=12345678), 5, 1e6),
+                ('simple_spread N=48, B=4096 (C5 point; just-in-time form, half-storage head)',
+                 lambda: BatchedParticleEnv('simple_spread', 4096, num_agents=48, max_episode_len=25, auto_reset=True, seed=12345678), 5, 5e5)):
             try:
                 o_env = mk_env()
                 o_env.set_actor_precision('f32')     # whatever the process environment says: these rollouts serve float32 only

@@ -216,3 +216,55 @@ def test_integration_doc_stub_matches_the_abi_structs():
     hdr = open(os.path.join(root, 'include', 'pworld.h')).read()
     for name in set(re.findall(r'`(pw_[a-z_0-9]+)`', doc)):
         assert re.search(r'\b%s\b' % name, hdr), name
+
+
+def test_wire_layouts_of_every_scenario_at_baseline_sizes():
+    """Host arithmetic of the wire blocks (no GPU): bytes per env-step at the BASELINE shapes -- simple_spread C2 114 B (row block 414),
+    simple_tag C3 (4 + 2, L = 2, B = 8192) <= 150 B (row block 539), simple_reference <= 80 B (row block 181) -- and what the layouts refuse."""
+    lib = _lib.load()
+    T = 100
+    sw = _lib.PwStateWire()
+    assert lib.pw_state_wire_layout_scn(_lib.PW_SIMPLE_SPREAD, T, 4096, 6, 6, 0, 25, C.byref(sw)) == 0
+    assert (sw.D, sw.F, sw.scenario, sw.num_adversaries) == (16, 4, _lib.PW_SIMPLE_SPREAD, 0) and 113.0 < sw.total_bytes / (T * 4096.0) < 116.0
+    old = _lib.PwStateWire()
+    assert lib.pw_state_wire_layout(T, 4096, 6, 6, 25, C.byref(old)) == 0 and bytes(old) == bytes(sw)       # the 0.1.5 entry point = the spread case
+    assert lib.pw_state_wire_layout_scn(_lib.PW_SIMPLE_TAG, T, 8192, 6, 2, 4, 25, C.byref(sw)) == 0
+    assert (sw.D, sw.F, sw.scenario, sw.num_adversaries) == (22, 4, _lib.PW_SIMPLE_TAG, 4)
+    tag_bytes = sw.total_bytes / (T * 8192.0)
+    cw = _lib.PwChunkWire()
+    assert lib.pw_chunk_wire_layout(T, 8192, 6, 22, 25, C.byref(cw)) == 0
+    assert tag_bytes <= 150.0 and tag_bytes < 0.25 * cw.total_bytes / (T * 8192.0)
+    assert lib.pw_state_wire_layout_scn(_lib.PW_SIMPLE_TAG, T, 8192, 6, 2, 7, 25, C.byref(sw)) < 0            # more adversaries than agents
+    assert lib.pw_state_wire_layout_scn(_lib.PW_SIMPLE_REFERENCE, T, 4096, 2, 3, 0, 25, C.byref(sw)) < 0     # its own compact-row layout
+    rw = _lib.PwRefWire()
+    assert lib.pw_ref_wire_layout(T, 4096, 25, C.byref(rw)) == 0 and rw.F == 4 and rw.total_bytes % 256 == 0
+    ref_bytes = rw.total_bytes / (T * 4096.0)
+    assert lib.pw_chunk_wire_layout(T, 4096, 2, 21, 25, C.byref(cw)) == 0
+    assert ref_bytes <= 80.0 and ref_bytes < 0.45 * cw.total_bytes / (T * 4096.0)
+    assert lib.pw_ref_wire_layout(1000, 8, 2, C.byref(rw)) < 0 and b'126' in lib.pw_last_error()
+
+
+def test_state_ring_arguments_are_checked_on_the_host():
+    """A STATE ring (pw_replay_store.state_rows) is filled by pw_replay_add_state_wire and read by pw_replay_gather only; every other writer and
+    every inconsistent shape is refused before anything is launched (no GPU needed)."""
+    lib = _lib.load()
+    st = _lib.PwReplayStore()
+    st.obs, st.next_obs, st.rew, st.done, st.act, st.lm = 4096, 8192, 12288, 16384, 20480, 24576      # fake, aligned "device pointers"
+    st.capacity, st.num_agents, st.obs_dim = 1000, 6, 16
+    st.state_rows, st.num_landmarks, st.scenario, st.num_adversaries = 1, 6, _lib.PW_SIMPLE_SPREAD, 0
+    p = C.c_void_p(4096)
+    assert lib.pw_replay_add(C.byref(st), 0, None, 4, p, p, p, p, None, None, None, None) < 0 and b'STATE ring' in lib.pw_last_error()
+    io = _lib.PwStepIO()
+    io.obs = io.rew_shared = io.terminal = 4096
+    assert lib.pw_replay_add_rollout(C.byref(st), 0, 4, 2, p, C.byref(io), p, None, None, None, None, None) < 0
+    assert b'STATE ring' in lib.pw_last_error()
+    assert lib.pw_replay_add_packed(C.byref(st), 0, 4, p, None) < 0 and b'STATE ring' in lib.pw_last_error()
+    idx = C.c_void_p(4096)
+    st.obs_dim = 18                                                        # not 4 + 2L
+    assert lib.pw_replay_gather(C.byref(st), idx, 4, p, p, p, p, p, None) < 0 and b'STATE ring' in lib.pw_last_error()
+    st.obs_dim, st.act_heads = 16, 2
+    assert lib.pw_replay_gather(C.byref(st), idx, 4, p, p, p, p, p, None) < 0
+    st.act_heads, st.scenario, st.num_adversaries, st.num_landmarks, st.obs_dim = 0, _lib.PW_SIMPLE_TAG, 4, 2, 22
+    sw = _lib.PwStateWire()
+    assert lib.pw_state_wire_layout_scn(_lib.PW_SIMPLE_SPREAD, 10, 8, 6, 6, 0, 25, C.byref(sw)) == 0
+    assert lib.pw_replay_add_state_wire(C.byref(st), 0, C.byref(sw), C.c_void_p(1 << 20), None) < 0          # a spread block into a tag ring

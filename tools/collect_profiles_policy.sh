@@ -8,7 +8,7 @@
 #   rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE                      (separate passes: MI355X guide)
 # (counter passes carry no trace flags: gpurun refuses the mix) and tools/summarize_policy_prof.py turns each into
 # gpurun_out/prof_${RT}p/summaries/${RT}_policy_<tag>_summary.json, copied into profiles/.
-# Usage: [RT=r5] tools/collect_profiles_policy.sh [tag ...]   (default: c2 tag ref n12 n24)
+# Usage: [RT=r5] tools/collect_profiles_policy.sh [tag ...]   (default: c2 tag ref n12 n24 n48)
 set -o pipefail
 R=$PWD
 RT=${RT:-r5}
@@ -16,8 +16,8 @@ O=$R/gpurun_out/prof_${RT}p
 mkdir -p $O/summaries
 cd /tmp; export TMPDIR=/tmp
 # tag | kernel family
-CONFIGS=("c2|pw_policy_rollout3_kernel" "tag|pw_policy_rollout_tag_kernel" "ref|pw_policy_rollout_ref_kernel" "n12|pw_policy_rollout3_kernel" "n24|pw_policy_rollout")
-DEFAULT=" c2 tag ref n12 n24 "
+CONFIGS=("c2|pw_policy_rollout3_kernel" "tag|pw_policy_rollout_tag_kernel" "ref|pw_policy_rollout_ref_kernel" "n12|pw_policy_rollout3_kernel" "n24|pw_policy_rollout" "n48|pw_policy_rollout")
+DEFAULT=" c2 tag ref n12 n24 n48 "
 want=" $* "
 for c in "${CONFIGS[@]}"; do
   IFS='|' read -r tag kern <<< "$c"

@@ -48,7 +48,7 @@ def main():
         env.set_dispatch(policy_form=a.form)
     two = isinstance(heads, list)
     actor = FusedActor(ActorNetwork(env.obs_dim, heads).to(dev).eval(), seed=12345678)
-    mem = ReplayBuffer(int(8e6 if two else 1e6), env.n, env.obs_dim, **(dict(act_heads=(5, 10)) if two else {}))
+    mem = ReplayBuffer(int(8e6 if two else 5e5 if env.n > 32 else 1e6), env.n, env.obs_dim, **(dict(act_heads=(5, 10)) if two else {}))
     ro = BatchedRollout(env, actor, mem)
     T = a.chunk
     t_r = time.perf_counter()
