@@ -86,6 +86,7 @@ def main(argv=None):
                 gather.prime()
             hist = train_batched(env, actor, critic, Trainer, scenario_name, action_type, cnt=cnt, out_dir=args.out_dir,
                                  chunk=args.chunk, max_updates_per_chunk=args.max_updates_per_chunk, gather=gather,
+                                 ring='state' if (gather is None and scenario_name in ('simple_spread', 'simple_tag')) else 'rows',
                                  rank=rank, world=world, log=print if rank == 0 else (lambda *a: None))
             results.append((scenario_name, cnt, hist['stats']))
             if rank == 0:

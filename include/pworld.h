@@ -241,8 +241,8 @@ size_t pw_algorithmic_bytes_per_env_step(const pw_handle *h);
  *     pw_replay_gather REBUILDS the rows it returns ([b,N,D]; every entry is the state itself or one float32 subtraction, so the
  *     batch is bit-identical to the row ring's).  scenario / num_landmarks / num_adversaries name the row layout: PW_SIMPLE_SPREAD
  *     with the local observation (D = 4 + 2L) or PW_SIMPLE_TAG (D = 4 + 2L + 2(N - 1) + 2(N - A), good agents' rows zero-padded).
- *     Filled by pw_replay_add_state_wire only (a row cannot be turned back into the landmarks it was built from); every other
- *     writer returns PW_EINVAL.  Plain single-head, shared-reward rings only. */
+ *     Filled by pw_replay_add_state_wire and by the pw_policy_rollout ring sink (which hold the state itself); the writers that are
+ *     handed ROWS return PW_EINVAL (a row cannot be turned back into the landmarks it was built from).  Plain single-head, shared-reward rings only. */
 typedef struct pw_replay_store {
     float *obs, *next_obs, *rew, *done;
     uint8_t *act;
@@ -472,7 +472,10 @@ int pw_actor_fused(const float *X, const float *frag, const float *b1, const flo
  * (ring_start + t*B + env) % capacity -- the order of T pw_replay_add calls; next_obs = the PRE-reset observation)
  * and the episode returns are kept in the same launch (episode_return [B] running returns, finished_sum /
  * finished_count accumulated reproducibly; scratch = pw_policy_rollout_scratch_bytes(h) device bytes, zeroed once).
- * ring may be NULL (bookkeeping only) and episode_return may be NULL (ring only). */
+ * ring may be NULL (bookkeeping only) and episode_return may be NULL (ring only).  0.1.6: the ring may be a STATE ring
+ * (pw_replay_store.state_rows) of the handle's scenario (simple_spread with the local observation, simple_tag): the launch then leaves
+ * {vel, pos} of every agent before / after the step and the episode's landmarks per transition -- 254 B at C2 instead of 782 -- and
+ * pw_replay_gather rebuilds the rows when a batch is sampled (bit-identical to the row ring's batch). */
 typedef struct pw_rollout_sink {
     const pw_replay_store *ring;
     int64_t ring_start;

@@ -84,6 +84,20 @@ __device__ __forceinline__ float shfl_add_ordered(float acc, const float v, cons
     return acc;
 }
 
+// Ring sink of the one-launch rollouts into a STATE ring (pw_replay_store.state_rows: the planes hold {vx, vy, px, py} per agent and the episode's
+// landmarks per transition; pw_replay_gather rebuilds the rows): the pre-step state + this lane's landmarks, and the post-step (pre-reset) state.
+__device__ __forceinline__ void sink_state_obs(const pw_replay_store &ring, const size_t slot, const int N, const int a, const int L,
+                                               const float2 *lmv, const float px, const float py, const float vx, const float vy)
+{
+    reinterpret_cast<float4 *>(ring.obs)[slot * N + a] = make_float4(vx, vy, px, py);
+    for (int l = a; l < L; l += N) reinterpret_cast<float2 *>(ring.lm)[slot * L + l] = lmv[l];
+}
+__device__ __forceinline__ void sink_state_next(const pw_replay_store &ring, const size_t slot, const int N, const int a, const float px,
+                                                const float py, const float vx, const float vy)
+{
+    reinterpret_cast<float4 *>(ring.next_obs)[slot * N + a] = make_float4(vx, vy, px, py);
+}
+
 // Ring slot of transition (t, env) of a chunk that starts at ring_start: (ring_start + t * B + env) mod capacity WITHOUT the 64-bit
 // division (~150 instructions on the environment waves' critical path, every step): the host guarantees 0 <= ring_start < capacity and
 // T * B <= capacity, so the sum is below 2 * capacity and one conditional subtraction is the modulo.

@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
     if (!live) { e_loc = 0; a = 0; el = env_wave ? ew * epw : 0; }
     const int base = e_loc * N, r = el * N + a;
     const long env = env0 + el;
-    const uint32_t g = (uint32_t)env * (uint32_t)N + (uint32_t)a;
+    const uint32_t g_lane = (uint32_t)env * (uint32_t)N + (uint32_t)a, g = g_lane;
     float2 *s_pos = S.s_posb + (env_wave ? ew : 0) * kWave;
     const float2 *pp = s_pos + base;
     float2 *lmv = S.s_lmb + el * L;
@@ -295,8 +295,13 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
             else ep_ret = rsum;
         }
     };
+    // `opaque`: the lane's launch-invariant global index passes through an empty asm wherever it feeds an output address -- otherwise every
+    // `pointer + g` of the step's stores is computed once per launch and kept in a register pair for the whole kernel (what pushed the widest
+    // instantiations over the 256-register cap: pw_kernels_policy_tag.hpp has the same device).
+    auto opaque = [](const uint32_t v) { uint32_t x = v; asm volatile("" : "+v"(x)); return x; };
     auto tail_stores = [&](const int t, const bool with_obs) {  // with_obs: V.obs too (no reset in between: the same row)
         const size_t tBN = (size_t)t * BN;
+        const uint32_t g = opaque(g_lane);
         if (live) {
             if (P.act_out) P.act_out[tBN + g] = ai;
             if (V.rew) V.rew[tBN + g] = t_rw;
@@ -306,7 +311,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
                 if (V.terminal) V.terminal[(size_t)t * A.B + env] = t_term ? 1 : 0;
             }
             if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
-                stream_write_obs<LT>(P.ring.next_obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
+                if (P.ring.state_rows) sink_state_next(P.ring, slot, N, a, px, py, vx, vy);
+                else stream_write_obs<LT>(P.ring.next_obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
                 if (a == 0) { P.ring.rew[slot] = t_acc; P.ring.done[slot] = 0.0f; }
             }
             if (with_obs && V.obs) stream_write_obs<LT>(V.obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
@@ -314,6 +320,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
     };
     auto env_step_with_reset = [&](const int t) {
         const size_t tBN = (size_t)t * BN;
+        const uint32_t g = opaque(g_lane);
         tail_compute();
         tail_stores(t, false);
         const bool term = t_term;
@@ -455,9 +462,13 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3_kernel(const PolicyRol
             if (SINK && P.has_ring) {  // the observation the policy acted on (still in LDS) -> ring.obs
                 slot = ring_slot(P.ring_start, t, A.B, (long)env, P.ring.capacity);
                 if (live) {
-                    const float2 *src = reinterpret_cast<const float2 *>(S.s_obs + r * DS);
-                    float2 *dst = reinterpret_cast<float2 *>(P.ring.obs + (slot * N + a) * D);
-                    for (int c = 0; c < D / 2; ++c) dst[c] = src[c];
+                    if (P.ring.state_rows) {   // the state the policy acted on (still in the registers) + the episode's landmarks
+                        sink_state_obs(P.ring, slot, N, a, L, lmv, px, py, vx, vy);
+                    } else {
+                        const float2 *src = reinterpret_cast<const float2 *>(S.s_obs + r * DS);
+                        float2 *dst = reinterpret_cast<float2 *>(P.ring.obs + (slot * N + a) * D);
+                        for (int c = 0; c < D / 2; ++c) dst[c] = src[c];
+                    }
                     P.ring.act[slot * N + a] = (uint8_t)ai;
                 }
             }

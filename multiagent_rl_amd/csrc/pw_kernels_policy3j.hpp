@@ -380,7 +380,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
         if (SINK && P.has_ring) {  // the observation the policy acted on: rebuilt from the (still pre-step) state
             slot = ring_slot(P.ring_start, t, A.B, (long)env, P.ring.capacity);
             if (live) {
-                stream_write_obs<0>(P.ring.obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
+                if (P.ring.state_rows) sink_state_obs(P.ring, slot, N, a, L, lmv, px, py, vx, vy);
+                else stream_write_obs<0>(P.ring.obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
                 P.ring.act[slot * N + a] = (uint8_t)ai;
             }
         }
@@ -419,7 +420,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
                 if (V.terminal) V.terminal[(size_t)t * A.B + env] = term ? 1 : 0;
             }
             if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
-                stream_write_obs<0>(P.ring.next_obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
+                if (P.ring.state_rows) sink_state_next(P.ring, slot, N, a, px, py, vx, vy);
+                else stream_write_obs<0>(P.ring.next_obs + (slot * N + a) * D, L, lmv, px, py, vx, vy);
                 if (a == 0) { P.ring.rew[slot] = acc; P.ring.done[slot] = 0.0f; }
             }
         }

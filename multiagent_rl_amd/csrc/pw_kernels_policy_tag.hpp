@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
             if (SINK && P.has_ring) {  // next_obs is the PRE-reset observation (run.py:52 vs :60)
                 const size_t slot = ring_slot(P.ring_start, t, A.B, (long)env, P.ring.capacity);
                 float *dst = P.ring.next_obs + (slot * N + a) * D;
-                if (with_obs) for (int c = 0; c < D / 2; ++c) reinterpret_cast<float2 *>(dst)[c] = row[c];
+                if (P.ring.state_rows) sink_state_next(P.ring, slot, N, a, px, py, vx, vy);
+                else if (with_obs) for (int c = 0; c < D / 2; ++c) reinterpret_cast<float2 *>(dst)[c] = row[c];
                 else write_row(dst);
                 if (a == 0) { P.ring.rew[slot] = t_acc; P.ring.done[slot] = 0.0f; }
             }
@@ -232,9 +233,13 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
             if (SINK && P.has_ring) {  // the observation the policy acted on (still in LDS) -> ring.obs
                 const size_t slot = ring_slot(P.ring_start, t, A.B, (long)env, P.ring.capacity);
                 if (live) {
-                    const float2 *src = reinterpret_cast<const float2 *>(s_obs + r * D);
-                    float2 *dst = reinterpret_cast<float2 *>(P.ring.obs + (slot * N + a) * D);
-                    for (int c = 0; c < D / 2; ++c) dst[c] = src[c];
+                    if (P.ring.state_rows) {
+                        sink_state_obs(P.ring, slot, N, a, L, lmv, px, py, vx, vy);
+                    } else {
+                        const float2 *src = reinterpret_cast<const float2 *>(s_obs + r * D);
+                        float2 *dst = reinterpret_cast<float2 *>(P.ring.obs + (slot * N + a) * D);
+                        for (int c = 0; c < D / 2; ++c) dst[c] = src[c];
+                    }
                     P.ring.act[slot * N + a] = (uint8_t)ai;
                 }
             }

@@ -204,7 +204,11 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
     if (!have_sink && (!act_out || !io->obs || !io->rew || !io->rew_shared || !io->done || !io->terminal))
         return fail(PW_EINVAL, "without a ring sink, act_out and the obs, rew, rew_shared, done, terminal outputs are required");
     if (sink) {
-        if (int rc = plain_ring_only(sink->ring, "pw_policy_rollout sink")) return rc;
+        if (sink->ring && sink->ring->state_rows) {   // a STATE ring as the sink: {vel, pos} + the episode's landmarks instead of the two rows
+            if (int rc = state_ring_ok(sink->ring, "pw_policy_rollout sink")) return rc;
+            if (sink->ring->scenario != h->cfg.scenario || sink->ring->num_landmarks != kp.L || sink->ring->num_adversaries != (tag ? kp.A : 0))
+                return fail(PW_EINVAL, "pw_policy_rollout sink: the STATE ring belongs to another scenario / shape");
+        } else if (int rc = plain_ring_only(sink->ring, "pw_policy_rollout sink")) return rc;
         if (sink->ring && (sink->ring->num_agents != kp.N || sink->ring->obs_dim != kp.D || sink->ring->capacity < 1 ||
                            sink->ring_start < 0 || sink->ring_start >= sink->ring->capacity || (int64_t)num_steps * kp.B > sink->ring->capacity))
             return fail(PW_EINVAL, "ring sink: shape mismatch or the chunk does not fit the ring");

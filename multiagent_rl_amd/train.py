@@ -110,13 +110,15 @@ def merge_histories(parts):
 
 def train_batched(env, actor, critic, Trainer, scenario_name, action_type='Discrete', cnt=0, arglist=None, memory=None,
                   out_dir='Models', log=print, chunk=100, max_updates_per_chunk=None, policy_seed=None,
-                  per_episode_history=True, gather=None, rank=0, world=1, make_rollout=None):
+                  per_episode_history=True, gather=None, rank=0, world=1, make_rollout=None, ring='rows'):
     """``experiments/run.py:run`` for a ``BatchedParticleEnv`` (auto_reset=True).  Runs until ``arglist.num_episodes`` episodes
     have finished (over all envs of this rank), then pickles the history with the reference's keys and saves the models.
     ``gather`` (a ``dist.FullTransitionGather``) switches to the multi-GPU form: every rank rolls out into the gather's wire
     block, the learner lives on rank 0.  ``make_rollout(env, actor, memory, seed) -> (fused_actor, batched_rollout)`` replaces
-    the HIP pair (tests drive the control flow without a GPU).  Returns the history dict (with ``stats``: env-steps, updates,
-    wall time)."""
+    the HIP pair (tests drive the control flow without a GPU).  ``ring='state'`` (single-rank form; simple_spread with the local
+    observation, simple_tag): the rollout's ring sink fills a STATE ring -- {vel, pos} + the episode's landmarks per transition, a
+    third of the bytes -- and ``sample_index`` rebuilds the rows the learner trains on (bit-identical batches).  Returns the history
+    dict (with ``stats``: env-steps, updates, wall time)."""
     from .replay_buffer import ReplayBuffer
     cfg = _default_arglist if arglist is None else arglist
     if action_type not in ('Discrete', 'MultiDiscrete'):
@@ -130,7 +132,13 @@ def train_batched(env, actor, critic, Trainer, scenario_name, action_type='Discr
             memory = gather.memory
         else:
             heads = tuple(int(h) for h in (env.action_space[0].high + 1)) if action_type == 'MultiDiscrete' else None
-            memory = ReplayBuffer(int(1e6), N, env.obs_dim, **(dict(act_heads=heads) if heads else {}))
+            kw = dict(act_heads=heads) if heads else {}
+            if ring == 'state':
+                if heads or getattr(env, 'scenario_name', None) not in ('simple_spread', 'simple_tag'):
+                    raise ValueError("ring='state' serves simple_spread (local observation) and simple_tag")
+                kw = dict(state_ring=dict(scenario=env.scenario_name, num_landmarks=env.num_landmarks,
+                                          num_adversaries=env.cfg.num_adversaries if env.scenario_name == 'simple_tag' else 0))
+            memory = ReplayBuffer(int(1e6), N, env.obs_dim, **kw)
     learner = Trainer(actor, critic, memory, action_type=action_type)
     seed = (cnt + 12345678 if policy_seed is None else policy_seed) + rank
     if make_rollout is None:

@@ -1011,6 +1011,50 @@ def test_reference_compact_wire_carries_the_two_head_policy_rollout():
         wire_actor.rollout(env_a, T, bad)
 
 
+@pytest.mark.parametrize('scenario,B,kw,T', [('simple_spread', 4096, dict(n=6), 60), ('simple_spread', 70, dict(n=24), 30),
+                                             ('simple_spread', 40, dict(n=33), 27), ('simple_spread', 100, dict(n=3), 55),
+                                             ('simple_tag', 8192, dict(num_adversaries=4, num_good=2), 53),
+                                             ('simple_tag', 37, dict(num_adversaries=2, num_good=3), 30)],
+                         ids=['C2-form3', 'N24-3j', 'N33-3j-half', 'N3', 'C3-tag', 'tag2+3'])
+def test_policy_rollout_sink_into_a_state_ring_samples_the_row_rings_batch(scenario, B, kw, T):
+    """The one-launch policy rollouts' own ring sink into a STATE ring (0.1.6): the launch leaves {vel, pos} before / after + the
+    episode's landmarks per transition instead of the two observation rows; sample_index on it (rows rebuilt by pw_replay_gather)
+    equals the batch of the ROW ring the same rollout fills from the same seeds, bit for bit -- every kernel form, across two resets,
+    chunks of 20 steps, a ring wrap."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    torch.manual_seed(2)
+    mk = lambda: make_batched_env(scenario, B, auto_reset=True, max_episode_len=25, seed=17, **kw)  # noqa: E731
+    env_a, env_b = mk(), mk()
+    N, D, L = env_a.n, env_a.obs_dim, env_a.num_landmarks
+    net = ActorNetwork(D, 5).cuda().eval()
+    cap = T * B - 3 * B // 2                                  # the last chunk wraps around the ring end
+    rows = ReplayBuffer(cap, N, D)
+    state = ReplayBuffer(cap, N, D, state_ring=dict(scenario=scenario, num_landmarks=L, num_adversaries=kw.get('num_adversaries', 0)))
+    for env, mem in ((env_a, rows), (env_b, state)):
+        env.reset()
+        actor = FusedActor(net, seed=5)
+        done = 0
+        while done < T:
+            n = min(20, T - done)
+            actor.rollout(env, n, False, memory=mem)
+            done += n
+    torch.cuda.synchronize()
+    assert len(rows) == len(state) == cap and rows._next_idx == state._next_idx
+    assert tuple(state.obs.shape[1:]) == (N, 4)
+    for lo in range(0, cap, 8192):
+        idx = list(range(lo, min(cap, lo + 8192)))
+        for name, x, y in zip(('obs', 'act', 'rew', 'next_obs', 'done'), state.sample_index(idx), rows.sample_index(idx)):
+            assert torch.equal(x, y), name
+    # a STATE ring of another scenario / shape is refused
+    other = ReplayBuffer(cap, N, D, state_ring=dict(scenario=scenario, num_landmarks=L + 1, num_adversaries=kw.get('num_adversaries', 0))) \
+        if scenario == 'simple_tag' else None
+    if other is not None:
+        with pytest.raises(Exception):
+            FusedActor(net, seed=5).rollout(env_a, 5, False, memory=other)
+
+
 def test_state_wire_carries_the_policy_rollout_and_stays_under_130_bytes_per_env_step():
     """C2 (B = 4096, N = 6, 100-step chunks) with the policy in the loop, as bench.py --gpus N drives it: FusedActor.rollout
     writes into FullTransitionGather.outputs(); the root ring equals the ring the same launch's own sink fills

@@ -91,10 +91,12 @@ def test_spread_policy_rollout_outputs_equal_the_oracle_on_its_own_actions(B, N,
     _assert_final_state(env, o32)
 
 
-@pytest.mark.parametrize('B,N,T', [(24, 48, 27), (11, 33, 26), (70, 40, 4)], ids=['N48', 'N33', 'N40'])
+@pytest.mark.parametrize('B,N,T', [(24, 48, 27), (11, 33, 26), (70, 40, 4), (17, 31, 27), (40, 50, 26), (33, 32, 5)],
+                         ids=['N48', 'N33', 'N40', 'N31', 'N50', 'N32'])
 def test_spread_policy_rollout_with_rows_longer_than_64_numbers(B, N, T):
     """BASELINE configs[4]'s largest point with the policy in the loop: N = L = 48 (D = 100).  Only the just-in-time form holds
-    such rows (8 environments per workgroup); its outputs equal the oracle's on its own actions bit for bit, and -- with a
+    such rows (round 5: 16 environments per workgroup -- the half-storage head, environment slots; N = 31 is the smallest such N, 50 the largest,
+    B = 17 / 24 / 40 / 70 leave ragged last workgroups); its outputs equal the oracle's on its own actions bit for bit, and -- with a
     sharpened head, so that the Gumbel noise cannot decide -- its actions are the arg-max of PyTorch's float32 logits on the
     oracle's observation rows (the per-step FusedActor does not serve D > 64, so this is the actor's own check here)."""
     from multiagent_rl_amd import make_batched_env
@@ -207,7 +209,8 @@ def _oracle_transitions(o32, obs0, acts, two_head=False):
 
 @pytest.mark.parametrize('scenario,B,kw', [('simple_spread', 256, dict(n=6)), ('simple_spread', 64, dict(n=3)),
                                           ('simple_tag', 100, dict(num_adversaries=4, num_good=2)),
-                                          ('simple_reference', 150, {})], ids=['spread6', 'spread3', 'tag4+2', 'reference'])
+                                          ('simple_reference', 150, {}), ('simple_spread', 40, dict(n=33)), ('simple_spread', 21, dict(n=24))],
+                         ids=['spread6', 'spread3', 'tag4+2', 'reference', 'spread33-half-head', 'spread24'])
 def test_collect_one_launch_ring_rows_equal_oracle_transitions(scenario, B, kw):
     """BatchedRollout.collect_one_launch: the rows the launches leave in the device ring -- obs, action, shared reward,
     pre-reset next_obs, done -- equal the transitions built from the oracle stepped with the ring's own actions."""
