@@ -26,9 +26,11 @@ for t in range(T):
     w = o.step(act_idx=acts[t])
     terms += int(w['terminal'].sum())
 assert int(lines[1].split()[1]) == terms == B, (lines[1], terms)
+ring = lines[2].split()
+assert ring[0] == 'state_ring' and ring[3:] == ['next_obs_equal', '1', 'obs_equal', '1', 'rew_equal', '1'], lines[2]   # the C side's own bitwise check
 assert np.array_equal(got['o'], w['obs'].reshape(-1).view(np.uint32)), 'observations differ'
 assert np.array_equal(got['r'], w['rew'].reshape(-1).view(np.uint32)), 'rewards differ'
 shared = ((np.float32(0) + w['rew'][:, 0]) + w['rew'][:, 1]) + w['rew'][:, 2]
 assert np.array_equal(got['s'], shared.view(np.uint32)), 'shared rewards differ'
-print('c_host ok: %d observations, %d rewards, %d shared rewards identical to the float32 oracle; %s' % (
-    got['o'].size, got['r'].size, got['s'].size, lines[0]))
+print('c_host ok: %d observations, %d rewards, %d shared rewards identical to the float32 oracle; state-only wire block (%s B per env-step) -> STATE ring -> '
+      'pw_replay_gather rebuilt the rows bit for bit; %s' % (got['o'].size, got['r'].size, got['s'].size, ring[2], lines[0]))
