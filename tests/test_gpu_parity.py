@@ -273,6 +273,39 @@ def test_every_step_resets_matches_oracle_bitwise(case):
     _assert_same_bits(_np(st['landmarks']), o32.lm, 'landmarks')
 
 
+@pytest.mark.parametrize('ep_len', [2, 3])
+@pytest.mark.parametrize('case', [
+    dict(scenario='simple_tag', num_agents=6, num_adversaries=4, num_envs=8192),
+    dict(scenario='simple_tag', num_agents=3, num_adversaries=2, num_landmarks=3, num_envs=77),
+    dict(scenario='simple_spread', num_agents=3, num_envs=4096),
+    dict(scenario='simple_spread', num_agents=6, num_envs=4096),
+    dict(scenario='simple_spread', num_agents=12, num_envs=4096),
+], ids=['tag4+2', 'tag2+1', 'spread3', 'spread6', 'spread12'])
+def test_very_short_episodes_on_the_multi_wave_forms_match_oracle_bitwise(case, ep_len):
+    """Episodes of 2 and 3 steps under the DEFAULT dispatch (the multi-wave forms: quad / duo / trio): a reset every second or third step
+    is the tightest schedule their LDS ring serves (two slots in a resetting step, the physics wave one step ahead) -- every output of
+    every step, the pre-reset rows included, against the float32 oracle."""
+    T = 13
+    env, cfg = _mk(max_episode_len=ep_len, auto_reset=True, seed=5, want_coll=False, **case)
+    B, N = env.num_envs, env.n
+    acts = np.random.RandomState(4).randint(0, 5, (T, B, N)).astype(np.int32)
+    o32 = co.COracle(cfg, B, np.float32)
+    _assert_same_bits(_np(env.reset()), o32.reset(), 'reset obs')
+    out = env.rollout(torch.from_numpy(acts))
+    assert any(k in env.last_kernel() for k in ('duo', 'quad')), env.last_kernel()
+    for t in range(T):
+        w = o32.step(act_idx=acts[t])
+        for name in ('obs', 'rew', 'rew_shared'):
+            _assert_same_bits(_np(out[name][t]), w[name], '%s[%d]' % (name, t))
+        _assert_same_bits(_np(out['terminal'][t]).astype(np.uint8), w['terminal'], 'terminal[%d]' % t)
+        if w['terminal'].any():
+            _assert_same_bits(_np(out['final_obs'][t]), w['final_obs'], 'final_obs[%d]' % t)
+    assert (T // ep_len) >= 4
+    st = env.get_state()
+    _assert_same_bits(_np(st['pos']), o32.pos, 'pos')
+    _assert_same_bits(_np(st['landmarks']), o32.lm, 'landmarks')
+
+
 def test_rollout_equals_repeated_steps_and_onehot_equals_index():
     T = 30
     rng = np.random.RandomState(11)
