@@ -29,10 +29,19 @@ __device__ __forceinline__ float fast_tanh(float x)
 
 // One LSTM cell (PyTorch's gate order i, f, g, o): pre-activations -> new cell state c and output h.  Every kernel form calls this
 // one function, so the forms agree bit for bit whatever the activations' rounding is.
+// (The four gates' exponent arguments and denominators are formed two at a time -- (i, f) and (g, o) sit in adjacent accumulator registers --
+// so that they compile to packed multiplies / adds; the operations and their bits are those of fast_sigmoid / fast_tanh.)
 __device__ __forceinline__ void lstm_cell(const float gi, const float gf, const float gg, const float go, float &c, float &h)
 {
-    c = fast_sigmoid(gf) * c + fast_sigmoid(gi) * fast_tanh(gg);
-    h = fast_sigmoid(go) * fast_tanh(c);
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    const v2 a = v2{gi, gf} * v2{-1.4426950408889634f, -1.4426950408889634f};   // exp(-x) = 2^(-log2(e) x)
+    const v2 b = v2{gg, go} * v2{-2.8853900817779268f, -1.4426950408889634f};   // tanh's exp(-2x) for g
+    const v2 d1 = v2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)} + v2{1.0f, 1.0f};
+    const v2 d2 = v2{__builtin_amdgcn_exp2f(b.x), __builtin_amdgcn_exp2f(b.y)} + v2{1.0f, 1.0f};
+    const float si = __builtin_amdgcn_rcpf(d1.x), sf = __builtin_amdgcn_rcpf(d1.y), so = __builtin_amdgcn_rcpf(d2.y);
+    const float tg = fmaf(2.0f, __builtin_amdgcn_rcpf(d2.x), -1.0f);
+    c = sf * c + si * tg;
+    h = so * fast_tanh(c);
 }
 
 // One hidden unit's four W_hh rows, gate pairs (i, f) and (g, o) packed so that a recurrence step is 64
