@@ -268,8 +268,10 @@ class FullTransitionGather(object):
         self.rank, self.world, self.device, self.group = rank, world, torch.device(device), group
         self.B, self.N, self.D, self.T = env.num_envs, env.n, env.obs_dim, int(T)
         self.L = int(getattr(env, 'num_landmarks', 0))
-        self.A = int(env.cfg.num_adversaries if hasattr(env, "cfg") else (getattr(env, "num_adversaries", 0) or 0)) if getattr(env, "scenario_name", "") == "simple_tag" else 0
         self.scenario = getattr(env, 'scenario_name', 'simple_spread')
+        self.A = 0                                        # adversaries: agents [0, A) of simple_tag
+        if self.scenario == 'simple_tag':
+            self.A = int(env.cfg.num_adversaries if hasattr(env, 'cfg') else (getattr(env, 'num_adversaries', 0) or 0))
         self.env = env
         if ring not in ('rows', 'state'):
             raise ValueError("ring must be 'rows' or 'state'")
