@@ -3,6 +3,7 @@
 
     python examples/train_batched.py --scenario simple_spread --envs 4096 --episodes 40960
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_batched.py --envs 4096
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 examples/train_batched.py --backend gloo   (one GPU)
 
 For every scenario and seed count ``cnt`` it does what main.py does -- build the env (``make_batched_env``: the reference's
 ``make_env`` contract, B worlds), seed protocol ``seed = cnt + 12345678`` (main.py:41-49), read the dims from the env
@@ -34,6 +35,9 @@ def main(argv=None):
     ap.add_argument('--max-updates-per-chunk', type=int, default=8)
     ap.add_argument('--save-rate', type=int, default=None)
     ap.add_argument('--out-dir', default='Models')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='process group of a multi-rank run: nccl (= RCCL, one GPU per rank) or gloo (the blocks of the full gather '
+                         'travel through pinned host buffers; ranks may share a GPU -- RCCL refuses that)')
     ap.add_argument('--reference', action='store_true', help="use the reference's Trainer / CriticNetwork (rls on sys.path)")
     args = ap.parse_args(argv)
 
@@ -50,12 +54,17 @@ def main(argv=None):
 
     rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.backend == 'gloo':
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29541')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'gloo':
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     if args.episodes is not None:
         arglist.num_episodes = args.episodes

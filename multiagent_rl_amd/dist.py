@@ -45,7 +45,12 @@ def broadcast_actor(actor, src=0, group=None, fused=None):
     Returns the number of floats moved."""
     tensors = [p.data for p in actor.parameters()] + [b.data for b in actor.buffers() if b.is_floating_point()]
     flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
-    dist.broadcast(flat, src=src, group=group)
+    if flat.is_cuda and dist.get_backend(group) == 'gloo':   # no device transport: through the host
+        host = flat.cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat.copy_(host)
+    else:
+        dist.broadcast(flat, src=src, group=group)
     off = 0
     for t in tensors:
         n = t.numel()
@@ -230,6 +235,21 @@ class SampledTransitionGather(object):
             torch.cuda.current_stream(self.device).wait_stream(self.side)
 
 
+class _HostStagedRecv(object):
+    """One inbound block of ``FullTransitionGather(transport='host')``: a CPU receive into a pinned buffer; ``wait()`` completes
+    it and queues the H2D copy into the root's device-side receive slot on the CURRENT stream."""
+
+    def __init__(self, work, host, dst):
+        self.work, self.host, self.dst = work, host, dst
+
+    def is_completed(self):
+        return False
+
+    def wait(self):
+        self.work.wait()
+        self.dst.copy_(self.host, non_blocking=True)
+
+
 class FullTransitionGather(object):
     """north_star's collective: EVERY transition of every rank's rollout chunk lands in the learner rank's replay
     ring (the reference keeps one buffer that sees every env-step: experiments/run.py:20-21,52).
@@ -263,9 +283,14 @@ class FullTransitionGather(object):
     SLOTS = 3
 
     def __init__(self, env, T, rank, world, device, memory=None, group=None, capacity=int(1e6), wire='auto', overlap_ingest=True,
-                 ring='rows'):
+                 ring='rows', transport='auto'):
         from ._lib import PwChunkWire, PwStateWire
         self.rank, self.world, self.device, self.group = rank, world, torch.device(device), group
+        if transport not in ('auto', 'direct', 'host'):
+            raise ValueError("transport must be 'auto', 'direct' or 'host'")
+        if transport == 'auto':   # a process group without a device transport (gloo) gets the blocks through pinned host buffers
+            transport = 'host' if (world > 1 and self.device.type == 'cuda' and dist.get_backend(group) == 'gloo') else 'direct'
+        self.transport = transport
         self.B, self.N, self.D, self.T = env.num_envs, env.n, env.obs_dim, int(T)
         self.L = int(getattr(env, 'num_landmarks', 0))
         self.scenario = getattr(env, 'scenario_name', 'simple_spread')
@@ -323,6 +348,11 @@ class FullTransitionGather(object):
                          done=torch.zeros(self.T, B, N, dtype=torch.bool, device=dev))
         if self.state_wire or self.ref_wire:   # the rows stay on the sender: only their first four (eight) columns travel
             self.side['obs'] = torch.empty(self.T, B, N, D, dtype=torch.float32, device=dev)
+        self._host = self._host_free = None
+        if self.transport == 'host' and world > 1:
+            pin = lambda: torch.empty(nbytes, dtype=torch.uint8, pin_memory=self.device.type == 'cuda')  # noqa: E731
+            self._host = [[None] + [pin() for _ in range(1, world)] if rank == 0 else pin() for _ in range(self.SLOTS)]
+            self._host_free = [None] * self.SLOTS   # root: the H2D copies out of slot s's host buffers have run
         self.memory = memory
         self.capacity = int(capacity)
         if rank == 0 and self.memory is None:
@@ -462,11 +492,28 @@ class FullTransitionGather(object):
         """Direct peer -> root transfers of this chunk's blocks, asynchronous."""
         if self.world == 1:
             return []
+        if self.transport == 'host':
+            return self._post_host(slot)
         if self.rank == 0:
             ops = [dist.P2POp(dist.irecv, self.recv[slot][r], r, group=self.group) for r in range(1, self.world)]
         else:
             ops = [dist.P2POp(dist.isend, self.wire[slot], 0, group=self.group)]
         return dist.batch_isend_irecv(ops)
+
+    def _post_host(self, slot):
+        """``transport='host'``: the same peer -> root sends staged through pinned host buffers (D2H, the group's CPU send / recv,
+        H2D) -- for process groups without a device transport (gloo: ranks sharing one GPU, boxes without peer access).  The
+        kernels either side (finalize, ring append) and the slot choreography are the ones of the direct path."""
+        if self.rank == 0:
+            if self._host_free[slot] is not None:
+                self._host_free[slot].synchronize()      # the copies out of this slot's host buffers (three exchanges ago) have run
+                self._host_free[slot] = None
+            return [_HostStagedRecv(dist.irecv(self._host[slot][r], r, group=self.group), self._host[slot][r], self.recv[slot][r])
+                    for r in range(1, self.world)]
+        self._host[slot].copy_(self.wire[slot], non_blocking=True)
+        if self.device.type == 'cuda':
+            torch.cuda.current_stream(self.device).synchronize()     # the block is complete in host memory before the CPU send reads it
+        return [dist.isend(self._host[slot], 0, group=self.group)]
 
     def _complete(self):
         if self._pending is None:
@@ -479,6 +526,9 @@ class FullTransitionGather(object):
                 if not w.is_completed():
                     w.wait()  # NCCL: orders the current stream after the transfer; does not block the host
             if self.rank == 0:
+                if self._host_free is not None and self.device.type == 'cuda':
+                    self._host_free[slot] = torch.cuda.Event()
+                    self._host_free[slot].record(torch.cuda.current_stream(self.device))
                 for r in range(self.world):  # rank order => deterministic ring layout
                     self._ingest(self.wire[slot] if r == 0 else self.recv[slot][r])
                     self.rows_ingested += self.T * self.B
@@ -493,6 +543,9 @@ class FullTransitionGather(object):
                 side.wait_event(self._finalized[slot])
             if self._reads_done is not None:     # the ring wraps: never overwrite rows an earlier optimize() is still sampling
                 side.wait_event(self._reads_done)
+            if self._host_free is not None:
+                self._host_free[slot] = torch.cuda.Event()
+                self._host_free[slot].record(side)
             for r in range(self.world):
                 self._ingest(self.wire[slot] if r == 0 else self.recv[slot][r])
                 self.rows_ingested += self.T * self.B

@@ -190,10 +190,12 @@ def _worker(rank, world, port, q):
 
     # ---- the same blocks into the learner rank's STATE ring (rows rebuilt when sampled), and simple_tag on the same layout
     extra = {}
-    for name, mk_env, kw in (('state_ring', lambda: _SpreadEnv(rank), dict(ring='state')), ('tag', lambda: _TagEnv(rank), {})):
+    for name, mk_env, kw in (('state_ring', lambda: _SpreadEnv(rank), dict(ring='state', transport='host')),
+                             ('tag', lambda: _TagEnv(rank), {})):
         xenv = mk_env()
         xg = CpuFullGather(xenv, T, rank, world, 'cpu', **kw)
         assert xg.state_wire and xg.scenario == xenv.scenario_name and xg.A == getattr(xenv, 'num_adversaries', 0)
+        assert xg.transport == kw.get('transport', 'direct')    # 'host': the blocks staged through host buffers (the one-GPU multi-rank path)
         scen, A = xg.scenario, xg.A
         state0, lm0, ep0 = spread_start(rank)
         for k in range(3):
