@@ -130,6 +130,23 @@ __device__ __forceinline__ void actor16_inproj(const float4 *s_xf, const int ts,
         for (int i = 0; i < 4; ++i) acc[T][i] += bias[T][i];
 }
 
+// The value of lane ^ 16 / lane ^ 32 by v_permlane16_swap / v_permlane32_swap (gfx950): the instruction swaps the odd rows (halves) of
+// its first operand with the even rows (halves) of the second, so with both operands the same value the first holds, in every
+// even row (half), its own value and the second its neighbour's -- one VALU instruction and a select instead of a ds_bpermute
+// round trip through the LDS crossbar (~120 cycles, exposed on the head's dependent chain).
+__device__ __forceinline__ uint32_t lane_xor16(const uint32_t v)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (threadIdx.x & 16) ? r[0] : r[1];
+}
+__device__ __forceinline__ uint32_t lane_xor32(const uint32_t v)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (threadIdx.x & 32) ? r[0] : r[1];
+}
+__device__ __forceinline__ float lane_xor16(const float v) { return __uint_as_float(lane_xor16(__float_as_uint(v))); }
+__device__ __forceinline__ float lane_xor32(const float v) { return __uint_as_float(lane_xor32(__float_as_uint(v))); }
+
 // LDS of the pass (floats from a 16-byte aligned base): dense1 output and head input in B-fragment order, the h exchange,
 // the dense1 constants
 struct Actor16Lds {
@@ -203,6 +220,7 @@ __device__ __forceinline__ void actor16_load(const ActorFusedArgs &A, const Acto
 //                   (o >> 2) keyed (seed; step, global row), as pw_actor_head_kernel -- block rg is exactly what the lanes of
 //                   row group rg need for their four logits
 //   act_g / act_l   sinks of the sampled indices [rows_here * nheads], global / LDS (either may be NULL); A.H, A.logits too
+//   noise_l         this pass's Gumbel noise in LDS (actor16_draw_noise, same step), or NULL: drawn here
 // Arithmetic: element for element the operation sequence of actor_forward_wg (see pw_kernels_policy3.hpp, "Bits").
 // On return every thread has passed a barrier after the last LDS access of the pass.  BF3: the opt-in bf16x3 input projection.
 // pre() / mid(): called by every wave before its dense1 blocks / before its head tiles -- the two windows in which waves without
@@ -210,11 +228,48 @@ __device__ __forceinline__ void actor16_load(const ActorFusedArgs &A, const Acto
 struct Actor16NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
+
+// The Gumbel noise of ONE pass's head(s), drawn ahead of the pass into LDS [rows_here][NB = ceil(OUT / 4) blocks][4] (16-byte aligned; the
+// lanes of row group kq read block kq of their row as one float4): value (row, logit o) = log(-log(u)), u = word (o & 3) of Philox
+// block (o >> 2) keyed (seed; step, global row) -- the numbers actor16_forward draws inline when it is given no noise.  One thread
+// per (row, block); called by `nthr` threads with indices t0 = 0 .. nthr - 1.  A rollout kernel runs it for step t + 1 on the waves
+// that wait while the environment waves advance step t: ten Philox rounds and two logarithms per logit leave the head's dependent
+// chain (stamps, simple_reference: 3.8 k of a step's 16 k cycles sat there).
+__host__ __device__ inline int actor16_noise_floats(int rows, int out) { return rows * 4 * ((out + 3) >> 2) + 4; }   // + alignment slack
+__device__ __forceinline__ void actor16_draw_noise(const ActorFusedArgs &A, float *s_noise, const int rows_here, const long row_base,
+                                                   const uint64_t step, const int t0, const int nthr)
+{
+    const int OUT = A.n_out0 + A.n_out1, NB = (OUT + 3) >> 2;
+    for (int idx = t0; idx < rows_here * NB; idx += nthr) {
+        const int rr = idx / NB;
+        const uint32_t blk = (uint32_t)(idx - rr * NB), tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
+        const long grow = row_base + rr;
+        uint32_t u[4];
+        pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | tag, (uint32_t)step, (uint32_t)(step >> 32),
+                         (uint32_t)A.seed, (uint32_t)(A.seed >> 32), u);
+        float nz[4];
+#pragma unroll
+        for (int wq = 0; wq < 4; ++wq) {   // (the words past OUT serve no logit: their values are never looked at)
+            const float uo = ((float)(u[wq] >> 8) + 0.5f) * 5.9604644775390625e-8f;  // (0, 1)
+            nz[wq] = __logf(-__logf(uo));
+        }
+        reinterpret_cast<float4 *>(s_noise)[idx] = make_float4(nz[0], nz[1], nz[2], nz[3]);
+    }
+}
+#ifdef PW_STAMPS   // probe builds only (tools/*_probe.hip): shader cycles per phase into the caller's accumulators
+#define PW_A16_STAMP_ARGS , unsigned long long *a16_st = nullptr, unsigned long long *a16_t0 = nullptr
+#define PW_A16_STAMP(i) do { if (a16_st) { unsigned long long n_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n_)::"memory"); \
+                                          a16_st[i] += n_ - *a16_t0; *a16_t0 = n_; } } while (0)
+#else
+#define PW_A16_STAMP_ARGS
+#define PW_A16_STAMP(i)
+#endif
 template <int S1C, bool BF3 = false, class Pre = Actor16NoHook, class Mid = Actor16NoHook>
 __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const Actor16Lds &S, const Actor16W &W,
                                                 const float *xrows, const int xstride, const int rows_here,
                                                 const int envs_here, const long row_base, const uint64_t step,
-                                                int32_t *act_g, int32_t *act_l, Pre pre = Pre(), Mid mid = Mid())
+                                                int32_t *act_g, int32_t *act_l, Pre pre = Pre(), Mid mid = Mid(),
+                                                const float *noise_l = nullptr PW_A16_STAMP_ARGS)
 {
     constexpr int S1 = 4 * S1C;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
@@ -225,6 +280,7 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
     const bool seq_ok = n16 < envs_here;
 
     pre();
+    PW_A16_STAMP(0);
     // ---- dense1 + ReLU: 32 x 32 blocks of relu(W1 X^T + b1), column rho = 16 * timestep + sequence
     for (int blk = wave; blk < nblk; blk += 8) {
         const int rt = blk >> 1, m = blk & 1;
@@ -256,7 +312,9 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
         for (int q = 0; q < 16; ++q) v[q] = fmaxf(acc1[q] + S.s_b1[m * 32 + mfma_row(q, half)], 0.0f);
         if (2 * rt + (col >> 4) < N) actor16_store_x1<BF3>(S.s_xf, 2 * rt + (col >> 4), m, half, col & 15, v);
     }
+    PW_A16_STAMP(1);
     wg_lds_barrier();  // the x1 fragments are in LDS
+    PW_A16_STAMP(2);
 
     // ---- the BiLSTM, one timestep per barrier
     auto inproj = [&](const int ts, f32x4 (&acc)[2]) { actor16_inproj<BF3>(S.s_xf, ts, lane, W.aih, W.ah, W.al, W.bias, acc); };
@@ -304,7 +362,9 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
         }
     }
 
+    PW_A16_STAMP(3);
     mid();
+    PW_A16_STAMP(4);
     // ---- optional: the hidden state H [rows][64] back in row order
     if (A.H) {
         for (int idx = tid; idx < rows_here * 64; idx += 512) {
@@ -321,22 +381,28 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
     const int OUT = A.n_out0 + A.n_out1, nheads = A.n_out1 > 0 ? 2 : 1;
     const bool sample = act_g != nullptr || act_l != nullptr;
     const int ntile = (rows_here + 15) >> 4;
+    const int NB = (OUT + 3) >> 2;
     for (int tile = wave; tile < ntile; tile += 8) {
         f32x4 lg;
 #pragma unroll
         for (int i = 0; i < 4; ++i) lg[i] = W.b2c[i];
-        const float4 *hf = S.s_hf + (tile * 4) * 64 + lane;
-#pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
-            const float4 b = hf[jx * 64];
-            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aw2[4 * jx + 0], b.x, lg, 0, 0, 0);
-            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aw2[4 * jx + 1], b.y, lg, 0, 0, 0);
-            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aw2[4 * jx + 2], b.z, lg, 0, 0, 0);
-            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aw2[4 * jx + 3], b.w, lg, 0, 0, 0);
-        }
         const int rr = tile * 16 + n16;
         const bool row_ok = rr < rows_here;
         const long grow = row_base + (row_ok ? rr : 0);
+        // every LDS operand of the tile is requested before the first matrix instruction (read one by one in front of its four
+        // products, each read is a round trip of its own on the chain)
+        const float4 *hf = S.s_hf + (tile * 4) * 64 + lane;
+        const float4 hb[4] = {hf[0], hf[64], hf[128], hf[192]};
+        float4 nzv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (noise_l) nzv = reinterpret_cast<const float4 *>(noise_l)[(row_ok ? rr : 0) * NB + (kq < NB ? kq : 0)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aw2[4 * jx + 0], hb[jx].x, lg, 0, 0, 0);
+            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aw2[4 * jx + 1], hb[jx].y, lg, 0, 0, 0);
+            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aw2[4 * jx + 2], hb[jx].z, lg, 0, 0, 0);
+            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(W.aw2[4 * jx + 3], hb[jx].w, lg, 0, 0, 0);
+        }
         if (A.logits && row_ok) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -344,7 +410,9 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
         }
         if (sample) {
             float p[4] = {lg[0], lg[1], lg[2], lg[3]};
-            if (4 * kq < OUT) {  // wave-divergent only by row group
+            if (noise_l) {   // (logits past OUT: rows of W2 / b2 that are zero, never candidates below)
+                p[0] = lg[0] - nzv.x; p[1] = lg[1] - nzv.y; p[2] = lg[2] - nzv.z; p[3] = lg[3] - nzv.w;
+            } else if (4 * kq < OUT) {  // wave-divergent only by row group
                 const uint32_t blk = (uint32_t)kq, tag = ((blk & 1u) << 31) | ((blk >> 1) << 30);
                 uint32_t u[4];
                 pw_philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32) | tag, (uint32_t)step, (uint32_t)(step >> 32),
@@ -355,30 +423,40 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
                     p[i] = lg[i] - __logf(-__logf(uo));
                 }
             }
-#pragma unroll 1
-            for (int hd = 0; hd < nheads; ++hd) {
-                const int lo = hd ? A.n_out0 : 0, cnt = hd ? A.n_out1 : A.n_out0;
+            // one arg-max per head (first maximum wins), written as selects: both heads' scans and exchanges are straight-line code
+            int bests[2] = {0, 0};
+#pragma unroll
+            for (int hd = 0; hd < 2; ++hd) {
+                const int lo = hd ? A.n_out0 : 0, cnt = hd ? A.n_out1 : A.n_out0;   // (one head: cnt = 0 for the second, nothing stored)
                 float bv = -INFINITY;
                 int best = 0x7fffffff;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int o = 4 * kq + i - lo;
-                    if (o >= 0 && o < cnt && (best == 0x7fffffff || p[i] > bv)) { bv = p[i]; best = o; }
+                    const bool take = o >= 0 && o < cnt && (best == 0x7fffffff || p[i] > bv);
+                    bv = take ? p[i] : bv;
+                    best = take ? o : best;
                 }
 #pragma unroll
                 for (int sh = 16; sh <= 32; sh <<= 1) {  // the lower logit index wins a tie: the first maximum, as a scan would find
-                    const float ov = __shfl_xor(bv, sh, kWave);
-                    const int ob = __shfl_xor(best, sh, kWave);
-                    if (ob != 0x7fffffff && (best == 0x7fffffff || ov > bv || (ov == bv && ob < best))) { bv = ov; best = ob; }
+                    const float ov = sh == 16 ? lane_xor16(bv) : lane_xor32(bv);
+                    const int ob = (int)(sh == 16 ? lane_xor16((uint32_t)best) : lane_xor32((uint32_t)best));
+                    const bool take = ob != 0x7fffffff && (best == 0x7fffffff || ov > bv || (ov == bv && ob < best));
+                    bv = take ? ov : bv;
+                    best = take ? ob : best;
                 }
-                if (kq == 0 && row_ok) {
-                    if (act_g) act_g[rr * nheads + hd] = best;
-                    if (act_l) act_l[rr * nheads + hd] = best;
-                }
+                bests[hd] = best;
+                if (nheads == 1) break;
+            }
+            if (kq == 0 && row_ok) {
+                if (act_g) { act_g[rr * nheads] = bests[0]; if (nheads == 2) act_g[rr * nheads + 1] = bests[1]; }
+                if (act_l) { act_l[rr * nheads] = bests[0]; if (nheads == 2) act_l[rr * nheads + 1] = bests[1]; }
             }
         }
     }
+    PW_A16_STAMP(5);
     wg_lds_barrier();
+    PW_A16_STAMP(6);
 }
 
 // The whole actor in ONE launch (pw_actor_fused) on the 16x16x4 core: 16 environments per workgroup at any N <= 16 that fits LDS

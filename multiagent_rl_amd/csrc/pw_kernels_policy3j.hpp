@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout3j_kernel(const PolicyRo
             }
         }
         const float p0 = lg[0] - nz[0], p1 = lg[1] - nz[1], p2 = lg[2] - nz[2], p3 = lg[3] - nz[3];
-        const float p4 = __shfl(p0, n16 + 16, kWave);  // logit 4 lives in register 0 of row group 1
+        const float p4 = lane_xor16(p0);              // logit 4 lives in register 0 of row group 1
         int bi = 0;
         float bv = p0;
         if (p1 > bv) { bv = p1; bi = 1; }

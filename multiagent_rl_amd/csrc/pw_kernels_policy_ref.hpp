@@ -33,6 +33,9 @@ struct PolicyRolloutRefArgs {
     unsigned long long *scratch;
 };
 
+#ifdef PW_STAMPS
+__device__ unsigned long long g_pw_ref_stamps[30];
+#endif
 template <int S1C, bool SINK = false>
 __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const PolicyRolloutRefArgs P)
 {
@@ -50,6 +53,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
     int32_t *s_act = reinterpret_cast<int32_t *>(s_obs2 + 2 * kFusedRows * D);  // [96][2] (movement, symbol)
     double *s_fs = reinterpret_cast<double *>(s_act + 2 * kFusedRows);     // [16] (+ [16] ints): finished-episode sums / counts (SINK)
     int *s_fc = reinterpret_cast<int *>(s_fs + 16);
+    float *s_noise = reinterpret_cast<float *>(smem_raw) +                 // [32][4 blocks][4] Gumbel noise of the coming heads (drawn a step
+                     (((int)(reinterpret_cast<float *>(s_fc + 16) - reinterpret_cast<float *>(smem_raw)) + 3) & ~3);   // ahead), 16-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,6 +92,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
         if (live) ref_write_obs<DC, false>(V, s, co, a, s_obs2 + r * D);
     }
     const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
+    actor16_draw_noise(A, s_noise, rows_here, row_base, step0, tid, 512);
     wg_lds_barrier();
 
     // the rest of a step once the agents are advanced and the next observation rows published: rewards + episode step count
@@ -132,12 +138,21 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
     auto pre_hook = [&]() { if (tail_stage == 1) { tail_compute(); tail_stage = 2; } };
     auto mid_hook = [&]() { if (tail_stage == 2) { tail_stores(tail_t, true); tail_stage = 0; } };
 
+#ifdef PW_STAMPS
+    unsigned long long rs[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, r0_ = 0, r1_ = 0;
+    PW_R2_START;
+#define PW_REF_STAMP_ARGS , rs, &r0_
+#else
+#define PW_REF_STAMP_ARGS
+#endif
     for (int t = 0; t < P.T; ++t) {
         float *s_obs = s_obs2 + (t & 1) * (kFusedRows * D);          // what the policy acts on in this step
         float *s_next = s_obs2 + ((t + 1) & 1) * (kFusedRows * D);   // where the environment lanes publish the next rows
         // ---- policy: observation rows (LDS) -> one sampled index per head and row (LDS)
         actor16_forward<S1C, false>(A, S, W, s_obs, D, rows_here, envs_here, row_base, step0 + (uint64_t)t, nullptr, s_act, pre_hook,
-                                    mid_hook);  // a barrier at its end
+                                    mid_hook, s_noise PW_REF_STAMP_ARGS);  // a barrier at its end
+        // the noise of the NEXT step's heads: by the seven waves that wait for the environment wave
+        if (t + 1 < P.T && !env_wave) actor16_draw_noise(A, s_noise, rows_here, row_base, step0 + (uint64_t)(t + 1), tid, 7 * kWave);
         if (SINK && P.has_ring && !env_wave) {
             // the observations the policy acted on -> ring.obs, by the seven waves that would otherwise wait for the environment wave
             for (int idx = tid; idx < rows_here * D; idx += 448) {
@@ -146,6 +161,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
                 P.ring.obs[(sl * N + (rr & 1)) * D + c] = s_obs[idx];
             }
         }
+        PW_R2_STAMP(7);
         // ---- environment step (pw_reference_rollout_kernel's arithmetic, index actions)
         if (env_wave) {
             const size_t row = (size_t)t * BN + g;
@@ -197,8 +213,14 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
                 tail_t = t;
             }
         }
+        PW_R2_STAMP(8);
         wg_lds_barrier();
+        PW_R2_STAMP(9);
     }
+#ifdef PW_STAMPS
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7 || wave == 3))
+        for (int i_ = 0; i_ < 10; ++i_) g_pw_ref_stamps[(wave == 0 ? 0 : wave == 7 ? 1 : 2) * 10 + i_] = rs[i_];
+#endif
     if (tail_stage == 1) tail_compute();
     if (tail_stage != 0) tail_stores(tail_t, true);
     if (live) {

@@ -23,11 +23,14 @@ __host__ __device__ inline size_t policy_tag_lds_bytes(int S1, int D, int E, int
 {
     return actor16_lds_floats(N, E * N, S1) * sizeof(float) + (size_t)kFusedRows * D * sizeof(float) + kFusedRows * sizeof(int32_t) +
            4 * kWave * sizeof(float2) + (size_t)E * L * sizeof(float2) + 3 * 2 * kWave * sizeof(float) +
-           16 * (sizeof(double) + sizeof(int));
+           16 * (sizeof(double) + sizeof(int)) + (size_t)actor16_noise_floats(kFusedRows, 5) * sizeof(float);
 }
 
 // One 5-logit head per agent: every agent of simple_tag takes the same five movement actions; the observation rows
 // of the good agents are zero-padded to the adversaries' width D (as every simple_tag kernel here writes them).
+#ifdef PW_STAMPS
+__device__ unsigned long long g_pw_tag_stamps[30];
+#endif
 template <int S1C, bool SINK>
 __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const PolicyRolloutTagArgs P)
 {
@@ -48,6 +51,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
     float *s_rewb = reinterpret_cast<float *>(s_mhib + 2 * kWave);         // [2][64]
     double *s_fs = reinterpret_cast<double *>(s_rewb + 2 * kWave);         // [16] (+ [16] ints)
     int *s_fc = reinterpret_cast<int *>(s_fs + 16);
+    float *s_noise = reinterpret_cast<float *>(smem_raw) +                 // [96][2 blocks][4] Gumbel noise of the coming head (drawn a step
+                     (((int)(reinterpret_cast<float *>(s_fc + 16) - reinterpret_cast<float *>(smem_raw)) + 3) & ~3);   // ahead), 16-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,6 +143,10 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
     }
     const float k = V.contact_margin, cf = V.contact_force, dt = V.dt, damp = V.damp, mass = V.mass;
     const uint64_t step0 = A.step_dev ? (uint64_t)*A.step_dev : A.step;
+    // the Gumbel noise of step t + 1 is drawn by the waves without environment duty while the environment waves advance step t (by
+    // everybody, first, when every wave has environment duty)
+    const int noise_thr = n_env_waves < 8 ? (8 - n_env_waves) * kWave : 512;
+    actor16_draw_noise(A, s_noise, rows_here, row_base, step0, tid, 512);
     wg_lds_barrier();
 
     // The rest of an environment step once the agents are advanced and the next observation rows published, in two pieces:
@@ -222,9 +231,18 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
     auto pre_hook = [&]() { if (tail_stage == 1) { tail_compute(); tail_stage = 2; } };
     auto mid_hook = [&]() { if (tail_stage == 2) { tail_stores(tail_t, true); tail_stage = 0; } };
 
+#ifdef PW_STAMPS
+    unsigned long long rs[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, r0_ = 0, r1_ = 0;
+    PW_R2_START;
+#define PW_TAG_STAMP_ARGS , rs, &r0_
+#else
+#define PW_TAG_STAMP_ARGS
+#endif
     for (int t = 0; t < P.T; ++t) {
         actor16_forward<S1C, false>(A, S, W, s_obs, D, rows_here, envs_here, row_base, step0 + (uint64_t)t, nullptr, s_act, pre_hook,
-                                    mid_hook);  // a barrier at its end
+                                    mid_hook, s_noise PW_TAG_STAMP_ARGS);  // a barrier at its end
+        if (t + 1 < P.T && tid < noise_thr) actor16_draw_noise(A, s_noise, rows_here, row_base, step0 + (uint64_t)(t + 1), tid, noise_thr);
+        PW_R2_STAMP(7);
         if (env_wave) {
             const size_t tBN = (size_t)t * BN;
             const uint32_t g = opaque(g_lane);
@@ -308,8 +326,14 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
                 tail_t = t;
             }
         }
+        PW_R2_STAMP(8);
         wg_lds_barrier();
+        PW_R2_STAMP(9);
     }
+#ifdef PW_STAMPS
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7 || wave == 3))
+        for (int i_ = 0; i_ < 10; ++i_) g_pw_tag_stamps[(wave == 0 ? 0 : wave == 7 ? 1 : 2) * 10 + i_] = rs[i_];
+#endif
     if (tail_stage == 1) tail_compute();
     if (tail_stage != 0) tail_stores(tail_t, true);
 

@@ -170,7 +170,7 @@ int pw_policy_rollout(pw_handle *h, const float *frag, const float *b1, const fl
         const int rS1C = (kp.D + 7) / 8;
         if (rS1C != 3) return fail(PW_EINVAL, "simple_reference one-launch rollout: the observation is 21 numbers (3 landmarks)");
         const size_t rshm = actor16_lds_floats(2, 32, 4 * rS1C) * sizeof(float) + (size_t)2 * kFusedRows * kp.D * sizeof(float) + 2 * kFusedRows * sizeof(int32_t) +
-                            16 * (sizeof(double) + sizeof(int));
+                            16 * (sizeof(double) + sizeof(int)) + (size_t)actor16_noise_floats(32, 5 + PW_DIM_C) * sizeof(float);
         if (rsink) { R.ring = *sink->ring; R.has_ring = 1; R.ring_start = sink->ring_start; }
         if (sink && sink->episode_return) {
             R.episode_return = sink->episode_return; R.finished_sum = sink->finished_sum;
