@@ -96,10 +96,14 @@ __device__ __forceinline__ void actor16_inproj(const float4 *s_xf, const int ts,
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!BF3) {
+        // all four x1 fragments are requested before the first product (left alone, the compiler reads each one in front of its
+        // eight matrix instructions through ONE register quad: four LDS round trips in a row on the timestep's chain)
         const float4 *xf = s_xf + (ts * 4) * 64 + lane;
+        const float4 xq[4] = {xf[0], xf[64], xf[128], xf[192]};
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int jx = 0; jx < 4; ++jx) {
-            const float4 b = xf[jx * 64];
+            const float4 b = xq[jx];
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 0], b.x, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[1][4 * jx + 0], b.x, acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aih[0][4 * jx + 1], b.y, acc[0], 0, 0, 0);
@@ -214,6 +218,32 @@ __device__ __forceinline__ void actor16_load(const ActorFusedArgs &A, const Acto
     for (int i = 0; i < 4; ++i) W.b2c[i] = 4 * kq + i < OUT ? A.b2[4 * kq + i] : 0.0f;
 }
 
+// dense1 by 16 x 16 TILES (optional; short agent axes): wave (w / 4, hq = w % 4) computes rows 16 hq .. 16 hq + 15 of relu(W1 x(ts) + b1) for
+// the 16 sequences of timestep ts = w / 4, w / 4 + 2, .. as ONE v_mfma_f32_16x16x4_f32 accumulator (K = D) -- pw_kernels_policy3j.hpp's
+// dense1, whose header has the argument for the bits: fed k = 4 s + kq the chain sums the same k in the same order as the 32x32x2 blocks.
+// With 32 x 32 blocks a pass has 2 ceil(N / 2) of them: at N = 2 (simple_reference) two waves work and six wait (stamps: 2.0 k of a
+// step's 14.7 k cycles); as tiles the same matrix instructions are spread over all eight waves.  W1's A fragments: 2 S1C registers.
+template <int S1C>
+struct Actor16D1 {
+    float a1[2 * S1C], b1v[4];
+};
+template <int S1C>
+__device__ __forceinline__ void actor16_load_d1(const ActorFusedArgs &A, Actor16D1<S1C> &T)
+{
+    constexpr int S1 = 4 * S1C;
+    const int lane = threadIdx.x & 63, n16 = lane & 15, kq = lane >> 4;
+    const int hq = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) & 3;
+    const float *w1p = A.frag + 8 * 2 * 4 * 64 * 4;   // the packed 32x32x2 image [2 m][S1][64 lane]: lane = row % 32 + 32 (k & 1), k step k / 2
+    const int h = 16 * hq + n16;
+#pragma unroll
+    for (int sx = 0; sx < 2 * S1C; ++sx) {
+        const int kk = 4 * sx + kq;
+        T.a1[sx] = w1p[((h >> 5) * S1 + (kk >> 1)) * 64 + (h & 31) + 32 * (kk & 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T.b1v[i] = A.b1[16 * hq + 4 * kq + i];
+}
+
 // One pass for the rows of this workgroup (all 512 threads call it; E <= 16 environments, rows env-major r = e * N + agent).
 //   xrows, xstride  observation rows [rows_here][xstride >= A.D] -- global memory or LDS (readable on entry)
 //   step            Philox step of the Gumbel noise: value (row, logit o) = log(-log(u)), u = word (o & 3) of Philox block
@@ -221,6 +251,7 @@ __device__ __forceinline__ void actor16_load(const ActorFusedArgs &A, const Acto
 //                   row group rg need for their four logits
 //   act_g / act_l   sinks of the sampled indices [rows_here * nheads], global / LDS (either may be NULL); A.H, A.logits too
 //   noise_l         this pass's Gumbel noise in LDS (actor16_draw_noise, same step), or NULL: drawn here
+//   d1              W1 as 16 x 16 tile fragments (actor16_load_d1): dense1 runs as tiles on all eight waves (exact form only), or NULL: 32 x 32 blocks
 // Arithmetic: element for element the operation sequence of actor_forward_wg (see pw_kernels_policy3.hpp, "Bits").
 // On return every thread has passed a barrier after the last LDS access of the pass.  BF3: the opt-in bf16x3 input projection.
 // pre() / mid(): called by every wave before its dense1 blocks / before its head tiles -- the two windows in which waves without
@@ -269,7 +300,7 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
                                                 const float *xrows, const int xstride, const int rows_here,
                                                 const int envs_here, const long row_base, const uint64_t step,
                                                 int32_t *act_g, int32_t *act_l, Pre pre = Pre(), Mid mid = Mid(),
-                                                const float *noise_l = nullptr PW_A16_STAMP_ARGS)
+                                                const float *noise_l = nullptr, const Actor16D1<S1C> *d1 = nullptr PW_A16_STAMP_ARGS)
 {
     constexpr int S1 = 4 * S1C;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
@@ -281,6 +312,31 @@ __device__ __forceinline__ void actor16_forward(const ActorFusedArgs &A, const A
 
     pre();
     PW_A16_STAMP(0);
+    // ---- dense1 + ReLU as 16 x 16 tiles (timestep, hidden quarter of this wave), all eight waves
+    if (!BF3 && d1) {
+        constexpr int KS = 2 * S1C;
+        const int nq = seq_ok ? n16 : 0;   // columns past the environments of this workgroup read a valid row; nobody uses their results
+        for (int ts = wave >> 2; ts < N; ts += 2) {
+            const float *xr = xrows + (size_t)(nq * N + ts) * xstride;
+            float xb[KS];
+#pragma unroll
+            for (int sx = 0; sx < KS; ++sx) {
+                const int kk = 4 * sx + kq;
+                xb[sx] = kk < D ? xr[kk] : 0.0f;
+            }
+            f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sx = 0; sx < KS; ++sx) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(d1->a1[sx], xb[sx], acc1, 0, 0, 0);
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc1[i] + d1->b1v[i], 0.0f);
+            // hidden unit 16 hq + 4 kq + i in the x1 fragment (pw_kernels_policy3j.hpp): fragment j = hq, lane slot (2 (i & 1) + (kq & 1)) * 16 + n,
+            // element 2 (kq / 2) + i / 2 -- registers (0, 2) and (1, 3) are two 8-byte stores
+            float4 *dst = S.s_xf + (ts * 4 + hq) * 64 + n16;
+            reinterpret_cast<float2 *>(dst + (kq & 1) * 16)[kq >> 1] = make_float2(v[0], v[2]);
+            reinterpret_cast<float2 *>(dst + (2 + (kq & 1)) * 16)[kq >> 1] = make_float2(v[1], v[3]);
+        }
+    } else
     // ---- dense1 + ReLU: 32 x 32 blocks of relu(W1 X^T + b1), column rho = 16 * timestep + sequence
     for (int blk = wave; blk < nblk; blk += 8) {
         const int rt = blk >> 1, m = blk & 1;

@@ -47,6 +47,8 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
     const int D = A.D;
     Actor16W W;  // the actor's weights: registers for the whole launch (pw_kernels_actor16.hpp)
     actor16_load<S1C>(A, S, W);
+    Actor16D1<S1C> T1;  // dense1 as 16 x 16 tiles: with N = 2 the 32 x 32 form has two blocks for eight waves
+    actor16_load_d1<S1C>(A, T1);
     // observation rows, TWO buffers of [96][D]: the policy reads buffer `cur`, the environment lanes publish the next rows into the other
     // one -- so that, with a ring sink, the IDLE waves can copy the rows the policy acted on into ring.obs during the environment step
     float *s_obs2 = reinterpret_cast<float *>(S.end);
@@ -150,7 +152,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_ref_kernel(const Policy
         float *s_next = s_obs2 + ((t + 1) & 1) * (kFusedRows * D);   // where the environment lanes publish the next rows
         // ---- policy: observation rows (LDS) -> one sampled index per head and row (LDS)
         actor16_forward<S1C, false>(A, S, W, s_obs, D, rows_here, envs_here, row_base, step0 + (uint64_t)t, nullptr, s_act, pre_hook,
-                                    mid_hook, s_noise PW_REF_STAMP_ARGS);  // a barrier at its end
+                                    mid_hook, s_noise, &T1 PW_REF_STAMP_ARGS);  // a barrier at its end
         // the noise of the NEXT step's heads: by the seven waves that wait for the environment wave
         if (t + 1 < P.T && !env_wave) actor16_draw_noise(A, s_noise, rows_here, row_base, step0 + (uint64_t)(t + 1), tid, 7 * kWave);
         if (SINK && P.has_ring && !env_wave) {

@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(512) pw_policy_rollout_tag_kernel(const Policy
 #endif
     for (int t = 0; t < P.T; ++t) {
         actor16_forward<S1C, false>(A, S, W, s_obs, D, rows_here, envs_here, row_base, step0 + (uint64_t)t, nullptr, s_act, pre_hook,
-                                    mid_hook, s_noise PW_TAG_STAMP_ARGS);  // a barrier at its end
+                                    mid_hook, s_noise, nullptr PW_TAG_STAMP_ARGS);  // a barrier at its end
         if (t + 1 < P.T && tid < noise_thr) actor16_draw_noise(A, s_noise, rows_here, row_base, step0 + (uint64_t)(t + 1), tid, noise_thr);
         PW_R2_STAMP(7);
         if (env_wave) {
