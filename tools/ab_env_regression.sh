@@ -6,7 +6,7 @@
 # Run on the GPU box from the repo root:  tools/ab_env_regression.sh > gpurun_out/ab_env.txt
 set -o pipefail
 R=$PWD
-OLD=$R/_ab/c58c133
+OLD=${OLD:-$R/_ab/c58c133}
 REPS=${REPS:-5}
 export PW_BENCH_NO_POLICY=1
 O=$R/gpurun_out/ab_env
