@@ -1481,3 +1481,53 @@ def test_collect_one_launch_multidiscrete_fills_the_two_head_ring_like_the_step_
     for a, b in zip(res[0][:8], res[1][:8]):
         assert torch.equal(a, b)
     assert abs(res[0][8] - res[1][8]) < 1e-9 * abs(res[0][8])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('state_ring', [False, True], ids=['row-ring', 'state-ring'])
+def test_reference_sized_ring_at_n48_indexes_past_four_gibi_elements(state_ring):
+    """The reference's ring size (1e6 transitions, run.py:20) at BASELINE's largest agent count (N = L = 48, D = 100): one observation plane
+    is 4.8e9 floats (19.2 GB) -- element offsets past 2^32 in the ring's upper half.  A chunk appended across the ring's END (add_rollout:
+    row ring; the policy rollout's own sink: both rings) and sampled back must equal the same chunk in a small ring, bit for bit."""
+    from multiagent_rl_amd import make_batched_env
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    if torch.cuda.mem_get_info()[0] < 60e9:
+        pytest.skip('needs ~45 GB of device memory')
+    cap, N, B, T = int(1e6), 48, 64, 20
+    kw = dict(state_ring=dict(scenario='simple_spread', num_landmarks=N, num_adversaries=0)) if state_ring else {}
+    mk = lambda: make_batched_env('simple_spread', B, n=N, auto_reset=True, max_episode_len=7, seed=5)  # noqa: E731
+    torch.manual_seed(1)
+    net = ActorNetwork(100, 5).cuda().eval()
+    start = cap - T * B // 2                                   # the chunk wraps around the ring's end
+    res = []
+    for size in (cap, 4 * T * B):
+        env = mk()
+        D = env.obs_dim
+        assert D == 100 and (state_ring or cap * N * D > 2 ** 32)
+        ring = ReplayBuffer(size, N, D, **kw)
+        env.reset()
+        ring._next_idx, ring._len = (start if size == cap else size - T * B // 2), size
+        first = ring._next_idx
+        actor = FusedActor(net, seed=3)
+        actor.rollout(env, T, False, memory=ring)              # the launch's own sink
+        idx = [(first + i) % size for i in range(T * B)]
+        got = [x.clone() for x in ring.sample_index(idx)]
+        if not state_ring:                                      # the same transitions again through pw_replay_add_rollout, one chunk further
+            env2 = mk()
+            o0 = env2.reset().clone()
+            out = {k: torch.empty((T,) + tuple(s), dtype=d, device='cuda') for k, s, d in (
+                ('obs', (B, N, D), torch.float32), ('final_obs', (B, N, D), torch.float32), ('rew', (B, N), torch.float32),
+                ('rew_shared', (B,), torch.float32), ('terminal', (B,), torch.bool), ('done', (B, N), torch.bool), ('act', (B, N), torch.int32))}
+            FusedActor(net, seed=3).rollout(env2, T, out)
+            ring._next_idx = first
+            ring.add_rollout(o0, out)
+            again = ring.sample_index(idx)
+            for nm, x, y in zip(('obs', 'act', 'rew', 'next_obs', 'done'), got, again):
+                assert torch.equal(x, y), ('add_rollout vs sink', size, nm)
+        res.append(got)
+        del ring
+        torch.cuda.empty_cache()
+    for nm, x, y in zip(('obs', 'act', 'rew', 'next_obs', 'done'), *res):
+        assert torch.equal(x, y), nm
+    assert torch.isfinite(res[0][0]).all() and (res[0][1].sum(-1) == 1).all()

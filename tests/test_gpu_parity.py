@@ -813,3 +813,51 @@ def test_dispatch_is_frozen_in_the_handle_not_read_from_the_environment_at_launc
         frozen.set_dispatch(duo=7)
     with pytest.raises(TypeError):
         frozen.set_dispatch(no_such_field=1)
+
+
+def test_output_planes_beyond_four_gibi_elements():
+    """Sized for the card (288 GB): B = 262144 envs x 200 steps of simple_spread N = 6 write observation planes of 5.03e9 floats (20 GB each) --
+    element offsets past 2^32.  Envs from both ends of the batch must equal single-env shards (env_id_base = e, the same actions: the partition
+    property of C4) at every step, for the synthetic-action rollout AND for the policy-in-the-loop rollout replayed on its own sampled actions."""
+    from multiagent_rl_amd.policy import ActorNetwork, FusedActor
+    B, N, T = 262144, 6, 200
+    free = torch.cuda.mem_get_info()[0]
+    if free < 120e9:
+        pytest.skip('needs ~100 GB of device memory')
+    picks = (0, 1, 131077, B - 2, B - 1)
+    env, _ = _mk(num_agents=N, num_envs=B, max_episode_len=25, auto_reset=True, seed=12345678, want_coll=False)
+    assert T * B * N * env.obs_dim > 2 ** 32
+    acts = torch.randint(0, 5, (T, B, N), dtype=torch.int32, device='cuda', generator=torch.Generator(device='cuda').manual_seed(9))
+    obs0 = env.reset()
+    out = env.rollout(acts)
+    torch.cuda.synchronize()
+    assert out['obs'].numel() > 2 ** 32 and out['terminal'][24].all() and out['terminal'][199].all()
+
+    def check(big, big_obs0, actions, what):
+        for e in picks:
+            shard, _ = _mk(num_agents=N, num_envs=1, max_episode_len=25, auto_reset=True, seed=12345678, env_id_base=e, want_coll=False)
+            assert torch.equal(shard.reset(), big_obs0[e:e + 1]), (what, 'reset', e)
+            o = shard.rollout(actions[:, e:e + 1].contiguous())
+            for k in ('obs', 'rew', 'rew_shared', 'terminal', 'final_obs'):
+                got, want = big[k][:, e:e + 1], o[k]
+                if k == 'final_obs':   # defined where an episode ended
+                    m = o['terminal'][:, 0]
+                    got, want = got[m], want[m]
+                assert torch.equal(got, want), (what, k, e)
+
+    check(out, obs0, acts, 'rollout')
+    del out, acts
+    torch.cuda.empty_cache()
+    # the policy in the loop at the same size (one launch per 100 steps), replayed through single-env shards on its own actions
+    torch.manual_seed(0)
+    penv, _ = _mk(num_agents=N, num_envs=B, max_episode_len=25, auto_reset=True, seed=12345678, want_coll=False)
+    actor = FusedActor(ActorNetwork(penv.obs_dim, 5).cuda().eval(), seed=5)
+    pobs0 = penv.reset().clone()
+    pout = {k: torch.empty((T,) + tuple(s), dtype=d, device='cuda') for k, s, d in (
+        ('obs', (B, N, penv.obs_dim), torch.float32), ('final_obs', (B, N, penv.obs_dim), torch.float32), ('rew', (B, N), torch.float32),
+        ('rew_shared', (B,), torch.float32), ('terminal', (B,), torch.bool), ('done', (B, N), torch.bool), ('act', (B, N), torch.int32))}
+    for c in range(T // 100):
+        actor.rollout(penv, 100, {k: v[c * 100:(c + 1) * 100] for k, v in pout.items()})
+    torch.cuda.synchronize()
+    assert int(pout['act'].min()) >= 0 and int(pout['act'].max()) <= 4
+    check(pout, pobs0, pout['act'], 'policy rollout')
