@@ -449,11 +449,11 @@ class FullTransitionGather(object):
     def _make_memory(self):
         from .replay_buffer import ReplayBuffer
         if self.ref_wire:
-            return ReplayBuffer(self.capacity, self.N, self.D, device=self.device, act_heads=(5, _lib.PW_DIM_C))
+            return ReplayBuffer(self.capacity, self.N, self.D, device=self.device, act_heads=(5, _lib.PW_DIM_C), device_index=True)
         if self.ring_kind == 'state':   # the learner rank writes 32 N + 8 L bytes per transition instead of 8 N D; rows rebuilt when sampled
-            return ReplayBuffer(self.capacity, self.N, self.D, device=self.device,
+            return ReplayBuffer(self.capacity, self.N, self.D, device=self.device, device_index=True,
                                 state_ring=dict(scenario=self.scenario, num_landmarks=self.L, num_adversaries=self.A))
-        return ReplayBuffer(self.capacity, self.N, self.D, device=self.device)
+        return ReplayBuffer(self.capacity, self.N, self.D, device=self.device, device_index=True)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

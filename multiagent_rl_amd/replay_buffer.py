@@ -48,12 +48,18 @@ def _ptr(t):
 
 
 class ReplayBuffer(object):
-    def __init__(self, size, num_agents=None, obs_dim=None, device=None, act_heads=None, per_agent=None, state_ring=None):
+    def __init__(self, size, num_agents=None, obs_dim=None, device=None, act_heads=None, per_agent=None, state_ring=None,
+                 device_index=False):
         """size: max number of transitions (``ReplayBuffer(size=1e+6)``, experiments/run.py:20).
         Storage is allocated on the first add (when N and D are known) unless given here.
         ``act_heads``: sizes of the action heads, ``(5,)`` (default) or ``(5, dim_c)``; ``per_agent``: per-agent
-        reward / done planes.  Left None they are taken from the first ``add`` (a scalar reward = shared)."""
+        reward / done planes.  Left None they are taken from the first ``add`` (a scalar reward = shared).
+        ``device_index=True``: ``make_index`` draws the batch's indices ON the device (one ``torch.randint``; uniform with replacement
+        like the reference's ``batch_size`` calls of Python's never-seeded ``random.randint``, rls/replay_buffer.py:51-52) and returns
+        the int64 tensor ``sample_index`` takes as it is -- 1024 host-side draws, a list and an upload cost a learner ~0.7 ms of every
+        update."""
         self._maxsize = int(size)
+        self.device_index = bool(device_index)
         self._next_idx = 0
         self._len = 0
         self._device = None if device is None else torch.device(device)
@@ -139,13 +145,15 @@ class ReplayBuffer(object):
             sl = slice(0, self._len)  # add() fills slots [0, len) before it ever wraps
             host = {k: getattr(self, k)[sl].cpu().numpy() for k in ('obs', 'next_obs', 'act', 'rew', 'done') + (('lm',) if self.state_ring else ())}
         return dict(maxsize=self._maxsize, next_idx=self._next_idx, len=self._len, num_agents=self.num_agents,
-                    obs_dim=self.obs_dim, act_heads=self.act_heads, per_agent=self.per_agent, planes=host, state_ring=self.state_ring)
+                    obs_dim=self.obs_dim, act_heads=self.act_heads, per_agent=self.per_agent, planes=host, state_ring=self.state_ring,
+                    device_index=self.device_index)
 
     def __setstate__(self, st):
         self.__init__(st['maxsize'], act_heads=st['act_heads'], per_agent=st['per_agent'])
         self._next_idx, self._len = st['next_idx'], st['len']
         self.num_agents, self.obs_dim = st['num_agents'], st['obs_dim']
         self.state_ring = st.get('state_ring')
+        self.device_index = bool(st.get('device_index', False))
         self._host_state = st['planes']   # uploaded by _ensure_device() on first use (unpickling needs no GPU)
 
     def _ensure_device(self):
@@ -324,6 +332,8 @@ class ReplayBuffer(object):
 
     # -- rls/replay_buffer.py:51-57
     def make_index(self, batch_size):
+        if self.device_index and self._store is not None:
+            return torch.randint(0, self._len, (int(batch_size),), dtype=torch.int64, device=self._device)
         return [random.randint(0, self._len - 1) for _ in range(batch_size)]
 
     def make_latest_index(self, batch_size):

@@ -138,7 +138,7 @@ def train_batched(env, actor, critic, Trainer, scenario_name, action_type='Discr
                     raise ValueError("ring='state' serves simple_spread (local observation) and simple_tag")
                 kw = dict(state_ring=dict(scenario=env.scenario_name, num_landmarks=env.num_landmarks,
                                           num_adversaries=env.cfg.num_adversaries if env.scenario_name == 'simple_tag' else 0))
-            memory = ReplayBuffer(int(1e6), N, env.obs_dim, **kw)
+            memory = ReplayBuffer(int(1e6), N, env.obs_dim, device_index=True, **kw)   # the batch's indices drawn on the device
     learner = Trainer(actor, critic, memory, action_type=action_type)
     seed = (cnt + 12345678 if policy_seed is None else policy_seed) + rank
     if make_rollout is None:

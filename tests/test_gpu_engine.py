@@ -41,6 +41,29 @@ def test_replay_buffer_matches_reference_semantics():
     assert allb[0].shape[0] == 5
 
 
+def test_device_side_index_draw_is_uniform_over_the_filled_ring_and_feeds_sample_index():
+    """ReplayBuffer(device_index=True): make_index is one torch.randint on the device (the reference draws batch_size times from
+    Python's never-seeded random: rls/replay_buffer.py:51-52 -- uniform with replacement either way); the tensor goes into
+    sample_index as it is.  The default keeps the list of the golden test above."""
+    import pickle
+    from multiagent_rl_amd.replay_buffer import ReplayBuffer
+    rb = ReplayBuffer(5000, 3, 10, device_index=True)
+    obs = torch.arange(3000, dtype=torch.float32, device='cuda')[:, None, None].expand(3000, 3, 10).contiguous()
+    rb.add_batch(obs, torch.zeros(3000, 3, dtype=torch.int32, device='cuda'), torch.zeros(3000, device='cuda'), obs + 0.5)
+    assert len(rb) == 3000
+    idx = rb.make_index(200000)
+    assert torch.is_tensor(idx) and idx.is_cuda and idx.dtype == torch.int64 and int(idx.min()) == 0 and int(idx.max()) == 2999
+    counts = torch.bincount(idx, minlength=3000).float()
+    assert abs(float(counts.mean()) - 200000 / 3000) < 1e-3 and float(counts.std()) < 2.0 * (200000 / 3000) ** 0.5   # Poisson-like spread
+    o, a, r, n, d = rb.sample_index(idx[:1024])
+    assert torch.equal(o[:, 0, 0], idx[:1024].float()) and torch.equal(n[:, 0, 0], idx[:1024].float() + 0.5)
+    rb2 = pickle.loads(pickle.dumps(rb))
+    assert rb2.device_index and len(rb2) == 3000
+    plain = ReplayBuffer(10, 3, 10)
+    plain._len = 5
+    assert isinstance(plain.make_index(4), list)
+
+
 def test_add_batch_ring_and_pre_reset_next_obs():
     from multiagent_rl_amd.replay_buffer import ReplayBuffer
     rb = ReplayBuffer(10, 2, 6)
