@@ -308,6 +308,9 @@ def main():
                              'python3 bench.py --no-cpu-baseline   (profiles/README.md)' % (args.gpus, preload))
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
+    # multi-process GPU work on this pool needs dmabuf IPC (the image exports it; kept here for an env that was built without it) --
+    # read by the HSA runtime when the first process touches the GPU, so before torch does
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -41,6 +41,7 @@ def main(argv=None):
     ap.add_argument('--reference', action='store_true', help="use the reference's Trainer / CriticNetwork (rls on sys.path)")
     args = ap.parse_args(argv)
 
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC for multi-process GPU work (read at the first GPU call)
     import torch
     import torch.distributed as dist
     from multiagent_rl_amd import arglist, make_batched_env
