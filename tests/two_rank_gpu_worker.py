@@ -31,6 +31,7 @@ CASES = [
 
 
 def run_case(rank, world, dev, name, scenario, kw, B, T, ep, ring, wire, chunks):
+    chunks = int(os.environ.get('PW_TWO_RANK_CHUNKS', chunks))   # stress runs: more chunks than block slots, many times over
     from multiagent_rl_amd import make_batched_env
     from multiagent_rl_amd.dist import FullTransitionGather
     from multiagent_rl_amd.policy import ActorNetwork, FusedActor
