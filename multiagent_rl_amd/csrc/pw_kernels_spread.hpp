@@ -673,6 +673,14 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_spread_duo_kernel(c
                                                             2 * kWave * sizeof(float) + 15) & ~(size_t)15));
     float2 *s_utab = reinterpret_cast<float2 *>(s_row + kWave);      // [8] action force per index (wave P)
     float2 *s_zero = s_utab + 8;                                     // {0, 0} (planned observation stores)
+    // Three-wave form at N = 12 (C5's N = 12 point: 820 workgroups at B = 4096): wave P's action indices arrive four steps ahead by
+    // LDS-direct loads, as in pw_spread_quad_kernel / pw_tag_duo_kernel (pw_common.hpp act_fetch_issue).  With the output wave split
+    // in two, P is the step's longest wave there and its one-step-ahead register load cost it 800 of its 3230 cycles per step (stamps,
+    // round 5: HBM latency under the output waves' write stream exceeds a step): +2.8 % env-steps/s at B = 4096, unchanged at B = 2048 /
+    // 6144 (profiles/r5_n12_action_ring.txt).  N = 24 in this form loses 1.4 % (B = 2048), and the two-wave form keeps the register load
+    // everywhere: its output wave is the longer one, and P waits for the index instead of waiting at the barrier (profiles/r3_tag_prefetch.txt).
+    constexpr bool kActRing = TRIO && NT == 12;
+    int32_t *s_actr = reinterpret_cast<int32_t *>(s_utab + 16);     // [4][64] (kActRing; 16-byte aligned)
     constexpr int kPlanIters = obs_plan_iters<NT, LT>();
     constexpr bool kPlan = BLOCK && kPlanIters >= 1 && kPlanIters <= PW_PLAN_MAX;
 
@@ -715,12 +723,29 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_spread_duo_kernel(c
         wave_lds_sync();
         MaskT near = duo_near_pass<NT, MaskT>(N, a, s_ring + base, px, py, A.near_thr2);
         const float k = A.contact_margin, cf = A.contact_force, dt = A.dt, damp = A.damp, mass = A.mass;
-        int act_next = A.act[g];
+        int act_next = 0;
+        const int32_t *act_g = A.act + g;
+        const uint32_t act_lds = kActRing ? __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(s_actr)) : 0u;
+        auto fetch_act = [&](int t) {  // indices of step t (clamped: the tail re-fetches the last step) -> slot t & 3
+            act_fetch_issue(act_g + (size_t)(t < T ? t : T - 1) * BN, act_lds + (uint32_t)(t & 3) * (kWave * 4));
+        };
+        if constexpr (kActRing) {
+            // every load the compiler counts is consumed before the first uncounted one is issued (pw_spread_quad_kernel)
+            asm volatile("" :: "v"(ep_step), "v"(ep_count), "v"(px), "v"(py), "v"(vx), "v"(vy), "v"(near) : "memory");
+            fetch_act(0); fetch_act(1); fetch_act(2); fetch_act(3);
+        } else {
+            act_next = A.act[g];
+        }
         PW_STAMP_DECL;
         for (int t = 0; t < T; ++t) {
             PW_STAMP_START;
-            const uint32_t ai = (uint32_t)act_next;
-            {
+            uint32_t ai;
+            if constexpr (kActRing) {
+                act_fetch_wait3();  // step t's indices are in LDS (the later fetches stay in flight)
+                ai = (uint32_t)s_actr[(t & 3) * kWave + lane];
+                fetch_act(t + 4);   // into the slot just read
+            } else {
+                ai = (uint32_t)act_next;
                 const int tn = t + 1 < T ? t + 1 : t;
                 act_next = A.act[(size_t)tn * BN + g];
             }
@@ -754,6 +779,7 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_spread_duo_kernel(c
             PW_STAMP(4);
         }
         PW_STAMP_FLUSH;
+        if constexpr (kActRing) act_fetch_drain();  // the tail's fetches have landed before the wave ends
         A.pos_x[g] = px; A.pos_y[g] = py;
         A.vel_x[g] = vx; A.vel_y[g] = vy;
         A.ep_step[env] = ep_step;

@@ -188,6 +188,10 @@ void setup_fast_path(pw_handle *h)
     h->fast = true;
 }
 
+#ifndef PW_TRIO_ROWS_LO
+#define PW_TRIO_ROWS_LO 1      // workgroups: the row-wise three-wave form of N = 9 / 12 (measured below)
+#define PW_TRIO_ROWS_HI 1280
+#endif
 #ifndef PW_N3_TRIO_HI
 #define PW_N3_TRIO_HI 600   // workgroups (C5 N = 3 at B = 4096: 512 of 8 envs): measured B = 1024 ... 4096: -6.5 % step time
 #endif
@@ -403,7 +407,7 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
         const bool duo = !every_step_resets && (dp.duo < 0 ? grid.x <= 8192 : dp.duo != 0);
         if (duo) {
             const size_t shm2 = 3 * kWave * sizeof(float4) + (size_t)kp.epw * kp.L * sizeof(float2) +
-                                2 * kWave * sizeof(float) + 16 + kWave * sizeof(float4) + 8 * sizeof(float2) + 16;
+                                2 * kWave * sizeof(float) + 16 + kWave * sizeof(float4) + 16 * sizeof(float2) + kActRingBytes;   // .. utab + zero (padded), action ring
             // three waves per env group (the output wave split in two) where the single output wave is the step's critical
             // path: block-store instantiations on mid-size grids (measured: profiles/r2_trio.txt).  pw_dispatch.trio overrides.
             // (only the compile-time instantiations below have the three-wave form: a runtime-N launch stays two waves wide)
@@ -417,6 +421,19 @@ int launch_rollout(pw_handle *h, const pw_step_io *io, int T, void *stream)
             if (trio3) {
                 if (dp.p_prio < 0) A.p_prio = 3;
                 PW_LAUNCH(h, (pw_spread_duo_kernel<3, 3, true, false, false, true>), grid, dim3(3 * kWave), shm2, st, A, T);
+                PW_HIP_CHECK(hipGetLastError());
+                return PW_OK;
+            }
+            // N = L = 9 / 12 with ROW-wise stores (grids below the block-store crossover; N = 9 -- the reference's middle scalability
+            // setting, main_scalability_1.py:30 -- never stores blocks: its 88-byte rows leave a wave's block off the 16-byte grid): the single
+            // output wave (N = 9 at B = 4096, stamps: rewards 1490 + rows 2550 busy cycles against the physics wave's 2640) splits in two.
+            // pw_dispatch.trio overrides.  (profiles/r5_trio_rows.txt)
+            const bool trio_rows = (key == 9 || key == 12) && um && !blk && !wc &&
+                                   (dp.trio >= 0 ? dp.trio != 0 : (grid.x >= PW_TRIO_ROWS_LO && grid.x <= PW_TRIO_ROWS_HI));
+            if (trio_rows) {
+                if (dp.p_prio < 0) A.p_prio = 3 | (3 << 4);
+                if (key == 9) PW_LAUNCH(h, (pw_spread_duo_kernel<9, 9, true, false, false, true>), grid, dim3(3 * kWave), shm2, st, A, T);
+                else PW_LAUNCH(h, (pw_spread_duo_kernel<12, 12, true, false, false, true>), grid, dim3(3 * kWave), shm2, st, A, T);
                 PW_HIP_CHECK(hipGetLastError());
                 return PW_OK;
             }

@@ -70,6 +70,7 @@ CASES = [
     dict(scenario='simple_spread', num_agents=3, num_envs=4096),            # configs[4] (C5) N = 3 point, full size
     dict(scenario='simple_spread', num_agents=6, num_envs=4096),            # configs[1] (C2) full size
     dict(scenario='simple_spread', num_agents=12, num_envs=333),
+    dict(scenario='simple_spread', num_agents=9, num_envs=700),             # the reference's middle scalability setting (main_scalability_1.py:30): 'trio' = its row-wise three-wave form
     dict(scenario='simple_spread', num_agents=24, num_envs=65),
     dict(scenario='simple_spread', num_agents=48, num_envs=33),
     dict(scenario='simple_spread', num_agents=12, num_envs=4096),           # configs[4] (C5) full size
@@ -681,7 +682,11 @@ def test_bench_path_full_size_every_output_bitwise(case, disp, kernel, kernel_co
     (dict(scenario='simple_spread', num_agents=24, num_envs=4096), 'pw_spread_duo_kernel<24,24,true,false,true>'),
     (dict(scenario='simple_spread', num_agents=48, num_envs=4096), 'pw_spread_duo_kernel<48,48,true,false,true>'),
     (dict(scenario='simple_spread', num_agents=6, num_envs=16384), 'pw_spread_duo_kernel<6,6,true,false,true>'),
-], ids=['N3', 'N12', 'N24', 'N48', 'B16384'])
+    # the reference's scalability settings off the C5 grid (main_scalability_1.py:30: n_agent in [6, 9, 12]): N = 9 never stores blocks
+    # below 700 workgroups and takes the row-wise three-wave form, as N = 12 does on small batches
+    (dict(scenario='simple_spread', num_agents=9, num_envs=4096), 'pw_spread_duo_kernel<9,9,true,false,false,true>'),
+    (dict(scenario='simple_spread', num_agents=12, num_envs=1024), 'pw_spread_duo_kernel<12,12,true,false,false,true>'),
+], ids=['N3', 'N12', 'N24', 'N48', 'B16384', 'N9', 'N12-B1024'])
 def test_c5_points_default_dispatch_rollout_across_two_resets_bitwise(case, kernel):
     """BASELINE configs[4] at full size under the DEFAULT dispatch (what bench.py's sweep times): 52 steps across two
     auto-resets, every output and the final state bit-identical to the float32 oracle."""
