@@ -858,13 +858,17 @@ __global__ void __launch_bounds__((TRIO ? 3 : 2) * kWave) pw_spread_duo_kernel(c
                 for (int i = 0; i < (NT ? NT : N); ++i) acc += s_rew[base + i];
                 PW_STAMP(1);
                 PW_PLANE_STORE(A.rew[tBN + g], r);
-                PW_PLANE_STORE(A.done[tBN + g], (uint8_t)0);
                 if (COLL) { PW_PLANE_STORE(A.coll[tBN + g], (uint64_t)coll); }
                 PW_PLANE_STORE(A.rew_shared[(size_t)t * A.B + env], acc);
             }
             ep_step += 1;
             const bool term = A.max_episode_len > 0 && ep_step >= A.max_episode_len;
-            if (do_rew) { PW_PLANE_STORE(A.terminal[(size_t)t * A.B + env], (uint8_t)(term ? 1 : 0)); }
+            // the two constant-ish planes: in the three-wave form by the observation wave, which has the slack (N = 12, stamps: 1370 busy
+            // cycles of a 3200-cycle step against the reward wave's 2640, the longest wave once the physics wave stopped waiting for its indices)
+            if (TRIO ? do_obs : do_rew) {
+                PW_PLANE_STORE(A.done[tBN + g], (uint8_t)0);
+                PW_PLANE_STORE(A.terminal[(size_t)t * A.B + env], (uint8_t)(term ? 1 : 0));
+            }
             if (term && A.auto_reset) {
                 if (do_obs && A.final_obs) stream_write_obs<LT>(A.final_obs + (tBN + g) * D, L, lmv, px, py, vx, vy);
                 wave_lds_sync();
